@@ -1,0 +1,154 @@
+/*
+ * jsplayer_amd — MI355X-native block-video decode path behind jsplayer's IVideoCodec.
+ *
+ * C ABI (plain pointers and sizes, no C++/torch types).  Every entry point cites the
+ * reference interface it replaces; paths are relative to /root/reference/src.
+ *
+ * Frame buffers follow the reference's contract (MSVideo1.hx:211-214, ScreenPressor.hx:189,
+ * Manager.hx:114-118,379): one int32 per pixel, value 0x00RRGGBB, stride = width ints,
+ * BOTTOM-UP rows, length >= width*height ints, allocated and owned by the CALLER.  The codec
+ * borrows `dst` and keeps it as its "previous frame" until a later frame replaces it; the caller
+ * never passes the current previous frame as `dst` (Manager.hx:424-443,477).
+ *
+ * `dst` may be either
+ *   - a DEVICE pointer (HBM; e.g. from jsp_pool_create): the frame stays on the GPU, or
+ *   - a HOST pointer: the codec decodes into an internal HBM frame and copies the result back
+ *     (compatibility mode for an unmodified Manager; PCIe-bound).
+ * The two kinds must not be mixed on one codec instance.
+ *
+ * Threading (reference: single-threaded, not re-entrant): one thread per codec instance at a
+ * time; distinct instances may be used concurrently from distinct threads.
+ * No exceptions cross this boundary; failures are reported by status + jsp_last_error().
+ */
+#ifndef JSPLAYER_AMD_H
+#define JSPLAYER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jsp_codec jsp_codec;
+typedef struct jsp_pool jsp_pool;
+typedef struct jsp_staged jsp_staged;
+
+/* Codec kinds = the three classes Manager.video_info_cb constructs (Manager.hx:105-110). */
+enum {
+    JSP_CODEC_MSVIDEO1_16 = 1,   /* new MSVideo1_16bit(w,h)            MSVideo1.hx:20-31   */
+    JSP_CODEC_MSVIDEO1_8 = 2,    /* new MSVideo1_8bit(w,h,palette)     MSVideo1.hx:267-274 */
+    JSP_CODEC_SCREENPRESSOR = 3  /* new ScreenPressor(w,h,bpp)         ScreenPressor.hx:53-64 */
+};
+
+/* enum DecoderState (IVideoCodec.hx:5-9) */
+enum { JSP_ZERO_STATE = 0, JSP_IN_PROGRESS = 1, JSP_ERROR_OCCURED = 2 };
+
+/* ---- IVideoCodec (IVideoCodec.hx:16-29) ------------------------------------------------- */
+
+/* Constructors (Manager.hx:105-110).  `palette` = the strf bytes after the 40-byte
+ * BITMAPINFOHEADER (AVIParser.hx:79-85), used by JSP_CODEC_MSVIDEO1_8 only; `bpp` is used by
+ * JSP_CODEC_SCREENPRESSOR only.  `device_id` = HIP device ordinal.  NULL on failure. */
+jsp_codec* jsp_codec_create(int kind, int width, int height, int bpp,
+                            const uint8_t* palette, int palette_bytes, int device_id);
+
+/* StopAndClean() (IVideoCodec.hx:28; MSVideo1.hx:33-35; ScreenPressor.hx:81-84) + release. */
+void jsp_codec_destroy(jsp_codec* c);
+
+/* Preinit(insignificant_lines) (IVideoCodec.hx:18; MSVideo1.hx:37-41,281-291;
+ * ScreenPressor.hx:86-89).  Called once by Manager with 36 (Manager.hx:61,128). */
+int jsp_preinit(jsp_codec* c, int insignificant_lines);
+
+/* PreviousFrame() (IVideoCodec.hx:20): the caller-owned buffer last adopted, or NULL.
+ * Compared BY IDENTITY by the caller (Manager.hx:470-475). */
+int32_t* jsp_previous_frame(jsp_codec* c);
+
+/* IsKeyFrame(data) (IVideoCodec.hx:21; MSVideo1.hx:226-259,395-427; ScreenPressor.hx:96-101).
+ * Pure host-side scan; returns 0/1. */
+int jsp_is_key_frame(jsp_codec* c, const uint8_t* src, size_t n);
+
+/* State() / ContinueI() (IVideoCodec.hx:22,25).  The reference never reports in_progress
+ * (resumable I-decode is disabled, ScreenPressor.hx:210-215,277-285); both return zero_state. */
+int jsp_state(jsp_codec* c);
+int jsp_continue_i(jsp_codec* c);
+
+/* DecompressI(src,dst):DecoderState (IVideoCodec.hx:24; MSVideo1.hx:62-67;
+ * ScreenPressor.hx:117-295).  Returns JSP_ZERO_STATE or JSP_ERROR_OCCURED. */
+int jsp_decompress_i(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst);
+
+/* DecompressP(src,dst):PFrameResult (IVideoCodec.hx:26; MSVideo1.hx:106-209,293-393;
+ * ScreenPressor.hx:302-484).  *data_pnt = the old previous frame ("no change", dst not adopted)
+ * or dst; *significant_changes = 0/1.  Returns JSP_ZERO_STATE, or JSP_ERROR_OCCURED where the
+ * reference would raise (e.g. an MSVideo1 skip code before any frame was decoded). */
+int jsp_decompress_p(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst,
+                     int32_t** data_pnt, int* significant_changes);
+
+/* NeedsIndex() (IVideoCodec.hx:27; MSVideo1.hx:221-224 -> 1; ScreenPressor.hx:486-489 -> 0). */
+int jsp_needs_index(jsp_codec* c);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* jsp_last_error(void);
+
+/* ---- frame pool in HBM (Manager.hx:114-118: num_buffers+1 frame buffers) ---------------- */
+
+jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf);
+int32_t* jsp_pool_buffer(jsp_pool* p, int i); /* device pointer, width*height ints, zeroed */
+int jsp_pool_count(jsp_pool* p);
+void jsp_pool_destroy(jsp_pool* p);
+/* Copy one frame between a device frame buffer and host memory (parity checks, display). */
+int jsp_download(const int32_t* device_frame, int32_t* host, size_t npixels);
+int jsp_upload(int32_t* device_frame, const int32_t* host, size_t npixels);
+
+/* ---- batched / resident-input entry points (extension; same semantics as the calls above) -- */
+
+/* Run the codec's HIP work on `hip_stream` (a hipStream_t, e.g. torch's current stream) instead
+ * of the codec's own stream.  NULL restores the codec's own stream. */
+int jsp_set_stream(jsp_codec* c, void* hip_stream);
+/* Block until everything queued by this codec has finished. */
+int jsp_sync(jsp_codec* c);
+
+/* Equivalent to calling DecompressI on frames 0..n-1 in order (Manager.hx:507 in a loop); device
+ * `dsts` only.  Key-frame-only MSVideo1 batches decode in ONE launch (grid.y = frame). */
+int jsp_decompress_i_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs,
+                           const size_t* lens, int32_t* const* dsts);
+
+/* Two-step form of the batch above, for measuring with inputs resident in HBM:
+ *   jsp_stage_batch   host stage (parse / entropy -> descriptor tables) + H2D, untimed by callers;
+ *   jsp_staged_decode queues the reconstruction kernels for the whole batch (asynchronous:
+ *                     follow with jsp_sync or events on the stream given to jsp_set_stream);
+ * `is_key[i]` selects DecompressI (non-zero) or DecompressP (zero) semantics for frame i
+ * (NULL = all key frames).  Staging advances the codec's host-side state (entropy models,
+ * previous-frame chain) exactly as the per-frame calls would; a staged batch may be decoded
+ * any number of times into the same `dsts`. */
+jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs,
+                            const size_t* lens, const uint8_t* is_key, int32_t* const* dsts);
+int jsp_staged_decode(jsp_codec* c, jsp_staged* s);
+void jsp_staged_destroy(jsp_staged* s);
+
+/* Accounting for a staged batch (bench.py roofline): */
+typedef struct jsp_staged_info {
+    uint64_t frames;
+    uint64_t pixels;           /* width*height*frames */
+    uint64_t stream_bytes;     /* compressed bytes consumed (S in SURVEY.md 8d) */
+    uint64_t descriptor_bytes; /* bytes of host-built tables resident in HBM */
+    uint64_t units_coded;      /* MSVideo1: coded 4x4 blocks; ScreenPressor: data pixels */
+    uint64_t units_copied;     /* MSVideo1: skipped blocks; ScreenPressor: pixels fetched from prev */
+    uint64_t runs;             /* ScreenPressor run descriptors (R) */
+    uint64_t algorithmic_bytes;/* SURVEY.md 8(d) formula for this batch */
+    uint64_t kernel_launches;  /* launches jsp_staged_decode issues */
+    double host_stage_ms;      /* wall time of the host parse / entropy stage */
+    double h2d_ms;             /* wall time of the uploads */
+} jsp_staged_info;
+int jsp_staged_get_info(const jsp_staged* s, jsp_staged_info* out);
+
+/* Per-frame results of a staged batch: status[i] (DecoderState), adopted[i] (1 if dsts[i] became
+ * the previous frame), significant[i] (valid after jsp_staged_decode + jsp_sync). */
+int jsp_staged_results(jsp_staged* s, int* status, int* adopted, int* significant);
+
+/* Library/build identification: "jsplayer_amd <version> gfx950". */
+const char* jsp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JSPLAYER_AMD_H */

@@ -1,0 +1,238 @@
+"""Host-side mirror of jsplayer's IVideoCodec plugin surface over the C ABI.
+
+Same class names, method names, argument meaning and results as the reference
+(IVideoCodec.hx:16-29; MSVideo1.hx:8,262; ScreenPressor.hx:19), so code written against the
+Haxe interface reads the same here:
+
+    dec = MSVideo1_16bit(320, 240)
+    dec.Preinit(36)
+    state = dec.DecompressI(frame_bytes, buf)          # DecoderState
+    res = dec.DecompressP(frame_bytes, other_buf)      # PFrameResult(data_pnt, significant_changes)
+    res.data_pnt is dec.PreviousFrame()                # identity, as Manager.hx:516 relies on
+
+Frame buffers are caller-owned int32 arrays of at least width*height elements, 0x00RRGGBB,
+bottom-up (Manager.hx:114-118): a CUDA/HIP `torch.int32` tensor (the frame stays in HBM) or a
+C-contiguous `numpy.int32` array (host-pointer compatibility mode).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Any, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+class DecoderState(enum.IntEnum):
+    """IVideoCodec.hx:5-9"""
+    zero_state = 0
+    in_progress = 1
+    error_occured = 2
+
+
+@dataclass
+class PFrameResult:
+    """IVideoCodec.hx:11-14"""
+    data_pnt: Any
+    significant_changes: bool
+
+
+class CodecError(RuntimeError):
+    pass
+
+
+def _src_arg(src):
+    """bytes / bytearray / memoryview / numpy uint8 -> (object to keep alive, pointer, length)"""
+    if src is None:
+        return None, None, 0
+    if isinstance(src, (bytes, bytearray)):
+        keep = bytes(src) if isinstance(src, bytearray) else src
+        return keep, C.cast(C.c_char_p(keep), C.c_void_p), len(keep)
+    arr = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src,
+                               dtype=np.uint8)
+    return arr, C.c_void_p(arr.ctypes.data), arr.size
+
+
+def _frame_ptr(buf, npixels: int) -> int:
+    """Address of a caller-owned frame buffer (torch device tensor or numpy host array)."""
+    if isinstance(buf, np.ndarray):
+        if buf.dtype != np.int32 or not buf.flags["C_CONTIGUOUS"] or buf.size < npixels:
+            raise CodecError("host frame buffer must be C-contiguous int32 with >= width*height elements")
+        return buf.ctypes.data
+    # torch tensor (duck-typed so importing this module does not import torch)
+    if hasattr(buf, "data_ptr"):
+        import torch
+        if buf.dtype != torch.int32 or not buf.is_contiguous() or buf.numel() < npixels:
+            raise CodecError("frame tensor must be contiguous int32 with >= width*height elements")
+        return buf.data_ptr()
+    raise CodecError(f"unsupported frame buffer type {type(buf)!r}")
+
+
+class _NativeCodec:
+    """Common part of the three codec classes: owns one jsp_codec handle."""
+
+    _kind = 0
+
+    def __init__(self, width: int, height: int, bpp: int = 0, palette: Optional[bytes] = None,
+                 device: int = 0):
+        self.X, self.Y = int(width), int(height)
+        self._lib = N.lib()
+        pal = bytes(palette) if palette is not None else None
+        self._h = self._lib.jsp_codec_create(self._kind, self.X, self.Y, int(bpp), pal,
+                                             len(pal) if pal else 0, int(device))
+        if not self._h:
+            raise CodecError(N.last_error())
+        self._bufs = {}  # address -> caller object, to hand identical objects back
+
+    # -- IVideoCodec ------------------------------------------------------------------------
+    def Preinit(self, insignificant_lines: int) -> None:
+        if self._lib.jsp_preinit(self._h, int(insignificant_lines)) != 0:
+            raise CodecError(N.last_error())
+
+    def PreviousFrame(self):
+        addr = self._lib.jsp_previous_frame(self._h)
+        return self._bufs.get(addr) if addr else None
+
+    def IsKeyFrame(self, data) -> bool:
+        keep, p, n = _src_arg(data)
+        return bool(self._lib.jsp_is_key_frame(self._h, p, n))
+
+    def State(self) -> DecoderState:
+        return DecoderState(self._lib.jsp_state(self._h))
+
+    def ContinueI(self) -> DecoderState:
+        return DecoderState(self._lib.jsp_continue_i(self._h))
+
+    def DecompressI(self, src, dst) -> DecoderState:
+        keep, p, n = _src_arg(src)
+        addr = _frame_ptr(dst, self.X * self.Y)
+        self._bufs[addr] = dst
+        return DecoderState(self._lib.jsp_decompress_i(self._h, p, n, C.c_void_p(addr)))
+
+    def DecompressP(self, src, dst) -> PFrameResult:
+        keep, p, n = _src_arg(src)
+        addr = _frame_ptr(dst, self.X * self.Y)
+        self._bufs[addr] = dst
+        out_ptr = C.c_void_p()
+        signif = C.c_int(0)
+        rc = self._lib.jsp_decompress_p(self._h, p, n, C.c_void_p(addr), C.byref(out_ptr), C.byref(signif))
+        if rc != 0:
+            # the reference raises out of DecompressP here (e.g. TypeError on a null prevFrame)
+            raise CodecError(N.last_error())
+        data = self._bufs.get(out_ptr.value) if out_ptr.value else None
+        return PFrameResult(data, bool(signif.value))
+
+    def NeedsIndex(self) -> bool:
+        return bool(self._lib.jsp_needs_index(self._h))
+
+    def StopAndClean(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.jsp_codec_destroy(self._h)
+            self._h = None
+        self._bufs = {}
+
+    # -- batched / resident-input extension ----------------------------------------------------
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        self._lib.jsp_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None)
+
+    def sync(self) -> None:
+        if self._lib.jsp_sync(self._h) != 0:
+            raise CodecError(N.last_error())
+
+    def stage_batch(self, srcs: Sequence, dsts: Sequence, is_key: Optional[Sequence[bool]] = None) -> "StagedBatch":
+        n = len(srcs)
+        if len(dsts) != n:
+            raise CodecError("srcs and dsts differ in length")
+        keeps, ptrs, lens = [], (C.c_void_p * n)(), (C.c_size_t * n)()
+        dptrs = (C.c_void_p * n)()
+        for i, (s, d) in enumerate(zip(srcs, dsts)):
+            keep, p, ln = _src_arg(s)
+            keeps.append(keep)
+            ptrs[i] = p.value if p is not None else None
+            lens[i] = ln
+            addr = _frame_ptr(d, self.X * self.Y)
+            self._bufs[addr] = d
+            dptrs[i] = addr
+        keys = bytes(bytearray(1 if k else 0 for k in is_key)) if is_key is not None else None
+        h = self._lib.jsp_stage_batch(self._h, n, ptrs, lens, keys, dptrs)
+        if not h:
+            raise CodecError(N.last_error())
+        return StagedBatch(self, h, n)
+
+    def DecompressI_batch(self, srcs: Sequence, dsts: Sequence) -> DecoderState:
+        st = self.stage_batch(srcs, dsts)
+        try:
+            st.decode()
+            self.sync()
+            status, _, _ = st.results()
+            bad = [s for s in status if s != 0]
+            return DecoderState(bad[0] if bad else 0)
+        finally:
+            st.close()
+
+    def __del__(self):
+        try:
+            self.StopAndClean()
+        except Exception:
+            pass
+
+
+class StagedBatch:
+    """A batch whose descriptor tables are resident in HBM (jsp_stage_batch)."""
+
+    def __init__(self, codec: _NativeCodec, handle: int, n: int):
+        self._codec, self._h, self.n = codec, handle, n
+
+    def decode(self) -> None:
+        """Queue the reconstruction kernels (asynchronous on the codec's stream)."""
+        if self._codec._lib.jsp_staged_decode(self._codec._h, self._h) != 0:
+            raise CodecError(N.last_error())
+
+    def info(self) -> dict:
+        out = N.StagedInfo()
+        self._codec._lib.jsp_staged_get_info(self._h, C.byref(out))
+        return out.as_dict()
+
+    def results(self):
+        st, ad, sg = (C.c_int * self.n)(), (C.c_int * self.n)(), (C.c_int * self.n)()
+        self._codec._lib.jsp_staged_results(self._h, st, ad, sg)
+        return list(st), list(ad), list(sg)
+
+    def close(self) -> None:
+        if self._h:
+            self._codec._lib.jsp_staged_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MSVideo1_16bit(_NativeCodec):
+    """MSVideo1.hx:8-260 — `new MSVideo1_16bit(width, height)`"""
+    _kind = N.JSP_CODEC_MSVIDEO1_16
+
+    def __init__(self, width: int, height: int, device: int = 0):
+        super().__init__(width, height, 16, None, device)
+
+
+class MSVideo1_8bit(_NativeCodec):
+    """MSVideo1.hx:262-429 — `new MSVideo1_8bit(width, height, palette)`; `palette` = the strf
+    bytes after the BITMAPINFOHEADER (RGBQUADs), AVIParser.hx:79-85."""
+    _kind = N.JSP_CODEC_MSVIDEO1_8
+
+    def __init__(self, width: int, height: int, palette: bytes, device: int = 0):
+        super().__init__(width, height, 8, palette, device)
+
+
+class ScreenPressor(_NativeCodec):
+    """ScreenPressor.hx:19-490 — `new ScreenPressor(width, height, bits_per_pixel)`"""
+    _kind = N.JSP_CODEC_SCREENPRESSOR
+
+    def __init__(self, width: int, height: int, bits_per_pixel: int, device: int = 0):
+        super().__init__(width, height, bits_per_pixel, None, device)

@@ -1,0 +1,65 @@
+// Internal C++ shape of the C ABI objects (include/jsplayer_amd.h).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "../../include/jsplayer_amd.h"
+#include "common.h"
+
+// One frame of a batch handed to the host stage.
+struct jsp_frame_in {
+    const uint8_t* src;
+    size_t n;
+    bool key;      // DecompressI (true) or DecompressP (false) semantics
+    int32_t* dst;  // DEVICE pointer
+};
+
+// A staged batch: descriptor tables resident in HBM + the launch plan.
+struct jsp_staged {
+    virtual ~jsp_staged() = default;
+    virtual void decode(hipStream_t stream) = 0;  // asynchronous
+    jsp_staged_info info{};
+    std::vector<int> status, adopted, significant;
+    // significance words written by the kernels (one per frame); -1 in `significant`
+    // marks "take it from the device word"
+    jsp::DeviceBuffer d_signif;
+    jsp::PinnedBuffer h_signif;
+    bool decoded = false;
+    void finish_results();  // after the stream has been synchronised
+};
+
+struct jsp_codec {
+    int kind = 0;
+    int X = 0, Y = 0;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // Caller-visible previous frame (identity) and where its pixels live in HBM.
+    int32_t* prev_caller = nullptr;
+    int32_t* prev_dev = nullptr;
+
+    // Host-pointer compatibility mode: two internal HBM frames used alternately.
+    int ptr_mode = 0;  // 0 unknown, 1 device pointers, 2 host pointers
+    jsp::DeviceBuffer compat[2];
+
+    std::unique_ptr<jsp_staged> scratch;  // reused by the per-frame entry points
+
+    virtual ~jsp_codec();
+    virtual int preinit(int lines) = 0;
+    virtual int is_key_frame(const uint8_t* src, size_t n) = 0;
+    virtual int needs_index() = 0;
+    // Host stage for `frames` (advances prev_dev / models), returns a staged batch.
+    // `reuse` may be a previous result of this codec whose buffers can be recycled.
+    virtual jsp_staged* stage(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse) = 0;
+    // True when a frame of this batch may leave some dst pixels unwritten (so a host-mode dst
+    // has to be uploaded first to keep them as the caller had them).
+    virtual bool may_leave_pixels(const jsp_frame_in& f) = 0;
+
+    void init_device(int device_id);
+    void activate();
+};
+
+// Factories (one per codec family).
+jsp_codec* jsp_make_msv1(int bits, int w, int h, const uint8_t* palette, int palette_bytes);
+jsp_codec* jsp_make_screenpressor(int w, int h, int bpp);

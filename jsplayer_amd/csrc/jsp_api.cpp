@@ -1,0 +1,312 @@
+// extern "C" surface of libjsplayer_amd.so (declared in include/jsplayer_amd.h).
+#include <mutex>
+
+#include "codec.h"
+
+namespace jsp {
+std::string& last_error_slot() {
+    thread_local std::string s;
+    return s;
+}
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_slot() = buf;
+}
+}  // namespace jsp
+
+using namespace jsp;
+
+// ---- jsp_codec common parts ---------------------------------------------------------------
+
+jsp_codec::~jsp_codec() {
+    scratch.reset();
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+void jsp_codec::init_device(int device_id) {
+    int count = 0;
+    JSP_HIP(hipGetDeviceCount(&count));
+    if (count <= 0) throw std::runtime_error("no HIP device visible: the HIP path is mandatory, there is no CPU fallback");
+    if (device_id < 0 || device_id >= count) throw std::runtime_error("device_id out of range");
+    device = device_id;
+    JSP_HIP(hipSetDevice(device));
+    JSP_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    stream = own_stream;
+}
+
+void jsp_codec::activate() { JSP_HIP(hipSetDevice(device)); }
+
+void jsp_staged::finish_results() {
+    if (!decoded) return;
+    const auto* words = static_cast<const uint32_t*>(h_signif.p);
+    for (size_t i = 0; i < significant.size(); ++i)
+        if (significant[i] < 0) significant[i] = words[i] ? 1 : 0;
+}
+
+struct jsp_pool {
+    int device = 0;
+    int X = 0, Y = 0;
+    std::vector<int32_t*> bufs;
+};
+
+namespace {
+
+// 1 = device memory, 2 = host memory
+int classify_pointer(const void* p) {
+    hipPointerAttribute_t attr{};
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd memory: not known to HIP
+        return 2;
+    }
+    return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? 1 : 2;
+}
+
+template <class F>
+int guarded(F&& f, int on_error = JSP_ERROR_OCCURED) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        set_error("%s", e.what());
+        return on_error;
+    }
+}
+
+// Shared body of DecompressI / DecompressP.
+int decompress_one(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool key, int32_t** data_pnt,
+                   int* significant) {
+    if (!c || !dst || (!src && n)) {
+        set_error("null argument");
+        return JSP_ERROR_OCCURED;
+    }
+    c->activate();
+    const int mode = classify_pointer(dst);
+    if (c->ptr_mode == 0) c->ptr_mode = mode;
+    if (c->ptr_mode != mode) {
+        set_error("host and device frame buffers mixed on one codec instance");
+        return JSP_ERROR_OCCURED;
+    }
+    const size_t npx = (size_t)c->X * c->Y;
+    jsp_frame_in f{src, n, key, dst};
+    if (mode == 2) {
+        for (auto& b : c->compat) b.reserve(npx * sizeof(int32_t) + 16);
+        int32_t* d0 = static_cast<int32_t*>(c->compat[0].p);
+        int32_t* d1 = static_cast<int32_t*>(c->compat[1].p);
+        f.dst = (c->prev_dev == d0) ? d1 : d0;
+        if (c->may_leave_pixels(f))
+            JSP_HIP(hipMemcpyAsync(f.dst, dst, npx * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<jsp_frame_in> frames{f};
+    jsp_staged* st = c->stage(frames, c->scratch.get());
+    if (st != c->scratch.get()) c->scratch.reset(st);
+    st->decode(c->stream);
+    // the reference paints dst in place, adopted or not: hand back whatever was written
+    if (mode == 2 && (st->info.units_coded || st->info.units_copied))
+        JSP_HIP(hipMemcpyAsync(dst, f.dst, npx * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    JSP_HIP(hipStreamSynchronize(c->stream));
+    st->finish_results();
+    if (st->adopted[0]) c->prev_caller = dst;
+    if (data_pnt) *data_pnt = c->prev_caller;
+    if (significant) *significant = st->significant[0];
+    if (st->status[0] != JSP_ZERO_STATE) set_error("decode aborted: the reference raises on this stream");
+    return st->status[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jsp_last_error(void) { return last_error_slot().c_str(); }
+const char* jsp_version(void) { return "jsplayer_amd 0.1 gfx950"; }
+
+jsp_codec* jsp_codec_create(int kind, int width, int height, int bpp, const uint8_t* palette,
+                            int palette_bytes, int device_id) {
+    try {
+        if (width <= 0 || height <= 0) throw std::runtime_error("bad frame size");
+        if ((uint64_t)width * height > (1ull << 28)) throw std::runtime_error("frame too large");
+        std::unique_ptr<jsp_codec> c;
+        switch (kind) {
+            case JSP_CODEC_MSVIDEO1_16: c.reset(jsp_make_msv1(16, width, height, nullptr, 0)); break;
+            case JSP_CODEC_MSVIDEO1_8: c.reset(jsp_make_msv1(8, width, height, palette, palette_bytes)); break;
+            case JSP_CODEC_SCREENPRESSOR: c.reset(jsp_make_screenpressor(width, height, bpp)); break;
+            default: throw std::runtime_error("unknown codec kind");
+        }
+        c->init_device(device_id);
+        return c.release();
+    } catch (const std::exception& e) {
+        set_error("%s", e.what());
+        return nullptr;
+    }
+}
+
+void jsp_codec_destroy(jsp_codec* c) {
+    if (!c) return;
+    try {
+        c->activate();
+        (void)hipStreamSynchronize(c->stream);
+    } catch (...) {
+    }
+    delete c;
+}
+
+int jsp_preinit(jsp_codec* c, int lines) {
+    return guarded([&] { return c->preinit(lines); });
+}
+
+int32_t* jsp_previous_frame(jsp_codec* c) { return c ? c->prev_caller : nullptr; }
+
+int jsp_is_key_frame(jsp_codec* c, const uint8_t* src, size_t n) {
+    return guarded([&] { return c->is_key_frame(src, n); }, 0);
+}
+
+int jsp_state(jsp_codec*) { return JSP_ZERO_STATE; }
+int jsp_continue_i(jsp_codec*) { return JSP_ZERO_STATE; }
+int jsp_needs_index(jsp_codec* c) { return c ? c->needs_index() : 0; }
+
+int jsp_decompress_i(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst) {
+    return guarded([&] { return decompress_one(c, src, n, dst, true, nullptr, nullptr); });
+}
+
+int jsp_decompress_p(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, int32_t** data_pnt,
+                     int* significant_changes) {
+    if (data_pnt) *data_pnt = c ? c->prev_caller : nullptr;
+    if (significant_changes) *significant_changes = 0;
+    return guarded([&] { return decompress_one(c, src, n, dst, false, data_pnt, significant_changes); });
+}
+
+// ---- pool ---------------------------------------------------------------------------------
+
+jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
+    try {
+        if (width <= 0 || height <= 0 || nbuf <= 0) throw std::runtime_error("bad pool shape");
+        int count = 0;
+        JSP_HIP(hipGetDeviceCount(&count));
+        if (device_id < 0 || device_id >= count) throw std::runtime_error("device_id out of range");
+        JSP_HIP(hipSetDevice(device_id));
+        auto p = std::make_unique<jsp_pool>();
+        p->device = device_id;
+        p->X = width;
+        p->Y = height;
+        const size_t bytes = (size_t)width * height * sizeof(int32_t);
+        for (int i = 0; i < nbuf; ++i) {
+            void* d = nullptr;
+            JSP_HIP(hipMalloc(&d, bytes));
+            p->bufs.push_back(static_cast<int32_t*>(d));
+            JSP_HIP(hipMemset(d, 0, bytes));
+        }
+        return p.release();
+    } catch (const std::exception& e) {
+        set_error("%s", e.what());
+        return nullptr;
+    }
+}
+int32_t* jsp_pool_buffer(jsp_pool* p, int i) {
+    return (p && i >= 0 && i < (int)p->bufs.size()) ? p->bufs[i] : nullptr;
+}
+int jsp_pool_count(jsp_pool* p) { return p ? (int)p->bufs.size() : 0; }
+void jsp_pool_destroy(jsp_pool* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (auto* b : p->bufs) (void)hipFree(b);
+    delete p;
+}
+int jsp_download(const int32_t* device_frame, int32_t* host, size_t npixels) {
+    return guarded([&] {
+        JSP_HIP(hipMemcpy(host, device_frame, npixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+int jsp_upload(int32_t* device_frame, const int32_t* host, size_t npixels) {
+    return guarded([&] {
+        JSP_HIP(hipMemcpy(device_frame, host, npixels * sizeof(int32_t), hipMemcpyHostToDevice));
+        return 0;
+    });
+}
+
+// ---- batched / staged ---------------------------------------------------------------------
+
+int jsp_set_stream(jsp_codec* c, void* hip_stream) {
+    if (!c) return JSP_ERROR_OCCURED;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return 0;
+}
+
+int jsp_sync(jsp_codec* c) {
+    return guarded([&] {
+        c->activate();
+        JSP_HIP(hipStreamSynchronize(c->stream));
+        return 0;
+    });
+}
+
+jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs, const size_t* lens,
+                            const uint8_t* is_key, int32_t* const* dsts) {
+    try {
+        if (!c || nframes < 0 || (nframes && (!srcs || !lens || !dsts))) throw std::runtime_error("null argument");
+        c->activate();
+        std::vector<jsp_frame_in> frames(nframes);
+        for (int i = 0; i < nframes; ++i) {
+            if (!dsts[i]) throw std::runtime_error("null dst in batch");
+            if (classify_pointer(dsts[i]) != 1) throw std::runtime_error("batch entry points take device frame buffers only");
+            frames[i] = jsp_frame_in{srcs[i], lens[i], is_key ? is_key[i] != 0 : true, dsts[i]};
+        }
+        if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
+        if (nframes) c->ptr_mode = 1;
+        jsp_staged* st = c->stage(frames, nullptr);
+        for (int i = 0; i < nframes; ++i)
+            if (st->adopted[i]) c->prev_caller = dsts[i];
+        return st;
+    } catch (const std::exception& e) {
+        set_error("%s", e.what());
+        return nullptr;
+    }
+}
+
+int jsp_staged_decode(jsp_codec* c, jsp_staged* s) {
+    return guarded([&] {
+        if (!c || !s) throw std::runtime_error("null argument");
+        c->activate();
+        s->decode(c->stream);
+        return 0;
+    });
+}
+
+void jsp_staged_destroy(jsp_staged* s) { delete s; }
+
+int jsp_staged_get_info(const jsp_staged* s, jsp_staged_info* out) {
+    if (!s || !out) return JSP_ERROR_OCCURED;
+    *out = s->info;
+    return 0;
+}
+
+int jsp_staged_results(jsp_staged* s, int* status, int* adopted, int* significant) {
+    if (!s) return JSP_ERROR_OCCURED;
+    s->finish_results();
+    for (size_t i = 0; i < s->status.size(); ++i) {
+        if (status) status[i] = s->status[i];
+        if (adopted) adopted[i] = s->adopted[i];
+        if (significant) significant[i] = s->significant[i] < 0 ? 0 : s->significant[i];
+    }
+    return 0;
+}
+
+int jsp_decompress_i_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs, const size_t* lens,
+                           int32_t* const* dsts) {
+    jsp_staged* st = jsp_stage_batch(c, nframes, srcs, lens, nullptr, dsts);
+    if (!st) return JSP_ERROR_OCCURED;
+    int rc = jsp_staged_decode(c, st);
+    if (rc == 0) rc = jsp_sync(c);
+    if (rc == 0) {
+        st->finish_results();
+        for (int s : st->status)
+            if (s != JSP_ZERO_STATE) rc = s;
+    }
+    jsp_staged_destroy(st);
+    return rc;
+}
+
+}  // extern "C"

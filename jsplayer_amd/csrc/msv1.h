@@ -1,0 +1,62 @@
+// MSVideo1 (CRAM) path: host parse -> per-block descriptor table -> HIP block reconstruction.
+// Reference behaviour: MSVideo1.hx (see include/jsplayer_amd.h for the per-call citations).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+namespace jsp {
+
+// Descriptor = one uint32 per 4x4 block, raster order over the (bottom-up) buffer:
+// byte offset of the block's code word inside the batch's stream buffer, or one of:
+constexpr uint32_t MSV1_DESC_SKIP = 0xFFFFFFFFu;       // copy the block from the previous frame
+constexpr uint32_t MSV1_DESC_UNTOUCHED = 0xFFFFFFFEu;  // leave dst as it is (end marker / abort)
+
+// Per-frame launch record, read by every workgroup of that frame (grid.y = frame).
+struct Msv1FrameArgs {
+    int32_t* dst;
+    const int32_t* prev;   // may be null when no block is a skip and no compare is requested
+    uint32_t* signif;      // device word OR-ed with 1 when a compared pixel differs
+    uint32_t stream_end;   // absolute offset one past this frame's last stream byte
+    uint32_t desc_base;    // index of this frame's first descriptor
+    uint32_t cmp_row_lo;   // first pixel row taking part in the stage-2 compare; ~0u = none
+    uint32_t pad;
+};
+
+struct Msv1Geometry {
+    int bits;  // 16 or 8
+    int X, Y;
+    int nbx, nby;
+    int nblocks;
+};
+
+struct Msv1Parse {
+    bool early_out = false;   // 16-bit only: empty / all-skip short stream -> prevFrame untouched
+    bool changes = false;     // at least one coded block (dst gets adopted)
+    bool s1 = false;          // stage-1 significance (coded block in a significant block row)
+    bool aborted = false;     // skip block with no previous frame: the reference raises
+    uint64_t n_coded = 0, n_skipped = 0, n_untouched = 0;
+    uint64_t consumed = 0;    // stream bytes walked over
+};
+
+// Host parse (sequential: code lengths are data dependent, MSVideo1.hx:128-181,311-364).
+// Writes geo.nblocks descriptors.  `base` is added to every offset (position of this frame's
+// bytes in the batch stream buffer).  `block_changes` is the codec's persistent per-row state.
+void msv1_parse(const Msv1Geometry& geo, const uint8_t* src, size_t n, bool have_prev,
+                size_t size_of_just_skips, int insignificant_blocks, uint32_t base,
+                uint32_t* desc, std::vector<uint8_t>& block_changes, Msv1Parse& out);
+
+bool msv1_just_skip_blocks(const Msv1Geometry& geo, const uint8_t* src, size_t n);
+int msv1_is_key_frame(const Msv1Geometry& geo, const uint8_t* src, size_t n);
+
+// Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
+void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
+                        const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
+                        bool vec_ok, hipStream_t stream);
+// Stage-2 compare over the pixels no block covers (X&3 / Y&3 remainders), MSVideo1.hx:197-203.
+void msv1_launch_edge_compare(const Msv1Geometry& geo, const Msv1FrameArgs* d_frames, int nframes,
+                              hipStream_t stream);
+
+}  // namespace jsp

@@ -1,0 +1,227 @@
+// MSVideo1 4x4 block reconstruction for gfx950 (MI355X).  Integer work, HBM-bound, no MFMA.
+//
+// One work-item per 4x4 block, blocks in raster order, so a wave covers 64 consecutive blocks:
+//   * descriptor reads are one coalesced dword per lane;
+//   * the wave's code words are neighbours in the stream (2..18 bytes per lane);
+//   * each of the four row stores is 16 B per lane = up to 1 KiB contiguous per wave.
+// grid.y = frame: a key-frame-only batch is one launch.
+//
+// Reference semantics reproduced per block: MSVideo1.hx:124-181 (16-bit), :307-364 (8-bit),
+// copy_block :74-84, fromRGB15 :211-214, stage-2 significance compare :195-204.
+#include "msv1.h"
+
+namespace jsp {
+namespace {
+
+constexpr int WG = 256;
+
+__device__ __forceinline__ uint32_t rgb555_to_rgb32(uint32_t c) {
+    return ((c & 0x1Fu) << 3) | ((c & 0x3E0u) << 6) | ((c & 0x7C00u) << 9);
+}
+
+// Little-endian 16-bit read at an even offset; 0 when either byte lies beyond `end`
+// (the reference reads NaN there, which every later expression turns into 0).
+__device__ __forceinline__ uint32_t ld16(const uint8_t* __restrict__ s, uint32_t o, uint32_t end) {
+    return (o + 1u < end) ? (uint32_t) * reinterpret_cast<const uint16_t*>(s + o) : 0u;
+}
+
+template <int BITS, bool VEC>
+__global__ __launch_bounds__(WG) void msv1_blocks_kernel(
+    const uint8_t* __restrict__ stream, const uint32_t* __restrict__ desc,
+    const Msv1FrameArgs* __restrict__ frames, const int32_t* __restrict__ palette, int nblocks,
+    int nbx, int X) {
+    __shared__ uint32_t s_pal[BITS == 8 ? 256 : 1];
+    if (BITS == 8) {
+        s_pal[threadIdx.x] = (uint32_t)palette[threadIdx.x];
+        __syncthreads();
+    }
+    const Msv1FrameArgs fa = frames[blockIdx.y];
+    const int blk = blockIdx.x * WG + threadIdx.x;
+    if (blk >= nblocks) return;
+    const uint32_t o = desc[fa.desc_base + blk];
+    if (o == MSV1_DESC_UNTOUCHED) return;
+    const int by = blk / nbx;
+    const int bx = blk - by * nbx;
+    const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
+    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst) + di;
+
+    if (o == MSV1_DESC_SKIP) {
+        const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev) + di;
+        if (VEC) {
+            uint4 r0 = *reinterpret_cast<const uint4*>(prev);
+            uint4 r1 = *reinterpret_cast<const uint4*>(prev + X);
+            uint4 r2 = *reinterpret_cast<const uint4*>(prev + 2 * (size_t)X);
+            uint4 r3 = *reinterpret_cast<const uint4*>(prev + 3 * (size_t)X);
+            *reinterpret_cast<uint4*>(dst) = r0;
+            *reinterpret_cast<uint4*>(dst + X) = r1;
+            *reinterpret_cast<uint4*>(dst + 2 * (size_t)X) = r2;
+            *reinterpret_cast<uint4*>(dst + 3 * (size_t)X) = r3;
+        } else {
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) dst[(size_t)y * X + x] = prev[(size_t)y * X + x];
+        }
+        return;
+    }
+
+    const uint32_t end = fa.stream_end;
+    // code word: a = low byte, b = high byte; a missing high byte makes the block "solid"
+    const bool b_ok = o + 1u < end;
+    const uint32_t w = b_ok ? (uint32_t) * reinterpret_cast<const uint16_t*>(stream + o)
+                            : (o < end ? (uint32_t)stream[o] : 0u);
+    const uint32_t b = w >> 8;
+    uint32_t c[8];
+    uint32_t flags;
+    if (BITS == 16) {
+        if (b_ok && b < 0x80u) {
+            flags = w ^ 0xFFFFu;
+            const uint32_t q0 = ld16(stream, o + 2u, end);
+            const uint32_t q1 = ld16(stream, o + 4u, end);
+            c[0] = rgb555_to_rgb32(q0);
+            c[1] = rgb555_to_rgb32(q1);
+            if (q0 & 0x8000u) {
+#pragma unroll
+                for (int k = 2; k < 8; ++k) c[k] = rgb555_to_rgb32(ld16(stream, o + 2u + 2u * k, end));
+            } else {
+                c[2] = c[4] = c[6] = c[0];
+                c[3] = c[5] = c[7] = c[1];
+            }
+        } else {
+            flags = 0;
+            const uint32_t v = rgb555_to_rgb32(w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = v;
+        }
+    } else {
+        if (b_ok && b < 0x80u) {
+            flags = w;
+            // first index byte is the colour of SET bits (p2[1]), second of clear bits (p2[0])
+            const uint32_t i0 = (o + 2u < end) ? s_pal[stream[o + 2u]] : 0u;
+            const uint32_t i1 = (o + 3u < end) ? s_pal[stream[o + 3u]] : 0u;
+            c[0] = c[2] = c[4] = c[6] = i1;
+            c[1] = c[3] = c[5] = c[7] = i0;
+        } else if (b_ok && b >= 0x90u) {
+            flags = w ^ 0xFFFFu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = (o + 2u + k < end) ? s_pal[stream[o + 2u + k]] : 0u;
+        } else {
+            flags = 0;
+            const uint32_t v = (o < end) ? s_pal[w & 0xFFu] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = v;
+        }
+    }
+
+    // pixel (x,y): quadrant q = ((y&2)<<1) + (x&2) is static, only the flag bit is dynamic
+    uint32_t px[16];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int q = ((y & 2) << 1) + (x & 2);
+            px[y * 4 + x] = ((flags >> (y * 4 + x)) & 1u) ? c[q + 1] : c[q];
+        }
+
+    if (VEC) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+            *reinterpret_cast<uint4*>(dst + (size_t)y * X) =
+                make_uint4(px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]);
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) dst[(size_t)y * X + x] = px[y * 4 + x];
+    }
+
+    // stage-2 significance: does any pixel at or above row cmp_row_lo differ from prev?
+    // (skipped blocks are equal by construction; only coded blocks can differ)
+    if (fa.cmp_row_lo != 0xFFFFFFFFu) {
+        const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev) + di;
+        bool diff = false;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            if ((uint32_t)(by * 4 + y) >= fa.cmp_row_lo) {
+                if (VEC) {
+                    const uint4 p = *reinterpret_cast<const uint4*>(prev + (size_t)y * X);
+                    diff |= (p.x != px[y * 4]) | (p.y != px[y * 4 + 1]) | (p.z != px[y * 4 + 2]) |
+                            (p.w != px[y * 4 + 3]);
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) diff |= prev[(size_t)y * X + x] != px[y * 4 + x];
+                }
+            }
+        }
+        if (__ballot(diff) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(diff)) - 1)
+            atomicOr(fa.signif, 1u);
+    }
+}
+
+// Pixels outside the block grid (x >= 4*nbx or y >= 4*nby) are never written by the decoder, but
+// the reference's compare loop still covers them (MSVideo1.hx:197-203).
+__global__ __launch_bounds__(WG) void msv1_edge_compare_kernel(const Msv1FrameArgs* __restrict__ frames,
+                                                               int X, int Y, int covered_x, int covered_y) {
+    const Msv1FrameArgs fa = frames[blockIdx.y];
+    if (fa.cmp_row_lo == 0xFFFFFFFFu) return;
+    const int strip = X - covered_x;             // right-hand columns, all rows
+    const long right = (long)strip * Y;
+    const long top = (long)covered_x * (Y - covered_y);  // rows above the grid, covered columns
+    const long total = right + top;
+    bool diff = false;
+    for (long i = (long)blockIdx.x * WG + threadIdx.x; i < total; i += (long)gridDim.x * WG) {
+        int x, y;
+        if (i < right) {
+            y = (int)(i / strip);
+            x = covered_x + (int)(i - (long)y * strip);
+        } else {
+            const long j = i - right;
+            y = covered_y + (int)(j / covered_x);
+            x = (int)(j - (long)(y - covered_y) * covered_x);
+        }
+        if ((uint32_t)y >= fa.cmp_row_lo) {
+            const size_t k = (size_t)y * X + x;
+            diff |= fa.dst[k] != fa.prev[k];
+        }
+    }
+    if (__ballot(diff) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(diff)) - 1)
+        atomicOr(fa.signif, 1u);
+}
+
+}  // namespace
+
+void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
+                        const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
+                        bool vec_ok, hipStream_t stream) {
+    if (geo.nblocks <= 0 || nframes <= 0) return;
+    dim3 grid((geo.nblocks + WG - 1) / WG, nframes), block(WG);
+    if (geo.bits == 16) {
+        if (vec_ok)
+            hipLaunchKernelGGL((msv1_blocks_kernel<16, true>), grid, block, 0, stream, d_stream, d_desc,
+                               d_frames, d_palette, geo.nblocks, geo.nbx, geo.X);
+        else
+            hipLaunchKernelGGL((msv1_blocks_kernel<16, false>), grid, block, 0, stream, d_stream, d_desc,
+                               d_frames, d_palette, geo.nblocks, geo.nbx, geo.X);
+    } else {
+        if (vec_ok)
+            hipLaunchKernelGGL((msv1_blocks_kernel<8, true>), grid, block, 0, stream, d_stream, d_desc,
+                               d_frames, d_palette, geo.nblocks, geo.nbx, geo.X);
+        else
+            hipLaunchKernelGGL((msv1_blocks_kernel<8, false>), grid, block, 0, stream, d_stream, d_desc,
+                               d_frames, d_palette, geo.nblocks, geo.nbx, geo.X);
+    }
+}
+
+void msv1_launch_edge_compare(const Msv1Geometry& geo, const Msv1FrameArgs* d_frames, int nframes,
+                              hipStream_t stream) {
+    const int cx = geo.nbx * 4, cy = geo.nby * 4;
+    if (cx == geo.X && cy == geo.Y) return;
+    const long total = (long)(geo.X - cx) * geo.Y + (long)cx * (geo.Y - cy);
+    if (total <= 0) return;
+    int gx = (int)((total + WG - 1) / WG);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(msv1_edge_compare_kernel, dim3(gx, nframes), dim3(WG), 0, stream, d_frames, geo.X,
+                       geo.Y, cx, cy);
+}
+
+}  // namespace jsp

@@ -1,0 +1,84 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement used as the CHECKER.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
+The classes mirror the reference's IVideoCodec surface on numpy host buffers so that the parity
+tests drive oracle and HIP path with identical calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(ORACLE_PATH)
+        L.orc_msv1_create.restype = C.c_void_p
+        L.orc_msv1_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.orc_msv1_destroy.argtypes = [C.c_void_p]
+        L.orc_msv1_preinit.argtypes = [C.c_void_p, C.c_int]
+        L.orc_msv1_previous_frame.restype = C.c_void_p
+        L.orc_msv1_previous_frame.argtypes = [C.c_void_p]
+        L.orc_msv1_is_key_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.orc_msv1_decompress_i.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        L.orc_msv1_decompress_p.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+class OracleAbort(RuntimeError):
+    """The reference would raise out of the call (uncaught JS TypeError)."""
+
+
+class OracleMSVideo1:
+    def __init__(self, bits, width, height, palette=None):
+        self.L = lib()
+        self.X, self.Y = width, height
+        pal = bytes(palette) if palette else None
+        self.h = self.L.orc_msv1_create(bits, width, height, pal, len(pal) if pal else 0)
+        assert self.h
+        self._bufs = {}
+
+    def Preinit(self, lines):
+        self.L.orc_msv1_preinit(self.h, lines)
+
+    def PreviousFrame(self):
+        a = self.L.orc_msv1_previous_frame(self.h)
+        return self._bufs.get(a) if a else None
+
+    def IsKeyFrame(self, data):
+        data = bytes(data)
+        return bool(self.L.orc_msv1_is_key_frame(self.h, data, len(data)))
+
+    def DecompressI(self, src, dst: np.ndarray):
+        src = bytes(src)
+        self._bufs[dst.ctypes.data] = dst
+        rc = self.L.orc_msv1_decompress_i(self.h, src, len(src), C.c_void_p(dst.ctypes.data))
+        return rc
+
+    def DecompressP(self, src, dst: np.ndarray):
+        src = bytes(src)
+        self._bufs[dst.ctypes.data] = dst
+        out, sg = C.c_void_p(), C.c_int()
+        rc = self.L.orc_msv1_decompress_p(self.h, src, len(src), C.c_void_p(dst.ctypes.data),
+                                          C.byref(out), C.byref(sg))
+        if rc != 0:
+            raise OracleAbort()
+        return (self._bufs.get(out.value) if out.value else None), bool(sg.value)
+
+    def close(self):
+        if self.h:
+            self.L.orc_msv1_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

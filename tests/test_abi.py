@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol
+include/jsplayer_amd.h declares; no compute is attempted without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from jsplayer_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "jsplayer_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_ivideocodec_surface():
+    syms = declared_symbols()
+    for required in ["jsp_codec_create", "jsp_codec_destroy", "jsp_preinit", "jsp_previous_frame",
+                     "jsp_is_key_frame", "jsp_state", "jsp_continue_i", "jsp_decompress_i",
+                     "jsp_decompress_p", "jsp_needs_index"]:
+        assert required in syms
+
+
+def test_library_exports_every_declared_symbol():
+    handle = ctypes.CDLL(N.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(handle, name), f"{name} declared in include/jsplayer_amd.h but not exported"
+
+
+def test_binding_table_matches_header():
+    assert sorted(N.SIGNATURES) == declared_symbols()
+    assert N.lib().jsp_version().decode().startswith("jsplayer_amd")
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from jsplayer_amd import MSVideo1_16bit, CodecError
+    with pytest.raises(CodecError):
+        MSVideo1_16bit(16, 16)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "jsplayer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle/" not in text and "liboracle" not in text and "oracle_binding" not in text, \
+                    f"{f} refers to the oracle"
