@@ -24,10 +24,11 @@ struct Msv1Staged : jsp_staged {
         bool edge_compare;
     };
     std::vector<Group> groups;
+    bool need_signif = false;  // some frame asked for the stage-2 compare
 
     void decode(hipStream_t stream) override {
         if (nframes == 0) return;
-        JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
+        if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
         for (const Group& g : groups) {
             msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p),
@@ -36,8 +37,9 @@ struct Msv1Staged : jsp_staged {
             if (g.edge_compare) msv1_launch_edge_compare(geo, frames + g.first, g.count, stream);
         }
         JSP_HIP(hipGetLastError());
-        JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
-                               stream));
+        if (need_signif)
+            JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
+                                   stream));
         decoded = true;
     }
 };
@@ -200,6 +202,8 @@ struct Msv1Codec : jsp_codec {
             if (st->adopted[i]) prev_dev = f.dst;
         }
         st->vec_ok = vec_ok;
+        st->need_signif = false;
+        for (int v : st->significant) st->need_signif |= v < 0;
         st->info.frames = nf;
         st->info.pixels = (uint64_t)X * Y * nf;
         st->info.descriptor_bytes = sizeof(uint32_t) * (uint64_t)geo.nblocks * nf + sizeof(Msv1FrameArgs) * nf;

@@ -1,0 +1,221 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on identical bytes.  Integer/byte work: the bar is bit-exact frames, identical
+significant_changes and identical "which buffer is prevFrame" answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from jsplayer_amd import CodecError, MSVideo1_16bit, MSVideo1_8bit
+from jsplayer_amd import streamgen as sg
+from oracle_binding import OracleAbort, OracleMSVideo1
+from test_msvideo1_oracle import KATS, run_kat
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_mod():
+    import torch
+    return torch
+
+
+def make_gpu(bits, w, h, pal=None):
+    return MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal or b"")
+
+
+def dev_buf(n, fill=0):
+    torch = torch_mod()
+    return torch.full((n,), fill, dtype=torch.int32, device="cuda")
+
+
+def to_np(t):
+    return t.cpu().numpy() if hasattr(t, "cpu") else t
+
+
+def test_native_library_is_the_one_loaded():
+    from jsplayer_amd import _native
+    assert os.path.exists(_native.LIB_PATH)
+    assert _native.lib().jsp_version().decode().endswith("gfx950")
+
+
+@pytest.mark.parametrize("kat", KATS, ids=[k["name"] for k in KATS])
+def test_known_answers_device_buffers(kat):
+    run_kat(make_gpu, dev_buf, to_np, kat)
+
+
+@pytest.mark.parametrize("kat", KATS, ids=[k["name"] for k in KATS])
+def test_known_answers_host_buffers(kat):
+    run_kat(make_gpu, lambda n, fill: np.full(n, fill, dtype=np.int32), to_np, kat)
+
+
+def drive_pair(bits, w, h, frames, keys, pal, lines=36, nbuf=3, host=False, prefill=0x00A5A5A5):
+    """Feed the same clip to the oracle and to the HIP path with Manager's buffer protocol and
+    compare everything observable after every frame."""
+    orc = OracleMSVideo1(bits, w, h, pal)
+    gpu = make_gpu(bits, w, h, pal)
+    orc.Preinit(lines)
+    gpu.Preinit(lines)
+    obufs = [np.full(w * h, prefill, dtype=np.int32) for _ in range(nbuf)]
+    gbufs = [np.full(w * h, prefill, dtype=np.int32) if host else dev_buf(w * h, prefill) for _ in range(nbuf)]
+    for i, (src, key) in enumerate(zip(frames, keys)):
+        oprev, gprev = orc.PreviousFrame(), gpu.PreviousFrame()
+        oi = next(k for k in range(nbuf) if obufs[k] is not oprev)
+        gi = next(k for k in range(nbuf) if gbufs[k] is not gprev)
+        assert oi == gi, "buffer choice diverged"
+        assert gpu.IsKeyFrame(src) == orc.IsKeyFrame(src)
+        if key:
+            assert orc.DecompressI(src, obufs[oi]) == 0
+            assert gpu.DecompressI(src, gbufs[gi]) == 0
+        else:
+            try:
+                odata, osig = orc.DecompressP(src, obufs[oi])
+            except OracleAbort:
+                with pytest.raises(CodecError):
+                    gpu.DecompressP(src, gbufs[gi])
+                odata = None
+            else:
+                res = gpu.DecompressP(src, gbufs[gi])
+                assert res.significant_changes == osig, f"frame {i}: significant_changes"
+                assert (res.data_pnt is gbufs[gi]) == (odata is obufs[oi]), f"frame {i}: data_pnt identity"
+                assert (res.data_pnt is None) == (odata is None)
+        onow, gnow = orc.PreviousFrame(), gpu.PreviousFrame()
+        assert (onow is None) == (gnow is None)
+        if onow is not None:
+            assert [k for k in range(nbuf) if obufs[k] is onow] == [k for k in range(nbuf) if gbufs[k] is gnow]
+        # every buffer, adopted or not, must hold the same pixels (the reference paints in place)
+        for k in range(nbuf):
+            assert np.array_equal(obufs[k], to_np(gbufs[k])), f"frame {i}: buffer {k} differs"
+    gpu.StopAndClean()
+
+
+SIZES = [(4, 4), (16, 16), (64, 48), (320, 240), (100, 52), (37, 23), (1920, 1080)]
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+@pytest.mark.parametrize("size", SIZES, ids=[f"{w}x{h}" for w, h in SIZES])
+def test_clip_parity_device(bits, size):
+    w, h = size
+    n = 4 if w * h > 500000 else 10
+    frames, keys, pal = sg.msv1_clip(20 + bits, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 40.0), key_every=5)
+    drive_pair(bits, w, h, frames, keys, pal)
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+@pytest.mark.parametrize("size", [(64, 48), (37, 23), (320, 240)], ids=["64x48", "37x23", "320x240"])
+def test_clip_parity_host_pointers(bits, size):
+    w, h = size
+    frames, keys, pal = sg.msv1_clip(40 + bits, w, h, 8, bits=bits, p_mix=sg.msv1_p_mix(0.5, 9.0))
+    drive_pair(bits, w, h, frames, keys, pal, host=True)
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+@pytest.mark.parametrize("mix", [sg.MIX_ALL_SOLID, sg.MIX_ALL_EIGHT, sg.Msv1Mix(0.0, 1.0, 0.0)],
+                         ids=["solid", "eight", "two"])
+def test_extreme_mixes(bits, mix):
+    w, h = 320, 240
+    frames, keys, pal = sg.msv1_clip(60, w, h, 2, bits=bits, key_mix=mix)
+    drive_pair(bits, w, h, frames, keys, pal)
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_truncated_and_garbage_streams(bits):
+    """Streams cut at every length + random bytes: the JS out-of-range semantics the oracle
+    documents must come out of the kernel too."""
+    w, h = 32, 16
+    frames, keys, pal = sg.msv1_clip(70 + bits, w, h, 2, bits=bits, p_mix=sg.msv1_p_mix(0.4, 5.0))
+    rng = np.random.default_rng(5)
+    clips = []
+    full = frames[1]
+    for cut in list(range(0, 40)) + [len(full) // 2, len(full) - 1]:
+        clips.append(full[:cut])
+    for _ in range(40):
+        clips.append(rng.integers(0, 256, size=int(rng.integers(1, 200)), dtype=np.uint8).tobytes())
+    srcs = [frames[0]]
+    ks = [True]
+    for c in clips:
+        srcs.append(c)
+        ks.append(False)
+    drive_pair(bits, w, h, srcs, ks, pal, lines=4)
+
+
+def test_skip_before_first_frame_is_an_error():
+    w, h = 16, 8
+    src = bytes([0x00, 0xFC, 0x01, 0x84] + [0] * 8)
+    drive_pair(16, w, h, [src], [False], None, lines=0)
+
+
+def test_negative_skip_and_all_skip_long_stream():
+    w, h = 64, 32
+    frames, _, _ = sg.msv1_clip(81, w, h, 1)
+    neg = bytes([0x1F, 0x80, 0x00, 0x84] + [0] * 20)
+    # 128 blocks, all-skip stream longer than size_of_just_skips: full copy, not adopted
+    allskip = bytes([0x10, 0x84] * 8)
+    drive_pair(16, w, h, [frames[0], neg, allskip, neg], [True, False, False, False], None, lines=0)
+
+
+def test_8bit_end_marker_mid_frame():
+    w, h = 32, 16
+    frames, _, pal = sg.msv1_clip(82, w, h, 2, bits=8)
+    cut = frames[1][:20] + b"\x00\x00" + frames[1][22:]
+    drive_pair(8, w, h, [frames[0], cut, frames[1]], [True, False, False], pal, lines=4)
+
+
+def test_batch_matches_sequential_and_full_size_properties():
+    """BASELINE config 2 shape: key-frame-only 1920x1080, one launch for the whole batch."""
+    torch = torch_mod()
+    w, h, n = 1920, 1080, 6
+    frames, keys, _ = sg.msv1_clip(2, w, h, n)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.Preinit(36)
+    dsts = [dev_buf(w * h, -1) for _ in range(n)]
+    st = gpu.stage_batch(frames, dsts)
+    info = st.info()
+    assert info["kernel_launches"] == 1
+    assert info["units_coded"] == n * 129600 and info["units_copied"] == 0
+    assert info["algorithmic_bytes"] == sum(len(f) for f in frames) + n * w * h * 4
+    st.decode()
+    gpu.sync()
+    status, adopted, _ = st.results()
+    assert status == [0] * n and adopted == [1] * n
+    assert gpu.PreviousFrame() is dsts[-1]
+    # decoding the staged batch again is idempotent
+    first = [d.clone() for d in dsts]
+    st.decode()
+    gpu.sync()
+    for a, b in zip(first, dsts):
+        assert torch.equal(a, b)
+    # frame-by-frame through the oracle
+    orc = OracleMSVideo1(16, w, h)
+    orc.Preinit(36)
+    ref = np.zeros(w * h, dtype=np.int32)
+    for src, d in zip(frames, dsts):
+        orc.DecompressI(src, ref)
+        assert np.array_equal(ref, to_np(d))
+    # size-independent property: every pixel is a left-aligned 5-bit-per-channel colour
+    assert int((dsts[0] & ~0x00F8F8F8).abs().max()) == 0
+    st.close()
+
+
+def test_batch_with_inter_frames_matches_oracle():
+    w, h, n = 320, 240, 12
+    frames, keys, _ = sg.msv1_clip(1, w, h, n, p_mix=sg.msv1_p_mix(0.7, 40.0), key_every=6)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.Preinit(36)
+    dsts = [dev_buf(w * h, 3) for _ in range(n)]
+    st = gpu.stage_batch(frames, dsts, is_key=keys)
+    st.decode()
+    gpu.sync()
+    status, adopted, signif = st.results()
+    orc = OracleMSVideo1(16, w, h)
+    orc.Preinit(36)
+    obufs = [np.full(w * h, 3, dtype=np.int32) for _ in range(n)]
+    for i in range(n):
+        if keys[i]:
+            orc.DecompressI(frames[i], obufs[i])
+        else:
+            data, sig = orc.DecompressP(frames[i], obufs[i])
+            assert bool(signif[i]) == sig
+            assert bool(adopted[i]) == (data is obufs[i])
+        assert np.array_equal(obufs[i], to_np(dsts[i])), i
+    st.close()
