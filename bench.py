@@ -109,7 +109,9 @@ def main():
     codec = (MSVideo1_16bit(w, h, device=local_rank) if spec["bits"] == 16
              else MSVideo1_8bit(w, h, pal, device=local_rank))
     codec.Preinit(36)
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-null) stream: kernels and the timing events are queued on the same one
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     codec.set_stream(stream.cuda_stream)
     dsts = [torch.empty(w * h, dtype=torch.int32, device="cuda") for _ in range(nfr)]
     staged = codec.stage_batch(frames, dsts, is_key=keys)   # host parse + H2D: outside the timed region

@@ -84,6 +84,13 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C jsplayer_amd/csrc). jsplayer_amd has no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64, so
+    # when torch is importable load it FIRST and let this library bind to the runtime torch brought
+    # (loading /opt/rocm's copy first and torch's second leaves the second one without a device).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a dependency of the C ABI
+        pass
     handle = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the ABI and the binding drift apart

@@ -1,0 +1,120 @@
+// Measured HBM ceilings on the box for the access shapes the decode kernels use
+// ("also report against a measured streaming-store ceiling").
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_ceiling.hip -o /tmp/hbm_ceiling && /tmp/hbm_ceiling
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <bool NT>
+__global__ __launch_bounds__(256) void fill16(u32x4* __restrict__ dst, size_t n, uint32_t v) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        u32x4 x = u32x4{v, v + 1, v + 2, v + 3};
+        if (NT) __builtin_nontemporal_store(x, dst + i); else dst[i] = x;
+    }
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void copy16(u32x4* __restrict__ dst, const u32x4* __restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        u32x4 x = NT ? __builtin_nontemporal_load(src + i) : src[i];
+        if (NT) __builtin_nontemporal_store(x, dst + i); else dst[i] = x;
+    }
+}
+// the MSVideo1 store shape: lane = 4x4 block, 4 row stores of 16 B, rows X ints apart
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_blocks(uint32_t* __restrict__ base, int nblocks, int nbx, int X, size_t frame_ints) {
+    uint32_t* dst = base + (size_t)blockIdx.y * frame_ints;
+    int blk = blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nblocks) return;
+    int by = blk / nbx, bx = blk - by * nbx;
+    uint32_t* p = dst + (size_t)by * 4 * X + bx * 4;
+    u32x4 x = u32x4{(uint32_t)blk, (uint32_t)blk + 1, (uint32_t)blk + 2, (uint32_t)blk + 3};
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        if (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p + (size_t)y * X));
+        else *reinterpret_cast<u32x4*>(p + (size_t)y * X) = x;
+    }
+}
+
+// A: linear, 4 stores per lane, workgroup covers 16 KB contiguous
+__global__ __launch_bounds__(256) void fill_lin4(u32x4* __restrict__ dst, size_t n) {
+    size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k * 256 < n) dst[base + k * 256] = u32x4{1u, 2u, 3u, (uint32_t)k};
+}
+// D: one workgroup (512 lanes, 480 active) per block row: 30 KB contiguous, written linearly
+__global__ __launch_bounds__(512) void fill_rowlinear(uint32_t* __restrict__ base, int nbx, int X, size_t frame_ints) {
+    u32x4* dst = reinterpret_cast<u32x4*>(base + (size_t)blockIdx.y * frame_ints + (size_t)blockIdx.x * 4 * X);
+    const int per_row = X / 4;  // 16-byte units per pixel row == nbx
+    for (int i = threadIdx.x; i < per_row * 4; i += 512) dst[i] = u32x4{1u, 2u, 3u, (uint32_t)i};
+}
+// E: block-shaped, XCD-aware: workgroup id remapped so the 8 workgroups an XCD gets in a round are
+// memory-adjacent chunks (blockIdx%8 picks the XCD under round-robin dispatch)
+__global__ __launch_bounds__(256) void fill_blocks_xcd(uint32_t* __restrict__ base, int nblocks, int nbx, int X, size_t frame_ints, int wgs_per_frame) {
+    uint32_t* dst = base + (size_t)blockIdx.y * frame_ints;
+    const int per_xcd = (wgs_per_frame + 7) / 8;
+    const int wg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (wg >= wgs_per_frame) return;
+    int blk = wg * 256 + threadIdx.x;
+    if (blk >= nblocks) return;
+    int by = blk / nbx, bx = blk - by * nbx;
+    uint32_t* p = dst + (size_t)by * 4 * X + bx * 4;
+    u32x4 x = u32x4{(uint32_t)blk, 1u, 2u, 3u};
+#pragma unroll
+    for (int y = 0; y < 4; ++y) *reinterpret_cast<u32x4*>(p + (size_t)y * X) = x;
+}
+
+template <class F>
+static double time_us(F&& launch, int reps) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; ++i) launch();
+    hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3 / reps;
+}
+
+int main() {
+    const int X = 1920, Y = 1080, F = 64;
+    const size_t frame_ints = (size_t)X * Y, bytes = frame_ints * 4 * F, n16 = bytes / 16;
+    u32x4 *d, *s;
+    CK(hipMalloc(&d, bytes)); CK(hipMalloc(&s, bytes));
+    CK(hipMemset(s, 1, bytes));
+    const int nblocks = (X / 4) * (Y / 4);
+    printf("buffer %.1f MB (64 frames 1920x1080 RGB32)\n", bytes / 1e6);
+    for (int grid : {2048, 8192, 32768, (int)((n16 + 255) / 256)}) {
+        double t1 = time_us([&] { fill16<false><<<grid, 256>>>(d, n16, 7); }, 50);
+        double t2 = time_us([&] { fill16<true><<<grid, 256>>>(d, n16, 7); }, 50);
+        double t3 = time_us([&] { copy16<false><<<grid, 256>>>(d, s, n16); }, 50);
+        double t4 = time_us([&] { copy16<true><<<grid, 256>>>(d, s, n16); }, 50);
+        printf("grid %8d  fill %7.1f us %6.0f GB/s | fill nt %7.1f us %6.0f GB/s | copy %7.1f us %6.0f GB/s (r+w) | copy nt %7.1f us %6.0f GB/s\n",
+               grid, t1, bytes / t1 / 1e3, t2, bytes / t2 / 1e3, t3, 2.0 * bytes / t3 / 1e3, t4, 2.0 * bytes / t4 / 1e3);
+    }
+    dim3 g((nblocks + 255) / 256, F);
+    double t5 = time_us([&] { fill_blocks<false><<<g, 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints); }, 50);
+    double t6 = time_us([&] { fill_blocks<true><<<g, 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints); }, 50);
+    printf("block-shaped fill (4 x 16 B rows per lane): %7.1f us %6.0f GB/s | nt %7.1f us %6.0f GB/s\n",
+           t5, bytes / t5 / 1e3, t6, bytes / t6 / 1e3);
+    {
+        double a = time_us([&] { fill_lin4<<<(int)((n16 + 1023) / 1024), 256>>>(d, n16); }, 50);
+        double dd = time_us([&] { fill_rowlinear<<<dim3(Y / 4, F), 512>>>((uint32_t*)d, X / 4, X, frame_ints); }, 50);
+        int wpf = (nblocks + 255) / 256;
+        double e = time_us([&] { fill_blocks_xcd<<<dim3(((wpf + 7) / 8) * 8, F), 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints, wpf); }, 50);
+        printf("A linear 4 stores/lane %7.1f us %6.0f GB/s | D row-linear 512-lane WG %7.1f us %6.0f GB/s | E block-shaped xcd-remap %7.1f us %6.0f GB/s\n",
+               a, bytes / a / 1e3, dd, bytes / dd / 1e3, e, bytes / e / 1e3);
+    }
+    double t7 = time_us([&] { (void)hipMemsetAsync(d, 0, bytes, 0); }, 20);
+    double t8 = time_us([&] { (void)hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0); }, 20);
+    printf("hipMemsetAsync %7.1f us %6.0f GB/s | hipMemcpyDtoD %7.1f us %6.0f GB/s (r+w)\n", t7, bytes / t7 / 1e3, t8, 2.0 * bytes / t8 / 1e3);
+    return 0;
+}
