@@ -20,6 +20,7 @@ struct jsp_staged {
     virtual void decode(hipStream_t stream) = 0;  // asynchronous
     jsp_staged_info info{};
     std::vector<int> status, adopted, significant;
+    std::vector<int> cleared;  // frame i ended with prevFrame == null (ScreenPressor RenewI + failure)
     // significance words written by the kernels (one per frame); -1 in `significant`
     // marks "take it from the device word"
     jsp::DeviceBuffer d_signif;

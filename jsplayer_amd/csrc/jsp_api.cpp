@@ -109,6 +109,7 @@ int decompress_one(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, boo
         JSP_HIP(hipMemcpyAsync(dst, f.dst, npx * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     JSP_HIP(hipStreamSynchronize(c->stream));
     st->finish_results();
+    if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
     if (st->adopted[0]) c->prev_caller = dst;
     if (data_pnt) *data_pnt = c->prev_caller;
     if (significant) *significant = st->significant[0];
@@ -257,8 +258,10 @@ jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* src
         if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
         if (nframes) c->ptr_mode = 1;
         jsp_staged* st = c->stage(frames, nullptr);
-        for (int i = 0; i < nframes; ++i)
+        for (int i = 0; i < nframes; ++i) {
+            if (!st->cleared.empty() && st->cleared[i]) c->prev_caller = nullptr;
             if (st->adopted[i]) c->prev_caller = dsts[i];
+        }
         return st;
     } catch (const std::exception& e) {
         set_error("%s", e.what());

@@ -1,0 +1,119 @@
+// ScreenPressor path: host entropy stage -> descriptor tables -> HIP reconstruction.
+//
+// The entropy contexts are derived from reconstructed pixels (ScreenPressor.hx:274-275,462-463),
+// so the host stage keeps a shadow of the current and previous frame while it decodes symbols;
+// what it hands to the GPU is a compact description from which the frame is materialised in HBM:
+//   I-frame  : run table (8 B per run) + one row index per image row; the kernel expands the runs
+//              row by row, resolving "copy from the row above" predictors through LDS;
+//   P-frame  : one 16-byte record per 16x16 block (unchanged / motion / sub-rectangle / data) and
+//              literal pixels for the data rectangles only; the kernel copies, motion-compensates
+//              and patches against the previous frame in HBM.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "sp_entropy.h"
+
+namespace jsp::sp {
+
+// ---- I-frame descriptors --------------------------------------------------------------------
+// kind: how the pixels of the run are produced
+enum RunKind : uint32_t {
+    RUN_CONST = 0,      // colour in the low 24 bits (literal runs, "repeat previous pixel" runs, flat)
+    RUN_ABOVE = 2,      // pixel i takes pixel i-X
+    RUN_ABOVE_LEFT = 5, // pixel i takes pixel i-X-1
+    RUN_ABOVE_PLUS = 4, // pixel i takes pixel i-X plus a per-run byte-wise delta (gradient predictor,
+                        // which telescopes inside a run: p[i]-p[i-X] = p[i0-1]-p[i0-1-X])
+};
+struct IRun {
+    uint32_t start;  // linear pixel index of the first pixel
+    uint32_t word;   // low 24 bits: colour or delta; bits 24..26: RunKind
+};
+
+// ---- P-frame descriptors --------------------------------------------------------------------
+enum : uint8_t { PB_SUBRECT = 1, PB_MOTION = 2, PB_DATA = 4 };  // 0 = unchanged block
+struct PBlock {        // 16 bytes
+    uint8_t flags;
+    uint8_t x1, y1, x2, y2;  // changed rectangle relative to the block origin, x2/y2 exclusive
+    uint8_t pad[3];
+    int16_t mx, my;
+    uint32_t payload;  // index of the rectangle's first literal pixel
+};
+static_assert(sizeof(PBlock) == 16, "PBlock is 16 bytes");
+
+struct Geometry {
+    int X, Y, bpp, nbx, nby;
+};
+
+enum class FrameKind { None, Flat, Intra, Inter };
+
+// What the host stage produced for one frame.
+struct FrameOut {
+    FrameKind kind = FrameKind::None;
+    int status = 0;            // DecoderState
+    bool adopted = false;      // dst becomes the previous frame
+    bool prev_cleared = false; // the call ended with prevFrame == null (RenewI ran, decode failed)
+    bool significant = false;
+    uint32_t flat_colour = 0;
+    std::vector<IRun> runs;          // Intra (with a sentinel run at start = X*Y)
+    std::vector<uint32_t> row_run;   // Intra: Y+1 entries, index of the run holding pixel y*X
+    std::vector<PBlock> blocks;      // Inter
+    std::vector<uint32_t> payload;   // Inter: literal pixels of the data rectangles
+    uint64_t prev_pixels = 0;        // Inter: pixels fetched from the previous frame
+    uint64_t data_pixels = 0;        // Inter: pixels taken from the payload
+    uint64_t stream_bytes = 0;
+    const char* error = nullptr;
+};
+
+// Host entropy stage for one stream (one codec instance): ScreenPressor.hx state + shadow frames.
+class HostDecoder {
+public:
+    HostDecoder(int width, int height, int bpp);
+    void preinit(int lines);  // ScreenPressor.hx:86-89
+    static bool is_key_frame(const uint8_t* src, size_t n);  // :96-101
+    // :117-295.  `have_prev` mirrors prevFrame != null (it becomes null inside RenewI).
+    void decode_i(const uint8_t* src, size_t n, FrameOut& out);
+    // :302-484
+    void decode_p(const uint8_t* src, size_t n, FrameOut& out);
+    const Geometry& geo() const { return g_; }
+    bool has_prev() const { return has_prev_; }
+
+private:
+    int32_t literal();
+    bool init_entropy(int version);
+    void renew_i();
+    Geometry g_;
+    int cx_ = 0, cx1_ = 0, cxshift_;
+    std::unique_ptr<EntropyDecoder> ec_;
+    std::vector<int32_t> shadow_[2];  // [cur_] is being written, [1-cur_] is the previous frame
+    int cur_ = 0;
+    bool has_prev_ = false;     // prevFrame != null
+    bool decoded_i_ = false;
+    bool last_flat_ = false;    // last_one_was_flat != null
+    bool use_bool_ = false;
+    int insignificant_blocks_ = 0;
+    std::vector<int32_t> bts_;
+    int stall_ = 0;
+};
+
+// ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------
+struct IFrameArgs {    // one per frame of an intra launch (grid.x = frame)
+    int32_t* dst;
+    const IRun* runs;
+    const uint32_t* row_run;
+    uint32_t nruns;
+    uint32_t flat;     // 1: fill with `colour`
+    uint32_t colour;
+    uint32_t pad;
+};
+void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hipStream_t stream);
+void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,
+                   const uint32_t* d_payload, hipStream_t stream);
+size_t iframe_lds_bytes(const Geometry& g);
+constexpr int kMaxIntraWidth = 8192;  // LDS plan of the row-wavefront kernel
+
+}  // namespace jsp::sp

@@ -1,0 +1,166 @@
+// ScreenPressor behind the IVideoCodec-shaped C ABI: host entropy stage (sp_host.cpp) + HIP
+// reconstruction (sp_kernels.hip).
+#include <algorithm>
+#include <unordered_set>
+
+#include "codec.h"
+#include "sp.h"
+
+namespace jsp {
+namespace {
+using namespace jsp::sp;
+
+struct SpStaged : jsp_staged {
+    Geometry geo{};
+    struct Op {
+        enum Kind { Intra, Inter } kind;
+        int first, count;      // Intra: range in the IFrameArgs array
+        int32_t* dst;          // Inter
+        const int32_t* prev;
+        size_t block_off, payload_off;
+    };
+    std::vector<Op> ops;
+    DeviceBuffer d_runs, d_rows, d_iargs, d_blocks, d_payload;
+
+    void decode(hipStream_t stream) override {
+        for (const Op& op : ops) {
+            if (op.kind == Op::Intra)
+                launch_iframes(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, stream);
+            else
+                launch_pframe(geo, op.dst, op.prev, static_cast<const PBlock*>(d_blocks.p) + op.block_off,
+                              static_cast<const uint32_t*>(d_payload.p) + op.payload_off, stream);
+        }
+        JSP_HIP(hipGetLastError());
+        decoded = true;
+    }
+};
+
+struct SpCodec : jsp_codec {
+    HostDecoder host;
+    SpCodec(int w, int h, int bpp) : host(w, h, bpp) {
+        kind = JSP_CODEC_SCREENPRESSOR;
+        X = w;
+        Y = h;
+        if (w > kMaxIntraWidth) throw std::runtime_error("ScreenPressor frames wider than 8192 pixels are not supported");
+    }
+    int preinit(int lines) override { host.preinit(lines); return JSP_ZERO_STATE; }
+    int is_key_frame(const uint8_t* src, size_t n) override { return HostDecoder::is_key_frame(src, n) ? 1 : 0; }
+    int needs_index() override { return 0; }
+    bool may_leave_pixels(const jsp_frame_in&) override { return false; }
+
+    jsp_staged* stage(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse) override {
+        activate();
+        const double t0 = now_ms();
+        auto* st = dynamic_cast<SpStaged*>(reuse);
+        std::unique_ptr<SpStaged> guard;
+        if (!st) { st = new SpStaged(); guard.reset(st); }
+        const int nf = (int)frames.size();
+        const Geometry& g = host.geo();
+        st->geo = g;
+        st->ops.clear();
+        st->decoded = false;
+        st->status.assign(nf, JSP_ZERO_STATE);
+        st->adopted.assign(nf, 0);
+        st->significant.assign(nf, 0);
+        st->cleared.assign(nf, 0);
+        st->info = jsp_staged_info{};
+
+        std::vector<IRun> runs;
+        std::vector<uint32_t> rows;
+        std::vector<IFrameArgs> iargs;
+        std::vector<size_t> iarg_run_off, iarg_row_off;
+        std::vector<PBlock> blocks;
+        std::vector<uint32_t> payload;
+        std::unordered_set<const void*> group_dsts;
+        FrameOut fo;
+        for (int i = 0; i < nf; ++i) {
+            const jsp_frame_in& f = frames[i];
+            if (f.key) host.decode_i(f.src, f.n, fo);
+            else host.decode_p(f.src, f.n, fo);
+            st->status[i] = fo.status;
+            st->adopted[i] = fo.adopted ? 1 : 0;
+            st->significant[i] = fo.significant ? 1 : 0;
+            st->cleared[i] = fo.prev_cleared ? 1 : 0;
+            if (fo.status != JSP_ZERO_STATE && fo.error) set_error("%s", fo.error);
+            if (fo.prev_cleared) prev_dev = nullptr;
+            st->info.stream_bytes += fo.stream_bytes;
+            const uint64_t npx = (uint64_t)g.X * g.Y;
+            switch (fo.kind) {
+                case FrameKind::Flat:
+                case FrameKind::Intra: {
+                    IFrameArgs a{};
+                    a.dst = f.dst;
+                    a.flat = fo.kind == FrameKind::Flat;
+                    a.colour = fo.flat_colour;
+                    a.nruns = (uint32_t)fo.runs.size();
+                    iarg_run_off.push_back(runs.size());
+                    iarg_row_off.push_back(rows.size());
+                    runs.insert(runs.end(), fo.runs.begin(), fo.runs.end());
+                    rows.insert(rows.end(), fo.row_run.begin(), fo.row_run.end());
+                    const bool join = !st->ops.empty() && st->ops.back().kind == SpStaged::Op::Intra &&
+                                      !group_dsts.count(f.dst);
+                    if (join) st->ops.back().count++;
+                    else {
+                        st->ops.push_back({SpStaged::Op::Intra, (int)iargs.size(), 1, nullptr, nullptr, 0, 0});
+                        group_dsts.clear();
+                    }
+                    group_dsts.insert(f.dst);
+                    iargs.push_back(a);
+                    const uint64_t r = fo.runs.empty() ? 0 : fo.runs.size() - 1;
+                    st->info.runs += r;
+                    st->info.units_coded += npx;
+                    st->info.algorithmic_bytes += 8 * r + 4 * npx;  // A = 8R + 4P
+                    break;
+                }
+                case FrameKind::Inter: {
+                    st->ops.push_back({SpStaged::Op::Inter, 0, 0, f.dst, prev_dev, blocks.size(), payload.size()});
+                    group_dsts.clear();
+                    blocks.insert(blocks.end(), fo.blocks.begin(), fo.blocks.end());
+                    payload.insert(payload.end(), fo.payload.begin(), fo.payload.end());
+                    st->info.units_coded += fo.data_pixels;
+                    st->info.units_copied += fo.prev_pixels;
+                    // A = 4P written + 4 P_prev fetched + 16 N_blk + literal payload of the data rectangles
+                    st->info.algorithmic_bytes += 4 * npx + 4 * fo.prev_pixels + 16 * (uint64_t)fo.blocks.size() +
+                                                  4 * fo.data_pixels;
+                    break;
+                }
+                case FrameKind::None: break;
+            }
+            if (fo.adopted) prev_dev = f.dst;
+        }
+        st->info.frames = nf;
+        st->info.pixels = (uint64_t)g.X * g.Y * nf;
+        st->info.kernel_launches = st->ops.size();
+        st->info.descriptor_bytes = runs.size() * sizeof(IRun) + rows.size() * 4 + iargs.size() * sizeof(IFrameArgs) +
+                                    blocks.size() * sizeof(PBlock) + payload.size() * 4;
+        st->info.host_stage_ms = now_ms() - t0;
+
+        const double t1 = now_ms();
+        st->d_runs.reserve(std::max<size_t>(runs.size(), 1) * sizeof(IRun));
+        st->d_rows.reserve(std::max<size_t>(rows.size(), 1) * 4);
+        st->d_iargs.reserve(std::max<size_t>(iargs.size(), 1) * sizeof(IFrameArgs));
+        st->d_blocks.reserve(std::max<size_t>(blocks.size(), 1) * sizeof(PBlock));
+        st->d_payload.reserve(std::max<size_t>(payload.size(), 1) * 4 + 16);
+        for (size_t k = 0; k < iargs.size(); ++k) {
+            iargs[k].runs = static_cast<const IRun*>(st->d_runs.p) + iarg_run_off[k];
+            iargs[k].row_run = static_cast<const uint32_t*>(st->d_rows.p) + iarg_row_off[k];
+        }
+        auto up = [&](DeviceBuffer& d, const void* h, size_t bytes) {
+            if (bytes) JSP_HIP(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream));
+        };
+        up(st->d_runs, runs.data(), runs.size() * sizeof(IRun));
+        up(st->d_rows, rows.data(), rows.size() * 4);
+        up(st->d_iargs, iargs.data(), iargs.size() * sizeof(IFrameArgs));
+        up(st->d_blocks, blocks.data(), blocks.size() * sizeof(PBlock));
+        up(st->d_payload, payload.data(), payload.size() * 4);
+        JSP_HIP(hipStreamSynchronize(stream));  // the host vectors go out of scope below
+        st->info.h2d_ms = now_ms() - t1;
+        guard.release();
+        return st;
+    }
+};
+
+}  // namespace
+}  // namespace jsp
+
+jsp_codec* jsp_make_screenpressor(int w, int h, int bpp) { return new jsp::SpCodec(w, h, bpp); }

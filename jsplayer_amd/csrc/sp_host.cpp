@@ -1,0 +1,346 @@
+// ScreenPressor host entropy stage: walks the symbol stream exactly as ScreenPressor.hx does
+// (DecompressI :117-295, DecompressP :302-484), keeps the shadow frames the context derivation
+// needs, and emits the descriptor tables the HIP kernels materialise the frame from.
+#include "sp.h"
+
+#include <cstring>
+
+namespace jsp::sp {
+
+namespace {
+constexpr int kStallLimit = 65536;  // consecutive zero-length runs before we call it a hang
+}
+
+HostDecoder::HostDecoder(int width, int height, int bpp) {
+    g_.X = width;
+    g_.Y = height;
+    g_.bpp = bpp;
+    g_.nbx = (width + 15) / 16;
+    g_.nby = (height + 15) / 16;
+    cxshift_ = bpp == 16 ? 0 : 2;  // ScreenPressor.hx:59
+    bts_.assign((size_t)g_.nbx * g_.nby, 0);
+    for (auto& s : shadow_) s.assign((size_t)width * height, 0);
+}
+
+void HostDecoder::preinit(int lines) { insignificant_blocks_ = g_.nbx * ((lines + 15) / 16); }
+
+bool HostDecoder::is_key_frame(const uint8_t* src, size_t n) {
+    if (!src || n == 0) return false;
+    const int b = src[0];
+    return b == 0x12 || b == 0x11 || b == 0x22 || b == 0x21 || b == 0x32 || b == 0x31;
+}
+
+bool HostDecoder::init_entropy(int version) {  // ScreenPressor.hx:66-79
+    switch (version) {
+        case 2: ec_ = make_range_decoder(); break;
+        case 3: ec_ = make_rans_decoder(64); cxshift_ = 2; break;
+        case 4: ec_ = make_rans_decoder(32); cxshift_ = 2; break;
+        default: return false;
+    }
+    use_bool_ = ec_->has_bool();
+    return true;
+}
+
+void HostDecoder::renew_i() {  // ScreenPressor.hx:108-115
+    has_prev_ = false;
+    if (last_flat_) return;
+    if (!ec_) throw DecodeAbort{"flat key frame before any coded key frame: the reference dereferences a null coder"};
+    ec_->renewI();
+}
+
+int32_t HostDecoder::literal() {  // ScreenPressor.hx:173-189 / 224-235 / 419-430
+    auto comp = [&](int base) {
+        const int ctx = base + cx_ + cx1_;
+        if (ctx < 0 || ctx >= 3 * 4096) throw DecodeAbort{"colour context outside the table"};
+        const int v = ec_->clr(ctx);
+        cx1_ = (cx_ << 6) & 0xFC0;
+        cx_ = v < 0 ? 0 : v >> cxshift_;
+        return v;
+    };
+    const int r = comp(0), g = comp(4096), b = comp(8192);
+    if (r < 0) return 0;  // (b<<16)+(g<<8)+undefined is NaN, stored as 0
+    return (int32_t)(((uint32_t)(b < 0 ? 0 : b) << 16) + ((uint32_t)(g < 0 ? 0 : g) << 8) + (uint32_t)r);
+}
+
+void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
+    out = FrameOut{};
+    const long X = g_.X, end = (long)g_.X * g_.Y;
+    int32_t* dst = shadow_[cur_].data();
+    const int head = n ? src[0] : 0;
+    const int version = (head >> 4) + 1;
+    const bool had_prev = has_prev_;
+    try {
+        if ((head & 0xF) == 1) {  // flat, :132-155
+            renew_i();
+            uint32_t c;
+            if (g_.bpp == 16) {
+                const int v = n >= 2 ? src[0] + src[1] * 256 : 0;
+                c = (uint32_t)((((v >> 10) & 0x1F) << 3) << 16) + (uint32_t)((((v >> 5) & 0x1F) << 3) << 8) +
+                    (uint32_t)((v & 0x1F) << 3);
+            } else {
+                const int b = n > 1 ? src[1] : -1, gg = n > 2 ? src[2] : 0, r = n > 3 ? src[3] : 0;
+                c = b < 0 ? 0u : (uint32_t)((r << 16) + (gg << 8) + b);
+            }
+            std::fill(dst, dst + end, (int32_t)c);
+            out.kind = FrameKind::Flat;
+            out.flat_colour = c;
+            out.adopted = true;
+            out.stream_bytes = n < 4 ? n : 4;
+            has_prev_ = true;
+            last_flat_ = true;
+            decoded_i_ = true;
+            cur_ ^= 1;
+            return;
+        }
+        last_flat_ = false;
+        if ((head & 0xF) != 2) { out.status = 2; out.error = "unknown ScreenPressor frame header"; return; }
+        if (!ec_ && !init_entropy(version)) { out.status = 2; out.error = "unknown ScreenPressor stream version"; return; }
+        renew_i();
+        ec_->begin(src, n, 1);
+        cx_ = cx1_ = 0;
+        stall_ = 0;
+        auto progress = [&](bool advanced) {
+            if (advanced) stall_ = 0;
+            else if (++stall_ > kStallLimit) throw DecodeAbort{"no progress: the reference would never return"};
+        };
+        auto& runs = out.runs;
+        runs.clear();
+        auto emit = [&](long start, int cnt, uint32_t kind, uint32_t payload) {
+            if (cnt <= 0 || start >= end) return;
+            runs.push_back({(uint32_t)start, (payload & 0xFFFFFFu) | (kind << 24)});
+        };
+        auto rd = [&](long i) -> int32_t { return (i >= 0 && i < end) ? dst[i] : 0; };
+        auto fill = [&](long at, int cnt, int32_t v) {
+            for (long i = at; i < at + cnt && i < end; ++i) dst[i] = v;
+        };
+        long di = 0, k = 0;
+        int32_t clr = 0;
+        while (k < X + 1) {  // phase 1: literal runs until a full row + 1 exists, :170-197
+            clr = literal();
+            const int cnt = ec_->run(0);
+            k += cnt;
+            progress(cnt > 0);
+            emit(di, cnt, RUN_CONST, (uint32_t)clr);
+            fill(di, cnt, clr);
+            di += cnt;
+        }
+        int mask1 = 0xFC00, shift1 = 4, shiftc = 18;
+        if (g_.bpp == 16 && ec_->rc_16bpp_constants()) { mask1 = 0xFF00; shift1 = 2; shiftc = 16; }
+        int pt = 0;
+        while (di < end) {  // phase 2, :218-286
+            pt = ec_->ptype(pt);
+            if (pt >= 6) throw DecodeAbort{"predictor type outside its tables"};
+            if (pt == 0) clr = literal();
+            const int cnt = ec_->run(pt);
+            progress(cnt > 0 && pt != 3);
+            switch (pt) {
+                case 0:
+                    emit(di, cnt, RUN_CONST, (uint32_t)clr);
+                    fill(di, cnt, clr);
+                    di += cnt;
+                    break;
+                case 1:  // repeat the pixel before the run
+                    clr = rd(di - 1);
+                    emit(di, cnt, RUN_CONST, (uint32_t)clr);
+                    fill(di, cnt, clr);
+                    di += cnt;
+                    break;
+                case 2:
+                    emit(di, cnt, RUN_ABOVE, 0);
+                    for (int c = 0; c < cnt; ++c, ++di) { clr = rd(di - X); if (di < end) dst[di] = clr; }
+                    break;
+                case 5:
+                    emit(di, cnt, RUN_ABOVE_LEFT, 0);
+                    for (int c = 0; c < cnt; ++c, ++di) { clr = rd(di - X - 1); if (di < end) dst[di] = clr; }
+                    break;
+                case 4: {  // left + above - aboveleft per byte; constant offset from the row above
+                    if (cnt > 0) {
+                        const uint32_t a = (uint32_t)rd(di - 1), b = (uint32_t)rd(di - 1 - X);
+                        const uint32_t d = (((a & 0xFF) - (b & 0xFF)) & 0xFF) | (((a & 0xFF00) - (b & 0xFF00)) & 0xFF00) |
+                                           (((a & 0xFF0000) - (b & 0xFF0000)) & 0xFF0000);
+                        emit(di, cnt, RUN_ABOVE_PLUS, d);
+                        for (int c = 0; c < cnt; ++c, ++di) {
+                            const uint32_t u = (uint32_t)rd(di - X);
+                            clr = (int32_t)((((u & 0xFF) + (d & 0xFF)) & 0xFF) | (((u & 0xFF00) + (d & 0xFF00)) & 0xFF00) |
+                                            (((u & 0xFF0000) + (d & 0xFF0000)) & 0xFF0000));
+                            if (di < end) dst[di] = clr;
+                        }
+                    }
+                    break;
+                }
+                default: break;  // 3 has no case in the I-frame switch: nothing written
+            }
+            cx1_ = (clr & mask1) >> shift1;
+            cx_ = clr >> shiftc;
+        }
+        runs.push_back({(uint32_t)end, 0});  // sentinel
+        out.row_run.assign(g_.Y + 1, 0);
+        size_t r = 0;
+        for (int y = 0; y <= g_.Y; ++y) {
+            const uint32_t first = (uint32_t)((long)y * X);
+            while (r + 1 < runs.size() && runs[r + 1].start <= first) ++r;
+            out.row_run[y] = (uint32_t)r;
+        }
+        out.kind = FrameKind::Intra;
+        out.adopted = true;
+        out.stream_bytes = ec_->consumed();
+        has_prev_ = true;
+        decoded_i_ = true;
+        cur_ ^= 1;
+    } catch (const DecodeAbort& a) {
+        out = FrameOut{};
+        out.status = 2;
+        out.error = a.why;
+        out.prev_cleared = had_prev && !has_prev_;  // RenewI nulled prevFrame and it stays null
+    }
+}
+
+void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
+    out = FrameOut{};
+    last_flat_ = false;
+    if (n == 0 || !decoded_i_) return;  // :308-309
+    if (src[0] == 0) return;            // :311-313 "no changes"
+    const long X = g_.X, end = (long)g_.X * g_.Y;
+    int32_t* dst = shadow_[cur_].data();
+    const int32_t* prev = shadow_[cur_ ^ 1].data();
+    try {
+        if (!ec_) throw DecodeAbort{"no entropy coder"};
+        int mask1 = 0xFC00, shift1 = 4, shiftc = 18;
+        if (ec_->rc_16bpp_constants() && g_.bpp == 16) { mask1 = 0xFF00; shift1 = 2; shiftc = 16; }
+        ec_->begin(src, n, 1);
+        stall_ = 0;
+        auto progress = [&](bool advanced) {
+            if (advanced) stall_ = 0;
+            else if (++stall_ > kStallLimit) throw DecodeAbort{"no progress: the reference would never return"};
+        };
+        int t = ec_->xx();
+        const int xx1 = (ec_->xx() << 8) + t;
+        t = ec_->xx();
+        const int xx2 = (ec_->xx() << 8) + t;
+        std::fill(bts_.begin(), bts_.end(), 0);
+        const long nb = (long)bts_.size();
+        for (long x = xx1; x <= xx2;) {  // block-type runs, :335-344
+            const int bt = ec_->bt();
+            const int cnt = ec_->bn();
+            for (int i = 0; i < cnt; ++i, ++x)
+                if (x >= 0 && x < nb) bts_[x] = bt;
+            progress(cnt > 0);
+        }
+        bool signif = false;
+        for (long i = insignificant_blocks_ < 0 ? 0 : insignificant_blocks_; i < nb; ++i)
+            if (bts_[i] > 0) { signif = true; break; }
+
+        out.blocks.assign((size_t)nb, PBlock{});
+        out.payload.clear();
+        auto rdp = [&](long i) -> int32_t { return (i >= 0 && i < end) ? prev[i] : 0; };
+        auto rdd = [&](long i) -> int32_t { return (i >= 0 && i < end) ? dst[i] : 0; };
+        auto need_prev = [&] { if (!has_prev_) throw DecodeAbort{"block copied from a previous frame that does not exist"}; };
+        int32_t clr = 0;
+        cx_ = cx1_ = 0;
+        int lastmx = 0, lastmy = 0;
+        for (int by = 0; by < g_.nby; ++by)
+            for (int bx = 0; bx < g_.nbx; ++bx) {
+                const int x16 = bx * 16, y16 = by * 16;
+                int x1 = x16, y1 = y16, x2 = x16 + 16 > g_.X ? g_.X : x16 + 16, y2 = y16 + 16 > g_.Y ? g_.Y : y16 + 16;
+                const int bw = x2 - x1;
+                const size_t bi = (size_t)by * g_.nbx + bx;
+                const int bt = bts_[bi];
+                PBlock& pb = out.blocks[bi];
+                auto copy_block = [&] {
+                    need_prev();
+                    for (int y = y1; y < y2; ++y) std::memcpy(dst + (long)y * X + x1, prev + (long)y * X + x1, sizeof(int32_t) * bw);
+                };
+                if (bt <= 0) {  // unchanged, :468-474
+                    copy_block();
+                    out.prev_pixels += (uint64_t)bw * (y2 - y1);
+                    continue;
+                }
+                const int tb = bt - 1;
+                if (tb & 1) {  // sub-rectangle: whole block from prev first, :375-386
+                    copy_block();
+                    out.prev_pixels += (uint64_t)bw * (y2 - y1);
+                    const int bx2 = x2, by2 = y2;
+                    x1 = ec_->sxy(0) + x16;
+                    y1 = ec_->sxy(1) + y16;
+                    x2 = ec_->sxy(2) + x16 + 1;
+                    y2 = ec_->sxy(3) + y16 + 1;
+                    if (x1 >= x2 || y1 >= y2 || x2 > bx2 || y2 > by2)
+                        throw DecodeAbort{"sub-rectangle empty or outside its block/frame (not produced by any encoder)"};
+                    pb.flags |= PB_SUBRECT;
+                }
+                pb.x1 = (uint8_t)(x1 - x16);
+                pb.y1 = (uint8_t)(y1 - y16);
+                pb.x2 = (uint8_t)(x2 - x16);
+                pb.y2 = (uint8_t)(y2 - y16);
+                if (tb & 2) {  // motion, :388-405
+                    int mx, my;
+                    if (use_bool_ && ec_->flag()) { mx = lastmx; my = lastmy; }
+                    else { mx = ec_->mx() - 256; my = ec_->my() - 256; }
+                    lastmx = mx;
+                    lastmy = my;
+                    need_prev();
+                    for (int y = y1; y < y2; ++y) {
+                        const long i = (long)y * X + x1, j = (long)(y + my) * X + (x1 + mx);
+                        for (int x = 0; x < x2 - x1; ++x) dst[i + x] = rdp(j + x);
+                    }
+                    pb.flags |= PB_MOTION;
+                    pb.mx = (int16_t)mx;
+                    pb.my = (int16_t)my;
+                    out.prev_pixels += (uint64_t)(x2 - x1) * (y2 - y1);
+                } else {  // data: run stream confined to the rectangle, :406-466
+                    int x = x1, y = y1, pt = 0;
+                    while (y < y2) {
+                        pt = ec_->ptype(pt);
+                        if (pt >= 6) throw DecodeAbort{"predictor type outside its tables"};
+                        if (pt == 0) clr = literal();
+                        const int cnt = ec_->run(pt);
+                        progress(cnt > 0);
+                        for (int c = 0; c < cnt; ++c) {
+                            // the reference keeps writing below the rectangle when a run is longer
+                            // than what is left of it; no encoder does that, and it cannot be
+                            // reproduced block-parallel: refuse the stream
+                            if (y >= y2) throw DecodeAbort{"run crosses the end of its rectangle"};
+                            const long di = (long)y * X + x;
+                            switch (pt) {
+                                case 1: clr = rdd(di - 1); break;
+                                case 2: clr = rdd(di - X); break;
+                                case 3: need_prev(); clr = rdp(di); break;
+                                case 4: {
+                                    const long l = di - 1, u = di - X, ul = di - X - 1;
+                                    if (l < 0 || u < 0 || ul < 0) { clr = 0; break; }  // NaN bytes
+                                    const uint32_t a = (uint32_t)dst[l], b = (uint32_t)dst[u], cc = (uint32_t)dst[ul];
+                                    clr = (int32_t)((((a & 0xFF) + (b & 0xFF) - (cc & 0xFF)) & 0xFF) |
+                                                    ((((a >> 8) & 0xFF) + ((b >> 8) & 0xFF) - ((cc >> 8) & 0xFF)) & 0xFF) << 8 |
+                                                    ((((a >> 16) & 0xFF) + ((b >> 16) & 0xFF) - ((cc >> 16) & 0xFF)) & 0xFF) << 16);
+                                    break;
+                                }
+                                case 5: clr = rdd(di - X - 1); break;
+                                default: break;
+                            }
+                            dst[di] = clr;  // inside the frame: the rectangle was checked above
+                            if (++x >= x2) { x = x1; ++y; }
+                        }
+                        cx1_ = (clr & mask1) >> shift1;
+                        cx_ = clr >> shiftc;
+                    }
+                    pb.flags |= PB_DATA;
+                    pb.payload = (uint32_t)out.payload.size();
+                    for (int yy = y1; yy < y2; ++yy)
+                        for (int xx = x1; xx < x2; ++xx) out.payload.push_back((uint32_t)dst[(long)yy * X + xx]);
+                    out.data_pixels += (uint64_t)(x2 - x1) * (y2 - y1);
+                }
+            }
+        out.kind = FrameKind::Inter;
+        out.adopted = true;
+        out.significant = signif;
+        out.stream_bytes = ec_->consumed();
+        has_prev_ = true;
+        cur_ ^= 1;
+    } catch (const DecodeAbort& a) {
+        out = FrameOut{};
+        out.status = 2;
+        out.error = a.why;
+    }
+}
+
+}  // namespace jsp::sp

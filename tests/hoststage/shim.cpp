@@ -1,0 +1,37 @@
+// TEST-ONLY shim: exposes the product's ScreenPressor HOST stage (jsplayer_amd/csrc/sp_host.cpp,
+// sp_entropy.cpp, sp_models.cpp — compiled from the same sources, no HIP runtime) so that the
+// descriptor tables it emits can be checked on a machine without a GPU.  Not part of the product
+// and not linked into libjsplayer_amd.so.
+#include <cstring>
+#include "../../jsplayer_amd/csrc/sp.h"
+
+using namespace jsp::sp;
+
+struct Shim {
+    HostDecoder host;
+    FrameOut out;
+    Shim(int w, int h, int bpp) : host(w, h, bpp) {}
+};
+
+extern "C" {
+void* hs_create(int w, int h, int bpp) { return new Shim(w, h, bpp); }
+void hs_destroy(void* p) { delete (Shim*)p; }
+void hs_preinit(void* p, int lines) { ((Shim*)p)->host.preinit(lines); }
+// returns status; fills meta: [kind, adopted, significant, prev_cleared, nruns, nrows, nblocks, npayload, flat_colour]
+int hs_decode(void* p, int key, const uint8_t* src, size_t n, uint64_t* meta) {
+    auto* s = (Shim*)p;
+    if (key) s->host.decode_i(src, n, s->out); else s->host.decode_p(src, n, s->out);
+    const FrameOut& o = s->out;
+    meta[0] = (uint64_t)o.kind; meta[1] = o.adopted; meta[2] = o.significant; meta[3] = o.prev_cleared;
+    meta[4] = o.runs.size(); meta[5] = o.row_run.size(); meta[6] = o.blocks.size(); meta[7] = o.payload.size();
+    meta[8] = o.flat_colour; meta[9] = o.prev_pixels; meta[10] = o.data_pixels; meta[11] = o.stream_bytes;
+    return o.status;
+}
+void hs_fetch(void* p, uint32_t* runs /*2 per run*/, uint32_t* rows, uint8_t* blocks /*16 B each*/, uint32_t* payload) {
+    const FrameOut& o = ((Shim*)p)->out;
+    if (runs) std::memcpy(runs, o.runs.data(), o.runs.size() * sizeof(IRun));
+    if (rows) std::memcpy(rows, o.row_run.data(), o.row_run.size() * 4);
+    if (blocks) std::memcpy(blocks, o.blocks.data(), o.blocks.size() * sizeof(PBlock));
+    if (payload) std::memcpy(payload, o.payload.data(), o.payload.size() * 4);
+}
+}

@@ -1,0 +1,133 @@
+"""Test-only access to the product's ScreenPressor HOST stage (tests/hoststage/shim.cpp) plus numpy
+re-statements of what the HIP kernels do with its descriptor tables, so the tables can be validated
+without a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(HERE, "hoststage", "libhoststage.so")
+_lib = None
+
+RUN_CONST, RUN_ABOVE, RUN_ABOVE_PLUS, RUN_ABOVE_LEFT = 0, 2, 4, 5
+PB_SUBRECT, PB_MOTION, PB_DATA = 1, 2, 4
+KIND_NONE, KIND_FLAT, KIND_INTRA, KIND_INTER = 0, 1, 2, 3
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hoststage")])
+        L = C.CDLL(_PATH)
+        L.hs_create.restype = C.c_void_p
+        L.hs_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.hs_destroy.argtypes = [C.c_void_p]
+        L.hs_preinit.argtypes = [C.c_void_p, C.c_int]
+        L.hs_decode.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]
+        L.hs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class HostStage:
+    def __init__(self, w, h, bpp):
+        self.L = lib()
+        self.X, self.Y = w, h
+        self.h = self.L.hs_create(w, h, bpp)
+
+    def preinit(self, lines):
+        self.L.hs_preinit(self.h, lines)
+
+    def decode(self, key: bool, src: bytes):
+        meta = np.zeros(12, dtype=np.uint64)
+        src = bytes(src)
+        status = self.L.hs_decode(self.h, 1 if key else 0, src, len(src), meta.ctypes.data)
+        m = [int(v) for v in meta]
+        out = dict(status=status, kind=m[0], adopted=bool(m[1]), significant=bool(m[2]), prev_cleared=bool(m[3]),
+                   flat_colour=m[8], prev_pixels=m[9], data_pixels=m[10], stream_bytes=m[11])
+        runs = np.zeros((m[4], 2), dtype=np.uint32)
+        rows = np.zeros(m[5], dtype=np.uint32)
+        blocks = np.zeros((m[6], 16), dtype=np.uint8)
+        payload = np.zeros(m[7], dtype=np.uint32)
+        self.L.hs_fetch(self.h, runs.ctypes.data, rows.ctypes.data, blocks.ctypes.data, payload.ctypes.data)
+        out.update(runs=runs, rows=rows, blocks=blocks, payload=payload)
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.hs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _add_bytes(u, d):
+    u = u.astype(np.uint32)
+    return ((((u & 0x00FF00FF) + (d & 0x00FF00FF)) & 0x00FF00FF) | (((u & 0xFF00) + (d & 0xFF00)) & 0xFF00)).astype(np.uint32)
+
+
+def expand_iframe(desc, X, Y):
+    """What sp_iframe_rows_kernel computes from the run table (row wavefront)."""
+    if desc["kind"] == KIND_FLAT:
+        return np.full(X * Y, desc["flat_colour"], dtype=np.uint32)
+    runs, rows = desc["runs"], desc["rows"]
+    starts, words = runs[:, 0].astype(np.int64), runs[:, 1]
+    out = np.zeros((Y, X), dtype=np.uint32)
+    xs = np.arange(X)
+    for y in range(Y):
+        r0, r1 = int(rows[y]), int(rows[y + 1])
+        idx = y * X + xs
+        k = np.searchsorted(starts[r0:r1 + 1], idx, side="right") - 1 + r0
+        w = words[k]
+        kind, val = w >> 24, w & 0xFFFFFF
+        v = val.copy()
+        if y > 0:
+            up = out[y - 1]
+            left = np.empty(X, dtype=np.uint32)
+            left[1:] = up[:-1]
+            left[0] = out[y - 2, X - 1] if y >= 2 else 0
+            v = np.where(kind == RUN_ABOVE, up, v)
+            v = np.where(kind == RUN_ABOVE_PLUS, _add_bytes(up, val), v)
+            v = np.where(kind == RUN_ABOVE_LEFT, left, v)
+        else:
+            v = np.where(kind == RUN_CONST, v, 0)
+        out[y] = v
+    return out.reshape(-1)
+
+
+def expand_pframe(desc, prev, X, Y):
+    """What sp_pframe_kernel computes from the block table + payload."""
+    nbx, nby = (X + 15) // 16, (Y + 15) // 16
+    prev2 = prev.reshape(Y, X)
+    out = np.zeros((Y, X), dtype=np.uint32)
+    blocks, payload = desc["blocks"], desc["payload"]
+    flat_prev = prev.reshape(-1)
+    for by in range(nby):
+        for bx in range(nbx):
+            b = blocks[by * nbx + bx]
+            x16, y16 = bx * 16, by * 16
+            xe, ye = min(x16 + 16, X), min(y16 + 16, Y)
+            out[y16:ye, x16:xe] = prev2[y16:ye, x16:xe]
+            flags = int(b[0])
+            if not flags:
+                continue
+            x1, y1, x2, y2 = int(b[1]), int(b[2]), int(b[3]), int(b[4])
+            mx, my = np.frombuffer(b[8:12].tobytes(), dtype=np.int16)
+            off = int(np.frombuffer(b[12:16].tobytes(), dtype=np.uint32)[0])
+            w = x2 - x1
+            for ly in range(y1, y2):
+                for lx in range(x1, x2):
+                    x, y = x16 + lx, y16 + ly
+                    if x >= X or y >= Y:
+                        continue
+                    if flags & PB_MOTION:
+                        j = (y + int(my)) * X + x + int(mx)
+                        out[y, x] = flat_prev[j] if 0 <= j < X * Y else 0
+                    else:
+                        out[y, x] = payload[off + (ly - y1) * w + (lx - x1)]
+    return out.reshape(-1)

@@ -82,3 +82,65 @@ class OracleMSVideo1:
 
     def __del__(self):
         self.close()
+
+
+def _sp_lib():
+    L = lib()
+    if not getattr(L, "_sp_ready", False):
+        L.orc_sp_create.restype = C.c_void_p
+        L.orc_sp_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_sp_destroy.argtypes = [C.c_void_p]
+        L.orc_sp_preinit.argtypes = [C.c_void_p, C.c_int]
+        L.orc_sp_previous_frame.restype = C.c_void_p
+        L.orc_sp_previous_frame.argtypes = [C.c_void_p]
+        L.orc_sp_is_key_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.orc_sp_decompress_i.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        L.orc_sp_decompress_p.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L._sp_ready = True
+    return L
+
+
+class OracleScreenPressor:
+    """oracle/screenpressor_oracle.cpp behind the IVideoCodec method names."""
+
+    def __init__(self, width, height, bpp):
+        self.L = _sp_lib()
+        self.X, self.Y = width, height
+        self.h = self.L.orc_sp_create(width, height, bpp)
+        assert self.h
+        self._bufs = {}
+
+    def Preinit(self, lines):
+        self.L.orc_sp_preinit(self.h, lines)
+
+    def PreviousFrame(self):
+        a = self.L.orc_sp_previous_frame(self.h)
+        return self._bufs.get(a) if a else None
+
+    def IsKeyFrame(self, data):
+        data = bytes(data)
+        return bool(self.L.orc_sp_is_key_frame(self.h, data, len(data)))
+
+    def DecompressI(self, src, dst: np.ndarray):
+        """0 zero_state, 2 error_occured, 3 the reference would raise / hang"""
+        src = bytes(src)
+        self._bufs[dst.ctypes.data] = dst
+        return self.L.orc_sp_decompress_i(self.h, src, len(src), C.c_void_p(dst.ctypes.data))
+
+    def DecompressP(self, src, dst: np.ndarray):
+        src = bytes(src)
+        self._bufs[dst.ctypes.data] = dst
+        out, sg = C.c_void_p(), C.c_int()
+        rc = self.L.orc_sp_decompress_p(self.h, src, len(src), C.c_void_p(dst.ctypes.data), C.byref(out), C.byref(sg))
+        if rc != 0:
+            raise OracleAbort()
+        return (self._bufs.get(out.value) if out.value else None), bool(sg.value)
+
+    def close(self):
+        if self.h:
+            self.L.orc_sp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,118 @@
+"""CPU tests for the ScreenPressor path: encoder -> oracle round trips (lossless identity on known
+images), and the product's HOST stage (descriptor tables, re-expanded in numpy the way the HIP
+kernels expand them) against the oracle."""
+import numpy as np
+import pytest
+
+from jsplayer_amd import streamgen as sg
+from oracle_binding import OracleAbort, OracleScreenPressor
+import hoststage_binding as hs
+
+
+def oracle_decode_clip(w, h, bpp, chunks, keys, lines=36):
+    o = OracleScreenPressor(w, h, bpp)
+    o.Preinit(lines)
+    bufs = [np.zeros(w * h, np.int32) for _ in range(3)]
+    frames, sigs = [], []
+    for c, k in zip(chunks, keys):
+        dst = next(b for b in bufs if b is not o.PreviousFrame())
+        if k:
+            assert o.DecompressI(c, dst) == 0
+            sigs.append(None)
+        else:
+            data, sig = o.DecompressP(c, dst)
+            sigs.append(sig)
+        frames.append(o.PreviousFrame().view(np.uint32).copy())
+    return frames, sigs
+
+
+@pytest.mark.parametrize("version", [2, 3, 4])
+@pytest.mark.parametrize("size,bpp", [((64, 48), 24), ((320, 240), 24), ((100, 52), 24), ((37, 23), 24), ((64, 48), 16)])
+def test_encoder_oracle_round_trip(version, size, bpp):
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(300 + version, w, h, 8, bpp=bpp, version=version, key_every=5,
+                                      flat_at=(3,), unchanged_at=(2,))
+    got, sigs = oracle_decode_clip(w, h, bpp, chunks, keys)
+    for i, (g, f) in enumerate(zip(got, frames)):
+        assert np.array_equal(g, f), f"frame {i} (key={keys[i]}) differs"
+    assert chunks[2] == b"\x00" and sigs[2] is False
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_round_trip_1080p_iframe_and_pframe(version):
+    w, h = 1920, 1080
+    chunks, keys, frames = sg.sp_clip(3, w, h, 2, version=version)
+    got, _ = oracle_decode_clip(w, h, 24, chunks, keys)
+    assert np.array_equal(got[0], frames[0]) and np.array_equal(got[1], frames[1])
+
+
+def test_is_key_frame_and_headers():
+    o = OracleScreenPressor(16, 16, 24)
+    for b, exp in [(0x12, True), (0x11, True), (0x22, True), (0x21, True), (0x32, True), (0x31, True),
+                   (0x00, False), (0x01, False), (0x42, False), (0x13, False)]:
+        assert o.IsKeyFrame(bytes([b, 0, 0])) == exp
+    assert o.IsKeyFrame(b"") is False
+    # unknown frame type -> error_occured ; unknown version -> error_occured
+    dst = np.zeros(256, np.int32)
+    assert o.DecompressI(bytes([0x13, 0, 0, 0]), dst) == 2
+    assert o.DecompressI(bytes([0x52, 0, 0, 0, 0, 0, 0]), dst) == 2
+    # flat key frame before any coded key frame: the reference dereferences a null coder
+    assert o.DecompressI(bytes([0x11, 1, 2, 3]), dst) == 3
+
+
+def drive_host_stage(w, h, bpp, chunks, keys, frames, lines=36):
+    """Host stage -> descriptors -> numpy kernel emulation, against the oracle frame by frame."""
+    host = hs.HostStage(w, h, bpp)
+    host.preinit(lines)
+    got, sigs = oracle_decode_clip(w, h, bpp, chunks, keys, lines)
+    prev = None
+    for i, (c, k) in enumerate(zip(chunks, keys)):
+        d = host.decode(k, c)
+        assert d["status"] == 0, i
+        if d["kind"] == hs.KIND_NONE:
+            assert not d["adopted"]
+            cur = prev
+        elif d["kind"] in (hs.KIND_FLAT, hs.KIND_INTRA):
+            cur = hs.expand_iframe(d, w, h)
+        else:
+            cur = hs.expand_pframe(d, prev, w, h)
+            assert d["significant"] == sigs[i]
+        assert np.array_equal(cur, got[i]), f"frame {i} kind {d['kind']}: {(cur != got[i]).sum()} pixels differ"
+        assert np.array_equal(cur, frames[i])
+        prev = cur
+    host.close()
+
+
+@pytest.mark.parametrize("version", [2, 3, 4])
+@pytest.mark.parametrize("size,bpp", [((64, 48), 24), ((320, 240), 24), ((100, 52), 24), ((37, 23), 24), ((64, 48), 16)])
+def test_host_stage_descriptors_match_oracle(version, size, bpp):
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(500 + version, w, h, 10, bpp=bpp, version=version, key_every=6,
+                                      flat_at=(4,), unchanged_at=(2,))
+    drive_host_stage(w, h, bpp, chunks, keys, frames, lines=4)
+
+
+def test_host_stage_rejects_what_the_reference_cannot_survive():
+    host = hs.HostStage(16, 16, 24)
+    assert host.decode(True, bytes([0x13, 0, 0, 0]))["status"] == 2
+    assert host.decode(True, bytes([0x52, 0, 0, 0, 0, 0, 0]))["status"] == 2
+    assert host.decode(True, bytes([0x11, 1, 2, 3]))["status"] == 2   # flat first: reference raises
+    assert host.decode(False, bytes([1, 2, 3]))["kind"] == hs.KIND_NONE  # P before any I: ignored
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_truncated_streams_agree(version):
+    """A stream cut short: the v2 coder is poisoned by the missing bytes (NaN in the reference) and
+    the reference never returns; v3/v4 read zeros.  Oracle and host stage must take the same exit."""
+    w, h = 64, 48
+    chunks, keys, frames = sg.sp_clip(700, w, h, 2, version=version)
+    for cut in (1, 2, 5, 6, 9, len(chunks[0]) // 2, len(chunks[0]) - 3):
+        src = chunks[0][:cut]
+        o = OracleScreenPressor(w, h, 24)
+        dst = np.zeros(w * h, np.int32)
+        rc = o.DecompressI(src, dst)
+        host = hs.HostStage(w, h, 24)
+        d = host.decode(True, src)
+        assert (rc == 0) == (d["status"] == 0), (version, cut, rc, d["status"])
+        if rc == 0:
+            assert np.array_equal(hs.expand_iframe(d, w, h), dst.view(np.uint32))

@@ -1,0 +1,139 @@
+"""GPU parity tests for ScreenPressor (run with -m gpu): host entropy stage + HIP reconstruction,
+through the C ABI, against the CPU oracle on identical bytes — bit-exact frames, identical
+significant_changes, identical previous-frame identity."""
+import numpy as np
+import pytest
+
+from jsplayer_amd import CodecError, DecoderState, ScreenPressor
+from jsplayer_amd import streamgen as sg
+from oracle_binding import OracleAbort, OracleScreenPressor
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_buf(n, fill=0):
+    import torch
+    return torch.full((n,), fill, dtype=torch.int32, device="cuda")
+
+
+def to_np(t):
+    return t.cpu().numpy() if hasattr(t, "cpu") else t
+
+
+def drive_pair(w, h, bpp, chunks, keys, frames=None, lines=36, nbuf=3, host=False):
+    orc, gpu = OracleScreenPressor(w, h, bpp), ScreenPressor(w, h, bpp)
+    orc.Preinit(lines)
+    gpu.Preinit(lines)
+    obufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) for _ in range(nbuf)]
+    gbufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) if host else dev_buf(w * h, 0x00A5A5A5) for _ in range(nbuf)]
+    for i, (src, key) in enumerate(zip(chunks, keys)):
+        oprev, gprev = orc.PreviousFrame(), gpu.PreviousFrame()
+        oi = next(k for k in range(nbuf) if obufs[k] is not oprev)
+        gi = next(k for k in range(nbuf) if gbufs[k] is not gprev)
+        assert oi == gi
+        assert gpu.IsKeyFrame(src) == orc.IsKeyFrame(src)
+        if key:
+            rc = orc.DecompressI(src, obufs[oi])
+            st = gpu.DecompressI(src, gbufs[gi])
+            assert (rc == 0) == (st == DecoderState.zero_state), f"frame {i}: oracle {rc} vs {st}"
+        else:
+            try:
+                odata, osig = orc.DecompressP(src, obufs[oi])
+            except OracleAbort:
+                with pytest.raises(CodecError):
+                    gpu.DecompressP(src, gbufs[gi])
+            else:
+                res = gpu.DecompressP(src, gbufs[gi])
+                assert res.significant_changes == osig, f"frame {i}"
+                assert (res.data_pnt is gbufs[gi]) == (odata is obufs[oi]), f"frame {i}"
+                assert (res.data_pnt is None) == (odata is None)
+        onow, gnow = orc.PreviousFrame(), gpu.PreviousFrame()
+        assert (onow is None) == (gnow is None), f"frame {i}"
+        if onow is not None:
+            assert [k for k in range(nbuf) if obufs[k] is onow] == [k for k in range(nbuf) if gbufs[k] is gnow]
+            assert np.array_equal(onow, to_np(gnow)), f"frame {i}: previous frame differs"
+            if frames is not None:
+                assert np.array_equal(onow.view(np.uint32), frames[i]), f"frame {i}: not the encoded image"
+    gpu.StopAndClean()
+
+
+SIZES = [(64, 48), (320, 240), (100, 52), (37, 23), (1920, 1080)]
+
+
+@pytest.mark.parametrize("version", [2, 3, 4])
+@pytest.mark.parametrize("size", SIZES, ids=[f"{w}x{h}" for w, h in SIZES])
+def test_clip_parity_device(version, size):
+    w, h = size
+    n = 4 if w * h > 500000 else 12
+    chunks, keys, frames = sg.sp_clip(900 + version, w, h, n, version=version, key_every=7, flat_at=(5,),
+                                      unchanged_at=(2,))
+    drive_pair(w, h, 24, chunks, keys, frames)
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_clip_parity_16bpp(version):
+    w, h = 160, 96
+    chunks, keys, frames = sg.sp_clip(910, w, h, 8, bpp=16, version=version, flat_at=(4,))
+    drive_pair(w, h, 16, chunks, keys, frames)
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_clip_parity_host_pointers(version):
+    w, h = 320, 240
+    chunks, keys, frames = sg.sp_clip(920, w, h, 8, version=version, key_every=5)
+    drive_pair(w, h, 24, chunks, keys, frames, host=True)
+
+
+def test_bad_headers_and_flat_first_frame():
+    w, h = 32, 32
+    chunks, keys, _ = sg.sp_clip(930, w, h, 2, version=4)
+    bad = [bytes([0x13, 0, 0, 0]), bytes([0x52, 0, 0, 0, 0, 0]), bytes([0x11, 1, 2, 3]), b""]
+    drive_pair(w, h, 24, bad + chunks, [True] * len(bad) + keys)
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_truncated_key_frame(version):
+    w, h = 64, 48
+    chunks, keys, _ = sg.sp_clip(940, w, h, 3, version=version)
+    cut = chunks[0][: len(chunks[0]) // 2]
+    # a failed key frame leaves prevFrame null; the P frame after it aborts in the reference
+    drive_pair(w, h, 24, [chunks[0], chunks[1], cut, chunks[1], chunks[0], chunks[1]],
+               [True, False, True, False, True, False])
+
+
+def test_batch_of_key_frames_one_launch_and_p_clip():
+    import torch
+    w, h = 640, 360
+    # independent I-frames (each from its own encoder): one launch for the whole batch
+    streams, images = [], []
+    for i in range(6):
+        c, k, f = sg.sp_clip(950 + i, w, h, 1, version=4)
+        streams.append(c[0])
+        images.append(f[0])
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    dsts = [dev_buf(w * h, -1) for _ in range(6)]
+    st = gpu.stage_batch(streams, dsts)
+    info = st.info()
+    assert info["kernel_launches"] == 1 and info["runs"] > 0
+    st.decode()
+    gpu.sync()
+    status, adopted, _ = st.results()
+    assert status == [0] * 6 and adopted == [1] * 6
+    for d, img in zip(dsts, images):
+        assert np.array_equal(to_np(d).view(np.uint32), img)
+    st.close()
+    # a P clip staged as one batch: one launch per frame, replayable
+    chunks, keys, frames = sg.sp_clip(960, w, h, 10, version=4)
+    gpu2 = ScreenPressor(w, h, 24)
+    gpu2.Preinit(36)
+    dsts = [dev_buf(w * h, -1) for _ in range(10)]
+    st = gpu2.stage_batch(chunks, dsts, is_key=keys)
+    for _ in range(2):
+        st.decode()
+    gpu2.sync()
+    for d, img in zip(dsts, frames):
+        assert np.array_equal(to_np(d).view(np.uint32), img)
+    info = st.info()
+    assert info["kernel_launches"] == 10
+    st.close()
