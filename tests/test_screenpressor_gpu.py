@@ -96,9 +96,12 @@ def test_truncated_key_frame(version):
     w, h = 64, 48
     chunks, keys, _ = sg.sp_clip(940, w, h, 3, version=version)
     cut = chunks[0][: len(chunks[0]) // 2]
-    # a failed key frame leaves prevFrame null; the P frame after it aborts in the reference
-    drive_pair(w, h, 24, [chunks[0], chunks[1], cut, chunks[1], chunks[0], chunks[1]],
-               [True, False, True, False, True, False])
+    # v2: the cut poisons the range coder and the reference never returns -> error, prevFrame null.
+    # v3/v4: missing bytes read as 0 and some garbage frame comes out (compared pixel for pixel).
+    # Either way the next coded key frame resets every model and decoding recovers.  (Inter frames
+    # decoded against a garbage key frame are outside the contract: DESIGN.md "invalid streams".)
+    drive_pair(w, h, 24, [chunks[0], chunks[1], cut, chunks[0], chunks[1], chunks[2]],
+               [True, False, True, True, False, False])
 
 
 def test_batch_of_key_frames_one_launch_and_p_clip():
