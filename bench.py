@@ -33,11 +33,24 @@ WORKLOADS = {
     "msvideo1_16_1080p_keyframes_eight": dict(bits=16, w=1920, h=1080, frames=64, mix="eight", config_index=2),
     "msvideo1_8_1080p_keyframes_m1": dict(bits=8, w=1920, h=1080, frames=64, mix="m1", config_index=2),
     "msvideo1_16_1080p_inter70": dict(bits=16, w=1920, h=1080, frames=64, mix="m1", config_index=2, inter=0.70),
+    # BASELINE.json configs[2]: ScreenPressor 1080p I-frames (host rANS -> GPU run expansion), 64 key frames
+    "screenpressor_v4_1080p_iframes": dict(sp=True, version=4, w=1920, h=1080, frames=64, config_index=3, mode="intra"),
+    "screenpressor_v2_1080p_iframes": dict(sp=True, version=2, w=1920, h=1080, frames=64, config_index=3, mode="intra"),
+    # BASELINE.json configs[3]: ScreenPressor 1080p 300-frame clip, inter-frame kernel (frame 0 = key frame, untimed)
+    "screenpressor_v4_1080p_pclip300": dict(sp=True, version=4, w=1920, h=1080, frames=300, config_index=4, mode="inter"),
 }
 
 
 def build_clip(spec, rank):
     from jsplayer_amd import streamgen as sg
+    if spec.get("sp"):
+        if spec["mode"] == "intra":   # every frame a key frame of its own synthetic desktop
+            chunks, keys, _ = sg.sp_clip(spec["config_index"] + 1000 * rank, spec["w"], spec["h"], spec["frames"],
+                                         version=spec["version"], key_every=1)
+        else:
+            chunks, keys, _ = sg.sp_clip(spec["config_index"] + 1000 * rank, spec["w"], spec["h"], spec["frames"],
+                                         version=spec["version"])
+        return chunks, keys, None
     mix = {"m1": sg.MIX_M1, "solid": sg.MIX_ALL_SOLID, "eight": sg.MIX_ALL_EIGHT}[spec["mix"]]
     p_mix = sg.msv1_p_mix(spec["inter"], 40.0) if "inter" in spec else None
     # seeds +0..+7 for the 8-stream configuration
@@ -49,9 +62,9 @@ def cpu_baseline(spec, frames, keys, pal, budget_s=12.0):
     """Oracle (C++ restatement of the Haxe reference, -O2, one thread) on the same frames."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    from oracle_binding import OracleMSVideo1
+    from oracle_binding import OracleMSVideo1, OracleScreenPressor
     w, h = spec["w"], spec["h"]
-    orc = OracleMSVideo1(spec["bits"], w, h, pal)
+    orc = OracleScreenPressor(w, h, 24) if spec.get("sp") else OracleMSVideo1(spec["bits"], w, h, pal)
     orc.Preinit(36)
     bufs = [np.zeros(w * h, dtype=np.int32) for _ in range(2)]
     done, t0 = 0, time.perf_counter()
@@ -72,7 +85,7 @@ def cpu_baseline(spec, frames, keys, pal, budget_s=12.0):
         "cores": 1,
         "kind": "port",
         "sample": f"{done} frames ({done // len(frames)} passes over the same {len(frames)}-frame 1920x1080 batch), "
-                  f"{el:.1f} s, oracle/msvideo1_oracle.cpp -O2 single thread, DecompressI/P only",
+                  f"{el:.1f} s, oracle/ C++ restatement -O2 single thread, DecompressI/P only (entropy decode included)",
     }
 
 
@@ -101,14 +114,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit
+    from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
 
     spec = WORKLOADS[args.workload]
     w, h, nfr = spec["w"], spec["h"], spec["frames"]
     frames, keys, pal = build_clip(spec, rank)
-    codec = (MSVideo1_16bit(w, h, device=local_rank) if spec["bits"] == 16
-             else MSVideo1_8bit(w, h, pal, device=local_rank))
+    all_frames, all_keys = frames, keys
+    if spec.get("sp"):
+        codec = ScreenPressor(w, h, 24, device=local_rank)
+    else:
+        codec = (MSVideo1_16bit(w, h, device=local_rank) if spec["bits"] == 16
+                 else MSVideo1_8bit(w, h, pal, device=local_rank))
     codec.Preinit(36)
+    if spec.get("mode") == "inter":
+        # the clip's key frame is decoded up front; the timed batch is the inter frames only
+        first = torch.empty(w * h, dtype=torch.int32, device="cuda")
+        assert codec.DecompressI(frames[0], first) == 0
+        frames, keys, nfr = frames[1:], keys[1:], nfr - 1
     # a dedicated (non-null) stream: kernels and the timing events are queued on the same one
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -175,16 +197,17 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
-                "codec": f"MSVideo1_{spec['bits']}bit",
+                "codec": f"ScreenPressor v{spec['version']}" if spec.get("sp") else f"MSVideo1_{spec['bits']}bit",
                 "frame": f"{w}x{h}",
                 "frames_per_step": nfr,
                 "streams": args.gpus,
                 "sharding": "one independent AVI stream per GPU, no data-path collective",
-                "inputs": "stream bytes + host-built block descriptors resident in HBM",
+                "inputs": "host-built descriptor tables (+ MSVideo1 stream bytes) resident in HBM",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "msv1_blocks_kernel",
+                "kernel": ("sp_iframe_rows_kernel" if spec.get("mode") == "intra" else "sp_pframe_kernel")
+                          if spec.get("sp") else "msv1_blocks_kernel",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -202,7 +225,7 @@ def main():
             "total_frames": total_frames,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, frames, keys, pal)
+            out["cpu_baseline"] = cpu_baseline(spec, all_frames, all_keys, pal)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out), flush=True)
     staged.close()

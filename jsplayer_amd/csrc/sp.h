@@ -47,6 +47,7 @@ static_assert(sizeof(PBlock) == 16, "PBlock is 16 bytes");
 
 struct Geometry {
     int X, Y, bpp, nbx, nby;
+    bool aligned16 = true;  // launch-time: every frame buffer of the launch is 16-byte aligned
 };
 
 enum class FrameKind { None, Flat, Intra, Inter };

@@ -42,6 +42,7 @@ struct SpCodec : jsp_codec {
         X = w;
         Y = h;
         if (w > kMaxIntraWidth) throw std::runtime_error("ScreenPressor frames wider than 8192 pixels are not supported");
+        if (iframe_lds_bytes(host.geo()) > 160 * 1024) throw std::runtime_error("ScreenPressor frame too large for the LDS plan of the I-frame kernel");
     }
     int preinit(int lines) override { host.preinit(lines); return JSP_ZERO_STATE; }
     int is_key_frame(const uint8_t* src, size_t n) override { return HostDecoder::is_key_frame(src, n) ? 1 : 0; }
@@ -57,6 +58,8 @@ struct SpCodec : jsp_codec {
         const int nf = (int)frames.size();
         const Geometry& g = host.geo();
         st->geo = g;
+        for (const auto& f : frames)
+            if (reinterpret_cast<uintptr_t>(f.dst) & 15) st->geo.aligned16 = false;
         st->ops.clear();
         st->decoded = false;
         st->status.assign(nf, JSP_ZERO_STATE);

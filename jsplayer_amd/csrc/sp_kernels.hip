@@ -16,11 +16,19 @@ namespace {
 
 constexpr int IWG = 512;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for this wave's
+// outstanding global stores (vmcnt(0)); the row loop would then pay a full HBM/L2 write latency per
+// image row although no other wave ever reads those stores back.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t add_bytes(uint32_t u, uint32_t d) {  // per byte, bytes 0..2
     return (((u & 0x00FF00FFu) + (d & 0x00FF00FFu)) & 0x00FF00FFu) | (((u & 0x0000FF00u) + (d & 0x0000FF00u)) & 0x0000FF00u);
 }
 
-__global__ __launch_bounds__(IWG) void sp_iframe_rows_kernel(const IFrameArgs* __restrict__ args, int X, int Y) {
+__global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
+                                                                    int run_cap) {
     extern __shared__ __align__(16) uint32_t lds[];
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
@@ -30,64 +38,248 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_kernel(const IFrameArgs* _
         for (size_t i = tid; i < npx; i += IWG) dst[i] = fa.colour;
         return;
     }
-    // LDS plan: two row buffers (with one guard word in front for the x-1 access) + run staging
-    const int rowcap = X + 4;
+    // LDS plan: two row buffers, the whole row index, and a window of run records {start, word}
+    // covering as many rows as fit (one global round trip per window instead of one per row)
+    const int rowcap = (X + 4 + 3) & ~3;
     uint32_t* rowbuf0 = lds;
     uint32_t* rowbuf1 = lds + rowcap;
-    uint32_t* rstart = lds + 2 * rowcap;          // X + 2 run starts
-    uint32_t* rword = rstart + (X + 2);           // X + 2 run words
-    uint32_t* lastpix = rword + (X + 2);          // last pixel of each of the 4 most recent rows
+    uint32_t* rowidx = lds + 2 * rowcap;              // Y + 1 entries
+    uint32_t* lastpix = rowidx + ((Y + 1 + 3) & ~3);  // last pixel of each of the 4 most recent rows
+    uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records
+    for (int k = tid; k <= Y; k += IWG) rowidx[k] = fa.row_run[k];
     if (tid < 4) lastpix[tid] = 0;
+    __syncthreads();
     const bool vec = (X & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-    for (int y = 0; y < Y; ++y) {
-        uint32_t* cur = (y & 1) ? rowbuf1 : rowbuf0;
-        const uint32_t* up = (y & 1) ? rowbuf0 : rowbuf1;
-        const uint32_t r0 = fa.row_run[y], r1 = fa.row_run[y + 1];
-        const int nr = (int)(r1 - r0) + 1;        // runs r0..r1 (the last one may start in the next row)
-        for (int k = tid; k < nr; k += IWG) {
-            const IRun r = fa.runs[r0 + k];
-            rstart[k] = r.start;
-            rword[k] = r.word;
-        }
-        // pixel (X-1, y-2) for the x == 0 case of the above-left predictor (linear index i-X-1)
-        const uint32_t wrap_left = y >= 2 ? lastpix[(y - 2) & 3] : 0u;
-        __syncthreads();
-        const uint32_t row0 = (uint32_t)((size_t)y * X);
-        for (int x0 = tid * 4; x0 < X; x0 += IWG * 4) {
-            // run holding pixel x0: last k with rstart[k] <= row0 + x0
-            const uint32_t i0 = row0 + x0;
-            int lo = 0, hi = nr - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (rstart[mid] <= i0) lo = mid; else hi = mid - 1;
-            }
-            int k = lo;
-            uint32_t px[4];
+    int hint = 0;  // this lane's run index relative to the row start, carried from row to row:
+                   // neighbouring rows of screen content are cut into runs almost identically
+    int y = 0;
+    while (y < Y) {
+        // window: rows y .. y_end-1 whose runs rowidx[y] .. rowidx[y_end] fit in run_cap records
+        // (a single row always fits: run_cap >= X + 2)
+        const uint32_t w0 = rowidx[y];
+        int y_end = y + 1;
+        while (y_end < Y && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
+        const int wn = (int)(rowidx[y_end] - w0) + 1;
+        const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
+        for (int k = tid; k < wn; k += IWG) win[k] = gruns[k];
+        __syncthreads();  // the run records arrive through vmcnt: full barrier once per window
+        for (; y < y_end; ++y) {
+            uint32_t* cur = (y & 1) ? rowbuf1 : rowbuf0;
+            const uint32_t* up = (y & 1) ? rowbuf0 : rowbuf1;
+            const uint2* rr = win + (int)(rowidx[y] - w0);          // first run of this row
+            const int nr = (int)(rowidx[y + 1] - rowidx[y]) + 1;    // runs intersecting the row
+            // pixel (X-1, y-2) for the x == 0 case of the above-left predictor (linear index i-X-1)
+            const uint32_t wrap_left = y >= 2 ? lastpix[(y - 2) & 3] : 0u;
+            const uint32_t row0 = (uint32_t)((size_t)y * X);
+            for (int x0 = tid * 4; x0 < X; x0 += IWG * 4) {
+                const uint32_t i0 = row0 + x0;
+                // the row above, fetched before the run lookup so both LDS latencies overlap
+                uint32_t u[5];  // u[0] = pixel x0-1 of the row above, u[1..4] = pixels x0..x0+3
+                if (vec) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(up + x0);
+                    u[1] = q.x; u[2] = q.y; u[3] = q.z; u[4] = q.w;
+                } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = x0 + j;
-                if (x < X) {
-                    const uint32_t i = row0 + x;
-                    while (k + 1 < nr && rstart[k + 1] <= i) ++k;
-                    const uint32_t w = rword[k];
-                    const uint32_t kind = w >> 24, val = w & 0xFFFFFFu;
+                    for (int j = 0; j < 4; ++j) u[1 + j] = x0 + j < X ? up[x0 + j] : 0u;
+                }
+                u[0] = x0 > 0 ? up[x0 - 1] : wrap_left;
+                // run holding pixel x0: try the hint, fall back to a binary search
+                int k = hint < nr ? hint : nr - 1;
+                uint2 e = rr[k];
+                uint2 nx = k + 1 < nr ? rr[k + 1] : make_uint2(0xFFFFFFFFu, 0u);
+                if (!(e.x <= i0 && i0 < nx.x)) {
+                    int lo = 0, hi = nr - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (rr[mid].x <= i0) lo = mid; else hi = mid - 1;
+                    }
+                    k = lo;
+                    e = rr[k];
+                    nx = k + 1 < nr ? rr[k + 1] : make_uint2(0xFFFFFFFFu, 0u);
+                }
+                hint = k;
+                uint32_t word = e.y;
+                uint32_t px[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t i = i0 + j;
+                    while (nx.x <= i) {   // next run starts at or before this pixel
+                        ++k;
+                        word = nx.y;
+                        nx = k + 1 < nr ? rr[k + 1] : make_uint2(0xFFFFFFFFu, 0u);
+                    }
+                    const uint32_t kind = word >> 24, val = word & 0xFFFFFFu;
                     uint32_t v;
                     if (kind == RUN_CONST) v = val;
                     else if (y == 0) v = 0;                                  // above the buffer: undefined -> 0
-                    else if (kind == RUN_ABOVE) v = up[x];
-                    else if (kind == RUN_ABOVE_PLUS) v = add_bytes(up[x], val);
-                    else v = x > 0 ? up[x - 1] : wrap_left;               // RUN_ABOVE_LEFT
+                    else if (kind == RUN_ABOVE) v = u[1 + j];
+                    else if (kind == RUN_ABOVE_PLUS) v = add_bytes(u[1 + j], val);
+                    else v = u[j];                                           // RUN_ABOVE_LEFT
                     px[j] = v;
-                    cur[x] = v;
-                    if (x == X - 1) lastpix[y & 3] = v;
-                } else
-                    px[j] = 0;
+                }
+                if (vec) {
+                    const uint4 q = make_uint4(px[0], px[1], px[2], px[3]);
+                    *reinterpret_cast<uint4*>(cur + x0) = q;
+                    *reinterpret_cast<uint4*>(dst + row0 + x0) = q;
+                    if (x0 + 4 == X) lastpix[y & 3] = px[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (x0 + j < X) {
+                            cur[x0 + j] = px[j];
+                            dst[row0 + x0 + j] = px[j];
+                            if (x0 + j == X - 1) lastpix[y & 3] = px[j];
+                        }
+                }
             }
-            if (vec) *reinterpret_cast<uint4*>(dst + row0 + x0) = make_uint4(px[0], px[1], px[2], px[3]);
-            else
-                for (int j = 0; j < 4 && x0 + j < X; ++j) dst[row0 + x0 + j] = px[j];
+            lds_barrier();
         }
-        __syncthreads();
+    }
+}
+
+// Fast path (X a multiple of 4, X <= 4*WG): no per-pixel search at all.
+//   scatter : one lane per run writes (run index + 1) at the run's first column of the row — and at
+//             every 256-pixel wave boundary the run covers — into a zeroed "head" row in LDS;
+//   resolve : a lane reads the 4 heads of its pixels, takes the running maximum (heads grow with the
+//             column), and gets the carry from the nearest lower lane that saw a head through one
+//             ballot + one cross-lane read; the first lane of every wave always sees a head.
+// The scatter for row y+1 does not depend on row y's pixels, so it is issued before the single
+// end-of-row barrier: one barrier and about four LDS round trips per image row.
+template <int WG>
+__global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
+                                                            int run_cap) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const IFrameArgs fa = args[blockIdx.x];
+    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
+    const int tid = threadIdx.x;
+    const size_t npx = (size_t)X * Y;
+    if (fa.flat) {
+        for (size_t i = (size_t)tid * 4; i < npx; i += (size_t)WG * 4)
+            *reinterpret_cast<uint4*>(dst + i) = make_uint4(fa.colour, fa.colour, fa.colour, fa.colour);
+        return;
+    }
+    const int rowcap = (X + 4 + 3) & ~3;
+    uint32_t* rowbuf0 = lds;
+    uint32_t* rowbuf1 = lds + rowcap;
+    uint32_t* head0 = lds + 2 * rowcap;
+    uint32_t* head1 = lds + 3 * rowcap;
+    uint32_t* rowidx = lds + 4 * rowcap;              // Y + 1 entries
+    uint32_t* lastpix = rowidx + ((Y + 1 + 3) & ~3);
+    uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records {start, word}
+    for (int k = tid; k <= Y; k += WG) rowidx[k] = fa.row_run[k];
+    for (int k = tid; k < 2 * rowcap; k += WG) head0[k] = 0;   // head0 and head1 are contiguous
+    if (tid < 4) lastpix[tid] = 0;
+    __syncthreads();
+    const int x0 = tid * 4;
+    const int lane = tid & 63;
+
+    auto scatter = [&](int yy, uint32_t w0, uint32_t* head) {
+        const uint2* rr = win + (int)(rowidx[yy] - w0);
+        const int nr = (int)(rowidx[yy + 1] - rowidx[yy]) + 1;
+        const uint32_t row0 = (uint32_t)((size_t)yy * X);
+        for (int r = tid; r < nr; r += WG) {
+            const uint32_t s = rr[r].x;
+            const uint32_t e = r + 1 < nr ? rr[r + 1].x : row0 + (uint32_t)X;
+            const uint32_t col = s <= row0 ? 0u : s - row0;
+            if (col >= (uint32_t)X) continue;            // the run that opens the next row
+            head[col] = (uint32_t)r + 1u;
+            const uint32_t ecol = e - row0 < (uint32_t)X ? e - row0 : (uint32_t)X;
+            for (uint32_t p = ((col >> 8) + 1u) << 8; p < ecol; p += 256u) head[p] = (uint32_t)r + 1u;
+        }
+    };
+
+    int y = 0;
+    while (y < Y) {
+        const uint32_t w0 = rowidx[y];
+        int y_end = y + 1;
+        while (y_end < Y && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
+        const int wn = (int)(rowidx[y_end] - w0) + 1;
+        const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
+        for (int k = tid; k < wn; k += WG) win[k] = gruns[k];
+        __syncthreads();  // run records arrive through vmcnt: full barrier once per window
+        scatter(y, w0, (y & 1) ? head1 : head0);
+        lds_barrier();
+        uint32_t ri0 = rowidx[y], ri1 = rowidx[y + 1];       // rolling copies of the row index
+        for (; y < y_end; ++y) {
+            uint32_t* cur = (y & 1) ? rowbuf1 : rowbuf0;
+            const uint32_t* up = (y & 1) ? rowbuf0 : rowbuf1;
+            uint32_t* head = (y & 1) ? head1 : head0;
+            uint32_t* head_next = (y & 1) ? head0 : head1;
+            const uint2* rr = win + (int)(ri0 - w0);
+            const bool more = y + 1 < y_end;
+            // ---- all loads of this row that do not depend on each other, issued together -------
+            const uint32_t ri2 = more ? rowidx[y + 2] : ri1;
+            const uint32_t wrap_left = y >= 2 ? lastpix[(y - 2) & 3] : 0u;
+            const bool active = x0 < X;
+            uint4 h = make_uint4(0, 0, 0, 0), q = make_uint4(0, 0, 0, 0);
+            uint32_t uleft = 0;
+            if (active) {
+                h = *reinterpret_cast<const uint4*>(head + x0);
+                q = *reinterpret_cast<const uint4*>(up + x0);
+                uleft = x0 > 0 ? up[x0 - 1] : wrap_left;
+            }
+            // first scatter item of the NEXT row (rows rarely have more runs than lanes)
+            const uint2* rn = win + (int)(ri1 - w0);
+            const int nr_next = more ? (int)(ri2 - ri1) + 1 : 0;
+            uint32_t ns = 0, ne = 0;
+            if (tid < nr_next) {
+                ns = rn[tid].x;
+                ne = tid + 1 < nr_next ? rn[tid + 1].x : 0xFFFFFFFFu;
+            }
+            const uint32_t row0 = (uint32_t)((size_t)y * X);
+            // ---- resolve ---------------------------------------------------------------------
+            if (active) {
+                *reinterpret_cast<uint4*>(head + x0) = make_uint4(0, 0, 0, 0);  // ready for row y+2
+                const uint32_t l0 = h.x, l1 = max(l0, h.y), l2 = max(l1, h.z), l3 = max(l2, h.w);
+                const unsigned long long seen = __ballot(l3 != 0u);
+                const unsigned long long lower = seen & ((1ull << lane) - 1ull);
+                const int src = lower ? 63 - __clzll((long long)lower) : lane;
+                uint32_t carry = (uint32_t)__shfl((int)l3, src);
+                if (!lower) carry = 0;
+                // run of each pixel (lane 0 of a wave always has h.x != 0)
+                const uint32_t w_0 = rr[max(carry, l0) - 1u].y, w_1 = rr[max(carry, l1) - 1u].y,
+                               w_2 = rr[max(carry, l2) - 1u].y, w_3 = rr[max(carry, l3) - 1u].y;
+                const uint32_t u[5] = {uleft, q.x, q.y, q.z, q.w};
+                const uint32_t w[4] = {w_0, w_1, w_2, w_3};
+                uint32_t px[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t kind = w[j] >> 24, val = w[j] & 0xFFFFFFu;
+                    const uint32_t above = kind == RUN_ABOVE_LEFT ? u[j] : u[j + 1];
+                    uint32_t v = kind == RUN_ABOVE_PLUS ? add_bytes(above, val) : above;
+                    if (y == 0) v = 0;                      // above the buffer: undefined -> 0
+                    px[j] = kind == RUN_CONST ? val : v;
+                }
+                const uint4 o = make_uint4(px[0], px[1], px[2], px[3]);
+                *reinterpret_cast<uint4*>(cur + x0) = o;
+                *reinterpret_cast<uint4*>(dst + row0 + x0) = o;
+                if (x0 + 4 == X) lastpix[y & 3] = px[3];
+            }
+            // ---- scatter the heads of row y+1 ------------------------------------------------
+            if (more) {
+                const uint32_t nrow0 = row0 + (uint32_t)X;
+                if (tid < nr_next) {
+                    const uint32_t col = ns <= nrow0 ? 0u : ns - nrow0;
+                    if (col < (uint32_t)X) {
+                        head_next[col] = (uint32_t)tid + 1u;
+                        const uint32_t en = ne < nrow0 + (uint32_t)X ? ne : nrow0 + (uint32_t)X;
+                        for (uint32_t p = ((col >> 8) + 1u) << 8; p < en - nrow0; p += 256u) head_next[p] = (uint32_t)tid + 1u;
+                    }
+                }
+                for (int r = tid + WG; r < nr_next; r += WG) {   // rows with more runs than lanes
+                    const uint32_t s2 = rn[r].x;
+                    const uint32_t e2 = r + 1 < nr_next ? rn[r + 1].x : nrow0 + (uint32_t)X;
+                    const uint32_t col = s2 <= nrow0 ? 0u : s2 - nrow0;
+                    if (col >= (uint32_t)X) continue;
+                    head_next[col] = (uint32_t)r + 1u;
+                    const uint32_t ecol = e2 - nrow0 < (uint32_t)X ? e2 - nrow0 : (uint32_t)X;
+                    for (uint32_t p = ((col >> 8) + 1u) << 8; p < ecol; p += 256u) head_next[p] = (uint32_t)r + 1u;
+                }
+            }
+            ri0 = ri1;
+            ri1 = ri2;
+            lds_barrier();
+        }
     }
 }
 
@@ -150,18 +342,51 @@ __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ d
 
 }  // namespace
 
-size_t iframe_lds_bytes(const Geometry& g) { return sizeof(uint32_t) * (2 * (size_t)(g.X + 4) + 2 * (size_t)(g.X + 2) + 4); }
+namespace {
+// LDS words needed besides the run window: row buffers (+ head rows on the fast path), row index,
+// last-pixel ring
+size_t iframe_fixed_words(const Geometry& g, bool fast) {
+    const size_t rowcap = ((size_t)g.X + 4 + 3) & ~size_t(3);
+    return (fast ? 4 : 2) * rowcap + (((size_t)g.Y + 1 + 3) & ~size_t(3)) + 4;
+}
+bool iframe_fast(const Geometry& g) { return (g.X & 3) == 0 && g.X <= 4096; }
+// run records staged per window: what a 72 KiB budget leaves (two workgroups per CU), at least a row
+int iframe_run_cap(const Geometry& g) {
+    const size_t fixed = iframe_fixed_words(g, iframe_fast(g));
+    const size_t budget_words = (72 * 1024) / 4;
+    size_t cap = budget_words > fixed ? (budget_words - fixed) / 2 : 0;
+    if (cap < (size_t)g.X + 2) cap = (size_t)g.X + 2;
+    return (int)cap;
+}
+}  // namespace
+size_t iframe_lds_bytes(const Geometry& g) {
+    return sizeof(uint32_t) * (iframe_fixed_words(g, iframe_fast(g)) + 2 * (size_t)iframe_run_cap(g));
+}
 
 void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hipStream_t stream) {
     if (nframes <= 0) return;
     const size_t lds = iframe_lds_bytes(g);
+    const int cap = iframe_run_cap(g);
+    // frame buffers handed to the fast path must be 16-byte aligned (checked by the caller: the
+    // codec routes misaligned buffers to the search kernel through g.X & 3 semantics is not enough)
     static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel),
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_search_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sp_iframe_rows_kernel, dim3(nframes), dim3(IWG), lds, stream, d_args, g.X, g.Y);
+    if (iframe_fast(g) && g.aligned16) {
+        if (g.X <= 2048)
+            hipLaunchKernelGGL(sp_iframe_rows_kernel<512>, dim3(nframes), dim3(512), lds, stream, d_args, g.X, g.Y, cap);
+        else
+            hipLaunchKernelGGL(sp_iframe_rows_kernel<1024>, dim3(nframes), dim3(1024), lds, stream, d_args, g.X, g.Y, cap);
+    } else {
+        hipLaunchKernelGGL(sp_iframe_rows_search_kernel, dim3(nframes), dim3(IWG), lds, stream, d_args, g.X, g.Y, cap);
+    }
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,
