@@ -159,14 +159,11 @@ def main():
     status, adopted, _ = staged.results()
     assert all(s == 0 for s in status)
 
-    # trivial counter reduce over RCCL (north_star): frames and pixels decoded by the whole job
-    counts = torch.tensor([nfr * args.steps, nfr * args.steps * w * h], dtype=torch.int64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if distributed:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_frames, total_pixels = int(counts[0]), int(counts[1])
-    elapsed = float(tmax[0])
+    # trivial counter reduce over RCCL (north_star): frames and pixels decoded by the whole job,
+    # time = max over ranks
+    from jsplayer_amd.sharding import reduce_counters
+    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * w * h, elapsed,
+                                                          device="cuda")
 
     if rank == 0:
         launches = info["kernel_launches"] * args.steps

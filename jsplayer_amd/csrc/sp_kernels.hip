@@ -297,16 +297,21 @@ __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ d
     const int y = by * 16 + ly;
     const int x0 = bx * 16 + (chunk & 3) * 4;
     if (y >= Y || x0 >= X) return;
-    const PBlock pb = blocks[(size_t)by * nbx + bx];
     const size_t npx = (size_t)X * Y;
     const size_t i0 = (size_t)y * X + x0;
+    const bool full = vec && x0 + 4 <= X;
+    // the block record and the co-located pixels of the previous frame are fetched together: most
+    // blocks are unchanged, and a dependent second round trip would double this short kernel
+    const PBlock pb = blocks[(size_t)by * nbx + bx];
+    uint4 same = make_uint4(0, 0, 0, 0);
+    if (full) same = *reinterpret_cast<const uint4*>(prev + i0);
     uint32_t px[4];
     const int cx0 = (chunk & 3) * 4;          // chunk origin relative to the block
     const bool row_in = ly >= pb.y1 && ly < pb.y2;
     const bool touched = pb.flags != 0 && row_in && cx0 < pb.x2 && cx0 + 4 > pb.x1;
     if (!touched) {
-        if (vec && x0 + 4 <= X) {
-            *reinterpret_cast<uint4*>(dst + i0) = *reinterpret_cast<const uint4*>(prev + i0);
+        if (full) {
+            *reinterpret_cast<uint4*>(dst + i0) = same;
             return;
         }
 #pragma unroll
@@ -330,7 +335,8 @@ __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ d
                     v = payload[pb.payload + (uint32_t)((ly - pb.y1) * w + (rx - pb.x1))];
                 }
             } else
-                v = prev[i0 + j];             // base copy around a sub-rectangle
+                v = full ? (j == 0 ? same.x : j == 1 ? same.y : j == 2 ? same.z : same.w)
+                         : prev[i0 + j];      // base copy around a sub-rectangle
         }
         px[j] = v;
     }
