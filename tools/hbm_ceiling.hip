@@ -71,6 +71,28 @@ __global__ __launch_bounds__(256) void fill_blocks_xcd(uint32_t* __restrict__ ba
     for (int y = 0; y < 4; ++y) *reinterpret_cast<u32x4*>(p + (size_t)y * X) = x;
 }
 
+// F: block-shaped, ONE store per lane: workgroup = 64 blocks x 4 rows, wave w writes row w (1 KiB contiguous)
+__global__ __launch_bounds__(256) void fill_blocks_rowsplit(uint32_t* __restrict__ base, int nblocks, int nbx, int X, size_t frame_ints) {
+    uint32_t* dst = base + (size_t)blockIdx.y * frame_ints;
+    const int blk = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = threadIdx.x >> 6;
+    if (blk >= nblocks) return;
+    int by = blk / nbx, bx = blk - by * nbx;
+    uint32_t* p = dst + ((size_t)by * 4 + y) * X + bx * 4;
+    *reinterpret_cast<u32x4*>(p) = u32x4{(uint32_t)blk, 1u, 2u, 3u};
+}
+// G: two stores per lane: workgroup = 128 blocks x 2 row pairs
+__global__ __launch_bounds__(256) void fill_blocks_rowsplit2(uint32_t* __restrict__ base, int nblocks, int nbx, int X, size_t frame_ints) {
+    uint32_t* dst = base + (size_t)blockIdx.y * frame_ints;
+    const int blk = blockIdx.x * 128 + (threadIdx.x & 127);
+    const int y = (threadIdx.x >> 7) * 2;
+    if (blk >= nblocks) return;
+    int by = blk / nbx, bx = blk - by * nbx;
+    uint32_t* p = dst + ((size_t)by * 4 + y) * X + bx * 4;
+    *reinterpret_cast<u32x4*>(p) = u32x4{(uint32_t)blk, 1u, 2u, 3u};
+    *reinterpret_cast<u32x4*>(p + X) = u32x4{(uint32_t)blk, 1u, 2u, 4u};
+}
+
 template <class F>
 static double time_us(F&& launch, int reps) {
     hipEvent_t a, b;
@@ -112,6 +134,11 @@ int main() {
         double e = time_us([&] { fill_blocks_xcd<<<dim3(((wpf + 7) / 8) * 8, F), 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints, wpf); }, 50);
         printf("A linear 4 stores/lane %7.1f us %6.0f GB/s | D row-linear 512-lane WG %7.1f us %6.0f GB/s | E block-shaped xcd-remap %7.1f us %6.0f GB/s\n",
                a, bytes / a / 1e3, dd, bytes / dd / 1e3, e, bytes / e / 1e3);
+    }
+    {
+        double f = time_us([&] { fill_blocks_rowsplit<<<dim3((nblocks + 63) / 64, F), 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints); }, 50);
+        double g2 = time_us([&] { fill_blocks_rowsplit2<<<dim3((nblocks + 127) / 128, F), 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints); }, 50);
+        printf("F block-shaped 1 store/lane (wave = row) %7.1f us %6.0f GB/s | G 2 stores/lane %7.1f us %6.0f GB/s\n", f, bytes / f / 1e3, g2, bytes / g2 / 1e3);
     }
     double t7 = time_us([&] { (void)hipMemsetAsync(d, 0, bytes, 0); }, 20);
     double t8 = time_us([&] { (void)hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0); }, 20);
