@@ -1,0 +1,130 @@
+"""Manager.worker-equivalent decode loop: the direct caller of the plugin surface,
+kept to what touches the codec — construction from VideoInfo (Manager.hx:103-142), the frame-buffer
+pool that never hands out the buffer holding the previous frame (:424-443,470-477), the
+DecompressI / DecompressP protocol with its identity test (:499-524) and
+`frames_differ_significantly` for key frames (:392-421).  Timers, seeking, bitmaps and audio of the
+reference's Manager are not rebuilt.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from .avi import CODEC_MSVC16, CODEC_MSVC8, CODEC_SCREENPRESSOR, VideoInfo
+
+INSIGNIFICANT_LINES = 36  # Manager.hx:61
+NUM_BUFFERS = 8           # Main.hx:148 (the pool holds NUM_BUFFERS + 1 frames, Manager.hx:114-118)
+
+
+@dataclass
+class DecodedFrame:
+    index: int
+    key: bool
+    buffer_index: int            # pool slot holding the picture shown for this frame
+    significant_changes: Optional[bool]
+    state: int = 0               # DecoderState of a key frame
+
+
+def make_decoder(vi: VideoInfo, classes) -> object:
+    """`classes` = (MSVideo1_16bit, MSVideo1_8bit, ScreenPressor) — the HIP codecs or the oracle's."""
+    m16, m8, sp = classes
+    if vi.codec == CODEC_SCREENPRESSOR:
+        return sp(vi.X, vi.Y, vi.bpp)
+    if vi.codec == CODEC_MSVC16:
+        return m16(vi.X, vi.Y)
+    if vi.codec == CODEC_MSVC8:
+        return m8(vi.X, vi.Y, vi.palette or b"")
+    raise ValueError(vi.codec)
+
+
+def _differ(a, b, start: int) -> bool:
+    if isinstance(a, np.ndarray):
+        return bool(np.any(a[start:] != b[start:]))
+    return bool((a[start:] != b[start:]).any().item())  # torch tensors
+
+
+class Manager:
+    """Feeds compressed frames to an IVideoCodec in order, with the reference's buffer discipline."""
+
+    def __init__(self, vi: VideoInfo, decoder, alloc: Callable[[int], object], num_buffers: int = NUM_BUFFERS):
+        self.vi, self.decoder = vi, decoder
+        self.buffers = [alloc(vi.X * vi.Y) for _ in range(num_buffers + 1)]
+        self.holds: List[Optional[range]] = [None] * len(self.buffers)  # frames each slot currently shows
+        self.decoder.Preinit(INSIGNIFICANT_LINES)
+        self.next_frame_to_decode = 0
+        self.frame_of_interest = 0
+        self.log: List[DecodedFrame] = []
+
+    def _slot_of(self, buf) -> int:
+        for i, b in enumerate(self.buffers):
+            if b is buf:
+                return i
+        return -1
+
+    def _get_free_buffer(self, prev_idx: int) -> int:  # Manager.hx:424-443
+        oldest, oldest_first = -1, 1 << 30
+        for i, h in enumerate(self.holds):
+            if i == prev_idx:
+                continue
+            if h is None:
+                return i
+            if h.stop - 1 < self.frame_of_interest and h.start < oldest_first:
+                oldest, oldest_first = i, h.start
+        if oldest >= 0:
+            self.holds[oldest] = None
+        return oldest
+
+    def worker(self, frame: bytes, index: int, prev_key_bytes: Optional[bytes]) -> DecodedFrame:
+        """One decode tick for compressed frame `index` (Manager.hx:454-539)."""
+        dec = self.decoder
+        key = index == 0 or dec.IsKeyFrame(frame)          # DataLoaderAVISeq.hx:45
+        prev = dec.PreviousFrame()
+        prev_idx = self._slot_of(prev) if prev is not None else -1
+        self.frame_of_interest = index                       # sequential playback keeps up with decode
+        free = self._get_free_buffer(prev_idx)
+        assert free >= 0
+        new = self.buffers[free]
+        if key:
+            state = int(dec.DecompressI(frame, new))
+            sig: Optional[bool] = None
+            if state == 0:
+                self.holds[free] = range(index, index + 1)
+                # frames_differ_significantly, Manager.hx:392-421
+                if index == 0:
+                    sig = True
+                elif prev_key_bytes is not None:
+                    sig = prev_key_bytes != frame
+                elif prev is None:
+                    sig = True
+                else:
+                    sig = _differ(new, prev, INSIGNIFICANT_LINES * self.vi.X)
+            out = DecodedFrame(index, True, free, sig, state)
+        else:
+            res = dec.DecompressP(frame, new)
+            shown = free
+            if res.data_pnt is not None:
+                if res.data_pnt is prev:                     # "no changes": the old slot keeps showing
+                    h = self.holds[prev_idx]
+                    self.holds[prev_idx] = range(h.start, index + 1) if h else range(index, index + 1)
+                    shown = prev_idx
+                else:
+                    self.holds[free] = range(index, index + 1)
+            out = DecodedFrame(index, False, shown, res.significant_changes)
+        self.log.append(out)
+        self.next_frame_to_decode = index + 1
+        return out
+
+    def play(self, frames: Sequence[bytes], on_frame: Optional[Callable[[DecodedFrame, object], None]] = None):
+        prev_key = None
+        for i, f in enumerate(frames):
+            was_key = i == 0 or self.decoder.IsKeyFrame(f)
+            d = self.worker(f, i, prev_key if was_key and i > 0 and self._last_was_key else None)
+            self._last_was_key = was_key
+            prev_key = f if was_key else prev_key
+            if on_frame:
+                on_frame(d, self.buffers[d.buffer_index])
+        return self.log
+
+    _last_was_key = False
