@@ -104,6 +104,12 @@ int jsp_upload(int32_t* device_frame, const int32_t* host, size_t npixels);
 /* Run the codec's HIP work on `hip_stream` (a hipStream_t, e.g. torch's current stream) instead
  * of the codec's own stream.  NULL restores the codec's own stream. */
 int jsp_set_stream(jsp_codec* c, void* hip_stream);
+/* Codec options.  Returns 0 when accepted, -1 for an unknown key/value.
+ *   "msv1_parse" = "host" (default) | "gpu" : MSVideo1 only.  "gpu" builds the per-block descriptor
+ *       table with the on-GPU parse kernels (raw frame bytes are all the device needs; a replay of a
+ *       staged batch re-runs the parse); frames the parse flags as special fall back to the host
+ *       parser one by one, so results are identical either way. */
+int jsp_set_option(jsp_codec* c, const char* key, const char* value);
 /* Block until everything queued by this codec has finished. */
 int jsp_sync(jsp_codec* c);
 
@@ -138,6 +144,7 @@ typedef struct jsp_staged_info {
     uint64_t kernel_launches;  /* launches jsp_staged_decode issues */
     double host_stage_ms;      /* wall time of the host parse / entropy stage */
     double h2d_ms;             /* wall time of the uploads */
+    double device_parse_ms;    /* wall time of the on-GPU parse at staging (0 with the host parser) */
 } jsp_staged_info;
 int jsp_staged_get_info(const jsp_staged* s, jsp_staged_info* out);
 

@@ -32,6 +32,7 @@ class StagedInfo(C.Structure):
         ("kernel_launches", C.c_uint64),
         ("host_stage_ms", C.c_double),
         ("h2d_ms", C.c_double),
+        ("device_parse_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -59,6 +60,7 @@ SIGNATURES = {
     "jsp_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "jsp_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "jsp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jsp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "jsp_sync": (C.c_int, [C.c_void_p]),
     "jsp_decompress_i_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_void_p)]),

@@ -138,6 +138,10 @@ class _NativeCodec:
     def set_stream(self, hip_stream: Optional[int]) -> None:
         self._lib.jsp_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None)
 
+    def set_option(self, key: str, value: str) -> None:
+        if self._lib.jsp_set_option(self._h, key.encode(), value.encode()) != 0:
+            raise CodecError(f"option {key}={value} not accepted")
+
     def sync(self) -> None:
         if self._lib.jsp_sync(self._h) != 0:
             raise CodecError(N.last_error())

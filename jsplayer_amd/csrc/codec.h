@@ -56,6 +56,7 @@ struct jsp_codec {
     // True when a frame of this batch may leave some dst pixels unwritten (so a host-mode dst
     // has to be uploaded first to keep them as the caller had them).
     virtual bool may_leave_pixels(const jsp_frame_in& f) = 0;
+    virtual int set_option(const char*, const char*) { return -1; }
 
     void init_device(int device_id);
     void activate();

@@ -236,6 +236,11 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream) {
     return 0;
 }
 
+int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
+    if (!c || !key || !value) return -1;
+    return c->set_option(key, value);
+}
+
 int jsp_sync(jsp_codec* c) {
     return guarded([&] {
         c->activate();

@@ -51,6 +51,30 @@ void msv1_parse(const Msv1Geometry& geo, const uint8_t* src, size_t n, bool have
 bool msv1_just_skip_blocks(const Msv1Geometry& geo, const uint8_t* src, size_t n);
 int msv1_is_key_frame(const Msv1Geometry& geo, const uint8_t* src, size_t n);
 
+// ---- on-GPU parse (msv1_parse_kernels.hip) ----------------------------------------------------
+struct Msv1ParseFrame {   // one per frame of a batch
+    uint32_t beg, end;        // byte range of the frame in the batch stream buffer (beg 16-byte aligned)
+    uint32_t desc_base;       // index of the frame's first descriptor
+    uint32_t first_tile, ntiles;
+    uint32_t host_parsed;     // 1: descriptors come from the host parser, the GPU parse skips the frame
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t MSV1_INFO_END_MARKER = 1u;  // an 8-bit end-of-data marker sits on the code chain
+constexpr uint32_t MSV1_INFO_S1 = 2u;          // a coded block lies in a significant block row
+struct Msv1FrameInfo {    // counters the parse kernels return per frame
+    uint32_t n_coded;         // coded (non-skip) blocks
+    uint32_t n_skip_codes;
+    uint32_t total_blocks;    // blocks covered by the whole stream (saturating); < nblocks = stream too short
+    uint32_t flags;
+    uint32_t consumed;        // bytes up to the end of the code covering the last block
+    uint32_t pad[3];
+};
+uint32_t msv1_parse_tile_bytes();
+void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_frames, int nframes,
+                       const uint32_t* d_tile_frame, int ntiles, int max_tiles_per_frame, uint32_t* d_tile_tab,
+                       uint32_t* d_tile_entry, uint32_t* d_tile_block0, uint32_t* d_desc, Msv1FrameInfo* d_info,
+                       int insignificant_blocks, hipStream_t stream);
+
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
                         const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,

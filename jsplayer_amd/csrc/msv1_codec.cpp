@@ -1,6 +1,8 @@
 // MSVideo1_16bit / MSVideo1_8bit behind the IVideoCodec-shaped C ABI.
 // Host side = control flow of MSVideo1.hx:106-209 / 293-393 (early-outs, changes, block_changes,
-// adoption of dst as prevFrame); pixels are produced by msv1_kernels.hip.
+// adoption of dst as prevFrame); pixels are produced by msv1_kernels.hip.  The descriptor table is
+// built either by the sequential host parser (msv1_host.cpp) or on the GPU
+// (msv1_parse_kernels.hip, option "msv1_parse" = "gpu").
 #include <algorithm>
 #include <unordered_set>
 
@@ -9,8 +11,6 @@
 
 namespace jsp {
 namespace {
-
-struct Msv1Codec;
 
 struct Msv1Staged : jsp_staged {
     Msv1Geometry geo{};
@@ -26,8 +26,26 @@ struct Msv1Staged : jsp_staged {
     std::vector<Group> groups;
     bool need_signif = false;  // some frame asked for the stage-2 compare
 
+    // on-GPU parse state
+    bool gpu_parse = false;
+    int ntiles = 0, max_tiles = 0, insignificant_blocks = 0;
+    DeviceBuffer d_pframes, d_tile_frame, d_tile_tab, d_tile_entry, d_tile_block0, d_info;
+    PinnedBuffer h_pframes, h_tile_frame, h_info;
+
+    void launch_parse(hipStream_t stream) {
+        msv1_launch_parse(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
+                          nframes, static_cast<const uint32_t*>(d_tile_frame.p), ntiles, max_tiles,
+                          static_cast<uint32_t*>(d_tile_tab.p), static_cast<uint32_t*>(d_tile_entry.p),
+                          static_cast<uint32_t*>(d_tile_block0.p), static_cast<uint32_t*>(d_desc.p),
+                          static_cast<Msv1FrameInfo*>(d_info.p), insignificant_blocks, stream);
+    }
+
     void decode(hipStream_t stream) override {
         if (nframes == 0) return;
+        // A replay re-executes the whole device pipeline: with the on-GPU parse that includes the
+        // parse kernels, so a staged batch can be timed from raw stream bytes.  (The first decode
+        // uses the tables the staging pass left behind.)
+        if (gpu_parse && decoded) launch_parse(stream);
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
         for (const Group& g : groups) {
@@ -54,6 +72,11 @@ struct Msv1Codec : jsp_codec {
     std::vector<uint8_t> palette_bytes;
     int32_t palette[256];
     DeviceBuffer d_palette;
+    bool opt_gpu_parse = false;
+    // block_changes is only maintained by the host parser; after frames parsed on the GPU it is
+    // rebuilt on demand from the bytes of the last fully parsed frame
+    bool block_changes_stale = false;
+    std::vector<uint8_t> last_full_frame;
 
     Msv1Codec(int bits, int w, int h, const uint8_t* pal, int pal_bytes) {
         kind = bits == 16 ? JSP_CODEC_MSVIDEO1_16 : JSP_CODEC_MSVIDEO1_8;
@@ -101,6 +124,26 @@ struct Msv1Codec : jsp_codec {
         // stream are guaranteed to be fully written.
         return (X & 3) || (Y & 3) || geo.bits == 8;
     }
+    int set_option(const char* key, const char* value) override {
+        if (std::strcmp(key, "msv1_parse") == 0) {
+            if (std::strcmp(value, "gpu") == 0) { opt_gpu_parse = true; return 0; }
+            if (std::strcmp(value, "host") == 0) { opt_gpu_parse = false; return 0; }
+        }
+        return -1;
+    }
+
+    // Host parse of one frame into `desc`, keeping block_changes exact.
+    void host_parse(const uint8_t* src, size_t n, uint32_t base, uint32_t* desc, Msv1Parse& pr) {
+        if (block_changes_stale) {  // replay the last GPU-parsed frame to recover the per-row flags
+            std::vector<uint32_t> scratch((size_t)std::max(geo.nblocks, 1));
+            Msv1Parse tmp;
+            msv1_parse(geo, last_full_frame.data(), last_full_frame.size(), true, 0, insignificant_blocks, 0,
+                       scratch.data(), block_changes, tmp);
+            block_changes_stale = false;
+        }
+        msv1_parse(geo, src, n, prev_dev != nullptr, size_of_just_skips, insignificant_blocks, base, desc,
+                   block_changes, pr);
+    }
 
     jsp_staged* stage(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse) override {
         activate();
@@ -109,6 +152,7 @@ struct Msv1Codec : jsp_codec {
         if (!st) st = new Msv1Staged();
         std::unique_ptr<Msv1Staged> guard(reuse ? nullptr : st);
         const int nf = (int)frames.size();
+        const size_t nblk = (size_t)std::max(geo.nblocks, 1);
         st->geo = geo;
         st->nframes = nf;
         st->decoded = false;
@@ -117,52 +161,148 @@ struct Msv1Codec : jsp_codec {
         st->adopted.assign(nf, 0);
         st->significant.assign(nf, 0);
         st->info = jsp_staged_info{};
+        st->insignificant_blocks = insignificant_blocks;
+        // the on-GPU parse packs block counts in 20 bits
+        st->gpu_parse = opt_gpu_parse && geo.nblocks > 0 && geo.nblocks < (1 << 20);
         if (geo.bits == 8 && !d_palette.p) {  // Preinit not called: all-zero palette
             d_palette.reserve(sizeof palette);
             JSP_HIP(hipMemcpy(d_palette.p, palette, sizeof palette, hipMemcpyHostToDevice));
         }
         st->d_palette = static_cast<const int32_t*>(d_palette.p);
 
+        // ---- lay the frames out in one stream buffer (16-byte aligned starts) ----------------
+        std::vector<size_t> beg(nf);
         size_t total_stream = 0;
-        for (const auto& f : frames) total_stream += (f.n + 1) & ~size_t(1);
+        for (int i = 0; i < nf; ++i) {
+            beg[i] = total_stream;
+            total_stream += (frames[i].n + 15) & ~size_t(15);
+        }
         if (total_stream + 64 > 0xFFFFFFF0u) throw std::runtime_error("batch stream exceeds 4 GiB");
         st->h_stream.reserve(total_stream + 64);
-        st->h_desc.reserve(sizeof(uint32_t) * (size_t)std::max(geo.nblocks, 1) * nf);
+        st->h_desc.reserve(sizeof(uint32_t) * nblk * std::max(nf, 1));
         st->h_frames.reserve(sizeof(Msv1FrameArgs) * std::max(nf, 1));
         st->d_signif.reserve(sizeof(uint32_t) * std::max(nf, 1));
         st->h_signif.reserve(sizeof(uint32_t) * std::max(nf, 1));
+        st->d_stream.reserve(total_stream + 64);
+        st->d_desc.reserve(sizeof(uint32_t) * nblk * std::max(nf, 1));
+        st->d_frames.reserve(sizeof(Msv1FrameArgs) * std::max(nf, 1));
         auto* h_stream = static_cast<uint8_t*>(st->h_stream.p);
         auto* h_desc = static_cast<uint32_t*>(st->h_desc.p);
         auto* h_frames = static_cast<Msv1FrameArgs*>(st->h_frames.p);
         auto* d_signif = static_cast<uint32_t*>(st->d_signif.p);
+        for (int i = 0; i < nf; ++i) {
+            if (frames[i].n) std::memcpy(h_stream + beg[i], frames[i].src, frames[i].n);
+            const size_t padded = (frames[i].n + 15) & ~size_t(15);
+            std::memset(h_stream + beg[i] + frames[i].n, 0, padded - frames[i].n);
+        }
+        double h2d_ms = 0;
+        auto timed_upload = [&](void* d, const void* h, size_t bytes) {
+            if (!bytes) return;
+            const double t = now_ms();
+            JSP_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+            JSP_HIP(hipStreamSynchronize(stream));
+            h2d_ms += now_ms() - t;
+        };
 
+        // ---- on-GPU parse: upload the raw bytes, parse, read the per-frame counters back --------
+        Msv1ParseFrame* h_pf = nullptr;
+        const Msv1FrameInfo* h_info = nullptr;
+        double gpu_parse_ms = 0;
+        if (st->gpu_parse && nf) {
+            const uint32_t tile_bytes = msv1_parse_tile_bytes();
+            st->h_pframes.reserve(sizeof(Msv1ParseFrame) * nf);
+            h_pf = static_cast<Msv1ParseFrame*>(st->h_pframes.p);
+            int ntiles = 0, max_tiles = 1;
+            for (int i = 0; i < nf; ++i) {
+                // an odd trailing byte is left to the host parser (it only matters when the chain reaches it,
+                // and then the stream counts as too short)
+                const size_t n_even = frames[i].n & ~size_t(1);
+                const int t = (int)((n_even + tile_bytes - 1) / tile_bytes);
+                // 16-bit early-outs (MSVideo1.hx:109-110) are settled by the host parser
+                const bool pre_host = geo.bits == 16 && frames[i].n < size_of_just_skips;
+                h_pf[i] = Msv1ParseFrame{(uint32_t)beg[i], (uint32_t)(beg[i] + n_even), (uint32_t)(i * nblk), (uint32_t)ntiles,
+                                         (uint32_t)t, pre_host || t == 0 ? 1u : 0u, 0, 0};
+                ntiles += t;
+                max_tiles = std::max(max_tiles, t);
+            }
+            st->ntiles = ntiles;
+            st->max_tiles = max_tiles;
+            st->h_tile_frame.reserve(sizeof(uint32_t) * std::max(ntiles, 1));
+            auto* h_tf = static_cast<uint32_t*>(st->h_tile_frame.p);
+            for (int i = 0; i < nf; ++i)
+                for (uint32_t k = 0; k < h_pf[i].ntiles; ++k) h_tf[h_pf[i].first_tile + k] = (uint32_t)i;
+            st->d_pframes.reserve(sizeof(Msv1ParseFrame) * nf);
+            st->d_tile_frame.reserve(sizeof(uint32_t) * std::max(ntiles, 1));
+            st->d_tile_tab.reserve(sizeof(uint32_t) * 9 * std::max(ntiles, 1));
+            st->d_tile_entry.reserve(sizeof(uint32_t) * std::max(ntiles, 1));
+            st->d_tile_block0.reserve(sizeof(uint32_t) * std::max(ntiles, 1));
+            st->d_info.reserve(sizeof(Msv1FrameInfo) * nf);
+            st->h_info.reserve(sizeof(Msv1FrameInfo) * nf);
+            timed_upload(st->d_stream.p, h_stream, total_stream);
+            timed_upload(st->d_pframes.p, h_pf, sizeof(Msv1ParseFrame) * nf);
+            timed_upload(st->d_tile_frame.p, h_tf, sizeof(uint32_t) * ntiles);
+            const double tp = now_ms();
+            st->launch_parse(stream);
+            JSP_HIP(hipGetLastError());
+            JSP_HIP(hipMemcpyAsync(st->h_info.p, st->d_info.p, sizeof(Msv1FrameInfo) * nf, hipMemcpyDeviceToHost, stream));
+            JSP_HIP(hipStreamSynchronize(stream));
+            gpu_parse_ms = now_ms() - tp;
+            h_info = static_cast<const Msv1FrameInfo*>(st->h_info.p);
+        }
+
+        // ---- per-frame protocol decisions, in stream order ------------------------------------
         bool vec_ok = (X & 3) == 0;
-        size_t off = 0;
         std::unordered_set<const void*> group_dsts;
         bool group_closed = true;  // true: the next frame must open a new launch group
+        int last_gpu_frame = -1;
+        bool pframes_dirty = false;
         for (int i = 0; i < nf; ++i) {
             const jsp_frame_in& f = frames[i];
-            if (f.n) std::memcpy(h_stream + off, f.src, f.n);
-            uint32_t* desc = h_desc + (size_t)i * geo.nblocks;
+            uint32_t* desc = h_desc + (size_t)i * nblk;
             Msv1Parse pr;
-            msv1_parse(geo, f.src, f.n, prev_dev != nullptr, size_of_just_skips, insignificant_blocks,
-                       (uint32_t)off, desc, block_changes, pr);
+            bool from_gpu = false;
+            if (st->gpu_parse && !h_pf[i].host_parsed) {
+                const Msv1FrameInfo& fi = h_info[i];
+                const bool needs_host = fi.total_blocks < (uint32_t)geo.nblocks ||      // stream too short
+                                        (fi.flags & MSV1_INFO_END_MARKER) ||             // 8-bit end marker
+                                        (fi.n_skip_codes && !prev_dev);                   // the reference raises
+                if (!needs_host) {
+                    pr.changes = fi.n_coded != 0;
+                    pr.s1 = pr.changes && (fi.flags & MSV1_INFO_S1);
+                    pr.n_coded = fi.n_coded;
+                    pr.n_skipped = (uint64_t)geo.nblocks - fi.n_coded;
+                    pr.consumed = std::min<uint64_t>(fi.consumed, f.n);
+                    from_gpu = true;
+                    last_gpu_frame = i;
+                    block_changes_stale = true;
+                }
+            }
+            if (!from_gpu) {
+                if (st->gpu_parse && last_gpu_frame >= 0 && block_changes_stale) {
+                    const jsp_frame_in& g = frames[last_gpu_frame];
+                    last_full_frame.assign(g.src, g.src + g.n);
+                }
+                host_parse(f.src, f.n, (uint32_t)beg[i], desc, pr);
+                if (pr.early_out) std::fill(desc, desc + geo.nblocks, MSV1_DESC_UNTOUCHED);
+                if (st->gpu_parse) {  // this frame's table comes from the host from now on
+                    h_pf[i].host_parsed = 1;
+                    pframes_dirty = true;
+                    timed_upload(static_cast<uint32_t*>(st->d_desc.p) + (size_t)i * nblk, desc, sizeof(uint32_t) * geo.nblocks);
+                }
+            }
             Msv1FrameArgs& fa = h_frames[i];
             fa.dst = f.dst;
             fa.prev = prev_dev;
             fa.signif = d_signif + i;
-            fa.stream_end = (uint32_t)(off + f.n);
-            fa.desc_base = (uint32_t)((size_t)i * geo.nblocks);
+            fa.stream_end = (uint32_t)(beg[i] + f.n);
+            fa.desc_base = (uint32_t)((size_t)i * nblk);
             fa.cmp_row_lo = 0xFFFFFFFFu;
             fa.pad = 0;
-            off += (f.n + 1) & ~size_t(1);
-
             if ((reinterpret_cast<uintptr_t>(f.dst) & 15) || (reinterpret_cast<uintptr_t>(prev_dev) & 15))
                 vec_ok = false;
             bool dependent = pr.n_skipped != 0;  // reads its predecessor
             if (pr.early_out) {
                 // nothing to paint: every block untouched, the frame rides along as a no-op
-                std::fill(desc, desc + geo.nblocks, MSV1_DESC_UNTOUCHED);
             } else if (pr.aborted) {
                 st->status[i] = JSP_ERROR_OCCURED;  // the reference raises out of DecompressP here
             } else {
@@ -179,9 +319,7 @@ struct Msv1Codec : jsp_codec {
                     // 8-bit: NaN loop bound -> no pixel is compared -> false
                 }
                 st->significant[i] = f.key ? 0 : sg;
-                if (pr.changes) {
-                    st->adopted[i] = 1;
-                }
+                if (pr.changes) st->adopted[i] = 1;
             }
             st->info.units_coded += pr.n_coded;
             st->info.units_copied += pr.n_skipped;
@@ -201,6 +339,10 @@ struct Msv1Codec : jsp_codec {
             if (writes) group_dsts.insert(f.dst);
             if (st->adopted[i]) prev_dev = f.dst;
         }
+        if (st->gpu_parse && last_gpu_frame >= 0 && block_changes_stale) {
+            const jsp_frame_in& g = frames[last_gpu_frame];
+            last_full_frame.assign(g.src, g.src + g.n);
+        }
         st->vec_ok = vec_ok;
         st->need_signif = false;
         for (int v : st->significant) st->need_signif |= v < 0;
@@ -209,22 +351,21 @@ struct Msv1Codec : jsp_codec {
         st->info.descriptor_bytes = sizeof(uint32_t) * (uint64_t)geo.nblocks * nf + sizeof(Msv1FrameArgs) * nf;
         // A = S + 64*N_coded + 128*N_skipped
         st->info.algorithmic_bytes = st->info.stream_bytes + 64 * st->info.units_coded + 128 * st->info.units_copied;
-        st->info.kernel_launches = st->groups.size();
-        st->info.host_stage_ms = now_ms() - t0;
+        // with the on-GPU parse every replay also runs tiles + chain + emit
+        st->info.kernel_launches = st->groups.size() + (st->gpu_parse ? 3 : 0);
+        st->info.host_stage_ms = now_ms() - t0 - h2d_ms - gpu_parse_ms;
 
-        const double t1 = now_ms();
-        st->d_stream.reserve(total_stream + 64);
-        st->d_desc.reserve(sizeof(uint32_t) * (size_t)std::max(geo.nblocks, 1) * nf);
-        st->d_frames.reserve(sizeof(Msv1FrameArgs) * std::max(nf, 1));
         if (nf) {
-            JSP_HIP(hipMemcpyAsync(st->d_stream.p, h_stream, total_stream, hipMemcpyHostToDevice, stream));
-            JSP_HIP(hipMemcpyAsync(st->d_desc.p, h_desc, sizeof(uint32_t) * (size_t)geo.nblocks * nf,
-                                   hipMemcpyHostToDevice, stream));
-            JSP_HIP(hipMemcpyAsync(st->d_frames.p, h_frames, sizeof(Msv1FrameArgs) * nf, hipMemcpyHostToDevice,
-                                   stream));
-            JSP_HIP(hipStreamSynchronize(stream));
+            if (!st->gpu_parse) {
+                timed_upload(st->d_stream.p, h_stream, total_stream);
+                timed_upload(st->d_desc.p, h_desc, sizeof(uint32_t) * nblk * nf);
+            } else if (pframes_dirty) {
+                timed_upload(st->d_pframes.p, h_pf, sizeof(Msv1ParseFrame) * nf);
+            }
+            timed_upload(st->d_frames.p, h_frames, sizeof(Msv1FrameArgs) * nf);
         }
-        st->info.h2d_ms = now_ms() - t1;
+        st->info.h2d_ms = h2d_ms;
+        st->info.device_parse_ms = gpu_parse_ms;
         guard.release();
         return st;
     }

@@ -1,0 +1,303 @@
+// On-GPU parse of MSVideo1 code streams: raw frame bytes in HBM -> the per-block
+// descriptor table msv1_blocks_kernel consumes, without the sequential host walk.
+//
+// The walk "offset += length(code at offset)" (MSVideo1.hx:128-181 / 311-364) is a chain through the
+// even byte offsets ("slots").  A code is 1, 3 or 9 slots long (16-bit; 1, 2 or 5 for 8-bit), so a
+// chain that enters a run of slots does so at one of its first 9 slots.  For any run of slots the
+// function   entry slot (0..8) -> (exit slot into the next run (0..8), blocks covered)
+// is a 9-entry table, and tables compose associatively.  Three kernels:
+//   K1 msv1_parse_tiles   : one workgroup per 16 KiB tile; each lane builds the table of its 32 slots
+//                           with a register-resident reverse DP (static indices only), the workgroup
+//                           reduces the 256 tables by composition -> one table per tile;
+//   K2 msv1_parse_chain   : one workgroup per frame walks its <= few hundred tile tables from entry 0
+//                           (in LDS) -> true entry slot and first block index of every tile;
+//   K3 msv1_parse_emit    : K1's work again + an inclusive scan of the lane tables, so every lane
+//                           knows where the real chain enters its slots and which block comes first;
+//                           it then replays its 32 slots and writes one descriptor per coded block.
+// Every tile owns the block range its codes cover and writes that whole range — coded blocks and
+// MSV1_DESC_SKIP for skipped ones — through an LDS staging buffer, so descriptor writes are coalesced.
+// Frames the reference treats specially (stream ends before all blocks are covered, 8-bit end
+// marker, skip code with no previous frame, 16-bit early-outs) are detected from the counters these
+// kernels return and re-done by the host parser (msv1_host.cpp), which is exact for every input.
+#include "msv1.h"
+
+namespace jsp {
+namespace {
+
+constexpr int PWG = 256;                 // lanes per workgroup
+constexpr int LSLOTS = 32;               // slots (2 bytes each) per lane
+constexpr int TSLOTS = PWG * LSLOTS;     // 8192 slots = 16 KiB per tile
+constexpr uint32_t BSAT = (1u << 28) - 1;
+
+__device__ __forceinline__ uint32_t pack(uint32_t exit_slot, uint32_t blocks) { return exit_slot | (blocks << 4); }
+__device__ __forceinline__ uint32_t add_blocks(uint32_t v, uint32_t n) {
+    const uint32_t b = (v >> 4) + n;
+    return (v & 15u) | ((b > BSAT ? BSAT : b) << 4);
+}
+// table composition: first `a` (value for one entry), then table `tb`
+__device__ __forceinline__ uint32_t compose(uint32_t a, const uint32_t* tb) {
+    return add_blocks(tb[a & 15u], a >> 4);
+}
+
+// Per-slot classification, packed: bits 0..3 length in slots, bit 4 coded block (not a skip code),
+// bit 5 end marker (8-bit), bits 8..27 blocks covered (BSAT-clamped later)
+template <int BITS>
+__device__ __forceinline__ uint32_t classify(uint32_t a, uint32_t b, uint32_t hi, bool hi_ok) {
+    if ((b & 0xFCu) == 0x84u) {
+        const uint32_t n = ((b - 0x84u) << 8) + a;          // 0 = "the rest of the frame"
+        return 1u | ((n ? n : 0xFFFFFu) << 8);
+    }
+    if (BITS == 16) {
+        if (b < 0x80u) return ((hi_ok && (hi & 0x80u)) ? 9u : 3u) | 16u | (1u << 8);
+        return 1u | 16u | (1u << 8);
+    }
+    if (a == 0u && b == 0u) return 1u | 32u;                 // end marker: covers nothing, flagged
+    if (b < 0x80u) return 2u | 16u | (1u << 8);
+    if (b >= 0x90u) return 5u | 16u | (1u << 8);
+    return 1u | 16u | (1u << 8);
+}
+
+// The lane's 32 slots: classification of every slot (cls[]) and the 9-entry table tab[e].
+// `w` = the lane's 64 bytes + 4 bytes of halo as 17 dwords; `p0` = absolute byte offset of slot 0;
+// `end` = absolute end of the frame's bytes.  Everything indexes registers statically.
+template <int BITS>
+__device__ __forceinline__ void lane_table(const uint32_t (&w)[17], uint32_t p0, uint32_t end, uint32_t (&cls)[LSLOTS],
+                                           uint32_t (&tab)[9]) {
+#pragma unroll
+    for (int s = 0; s < LSLOTS; ++s) {
+        const uint32_t a = (w[(2 * s) >> 2] >> (8 * ((2 * s) & 3))) & 0xFFu;
+        const uint32_t b = (w[(2 * s + 1) >> 2] >> (8 * ((2 * s + 1) & 3))) & 0xFFu;
+        const uint32_t hi = (w[(2 * s + 3) >> 2] >> (8 * ((2 * s + 3) & 3))) & 0xFFu;
+        const uint32_t p = p0 + 2u * s;
+        // slots past the end of the data cover nothing (frames are even-padded: a present => b present)
+        cls[s] = p < end ? classify<BITS>(a, b, hi, p + 3u < end) : 1u;
+    }
+    // reverse DP with a 9-deep window: d[k] = value of slot s+1+k
+    uint32_t d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = pack(k, 0);
+#pragma unroll
+    for (int s = LSLOTS - 1; s >= 0; --s) {
+        const uint32_t len = cls[s] & 15u;
+        uint32_t nx;
+        if (BITS == 16) nx = len == 1u ? d[0] : (len == 3u ? d[2] : d[8]);
+        else nx = len == 1u ? d[0] : (len == 2u ? d[1] : d[4]);
+        const uint32_t v = add_blocks(nx, cls[s] >> 8);
+#pragma unroll
+        for (int k = 8; k > 0; --k) d[k] = d[k - 1];
+        d[0] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tab[e] = d[e];
+}
+
+// Stage a tile through LDS and hand every lane its 17 dwords.
+__device__ __forceinline__ void load_lane_bytes(const uint8_t* __restrict__ stream, uint32_t tile_byte0, uint32_t end,
+                                                uint32_t* lds_bytes /* TSLOTS*2/4 + 4 dwords */, uint32_t (&w)[17]) {
+    const uint32_t tile_bytes = TSLOTS * 2;
+    for (uint32_t o = threadIdx.x * 16u; o < tile_bytes + 16u; o += PWG * 16u) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tile_byte0 + o < end) v = *reinterpret_cast<const uint4*>(stream + tile_byte0 + o);  // buffers are padded
+        *reinterpret_cast<uint4*>(lds_bytes + o / 4) = v;
+    }
+    __syncthreads();
+    const uint32_t* mine = lds_bytes + threadIdx.x * (LSLOTS * 2 / 4);
+#pragma unroll
+    for (int k = 0; k < 17; ++k) w[k] = mine[k];
+}
+
+template <int BITS>
+__global__ __launch_bounds__(PWG) void msv1_parse_tiles(const uint8_t* __restrict__ stream,
+                                                        const Msv1ParseFrame* __restrict__ frames,
+                                                        const uint32_t* __restrict__ tile_frame,
+                                                        uint32_t* __restrict__ tile_tab) {
+    __shared__ __align__(16) uint32_t lds_bytes[TSLOTS * 2 / 4 + 8];
+    __shared__ uint32_t tabs[2][PWG][9];
+    const uint32_t t = blockIdx.x;
+    const Msv1ParseFrame fr = frames[tile_frame[t]];
+    if (fr.host_parsed) return;
+    const uint32_t tile_byte0 = fr.beg + (t - fr.first_tile) * (TSLOTS * 2);
+    uint32_t w[17], cls[LSLOTS], tab[9];
+    load_lane_bytes(stream, tile_byte0, fr.end, lds_bytes, w);
+    lane_table<BITS>(w, tile_byte0 + threadIdx.x * (LSLOTS * 2), fr.end, cls, tab);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tabs[0][threadIdx.x][e] = tab[e];
+    __syncthreads();
+    // reduce by composition, every (node, entry) pair one work item, ping-pong between two buffers
+    int cur = 0;
+    for (int l = 1; l <= 8; ++l) {
+        const int nodes = PWG >> l;
+        for (int k = threadIdx.x; k < nodes * 9; k += PWG) {
+            const int j = k / 9, e = k - j * 9;
+            tabs[cur ^ 1][j][e] = compose(tabs[cur][2 * j][e], tabs[cur][2 * j + 1]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (threadIdx.x < 9) tile_tab[t * 9 + threadIdx.x] = tabs[cur][0][threadIdx.x];
+}
+
+// One workgroup per frame: chain the tile tables from entry slot 0.
+__global__ __launch_bounds__(64) void msv1_parse_chain(const Msv1ParseFrame* __restrict__ frames,
+                                                       const uint32_t* __restrict__ tile_tab,
+                                                       uint32_t* __restrict__ tile_entry, uint32_t* __restrict__ tile_block0,
+                                                       Msv1FrameInfo* __restrict__ info) {
+    extern __shared__ uint32_t tt[];  // ntiles * 9
+    const Msv1ParseFrame fr = frames[blockIdx.x];
+    if (fr.host_parsed) return;
+    for (uint32_t k = threadIdx.x; k < fr.ntiles * 9u; k += 64) tt[k] = tile_tab[fr.first_tile * 9u + k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t e = 0, blocks = 0;
+        for (uint32_t t = 0; t < fr.ntiles; ++t) {
+            tile_entry[fr.first_tile + t] = e;
+            tile_block0[fr.first_tile + t] = blocks;
+            const uint32_t v = tt[t * 9u + e];
+            e = v & 15u;
+            blocks = blocks + (v >> 4) > BSAT ? BSAT : blocks + (v >> 4);
+        }
+        info[blockIdx.x].total_blocks = blocks;
+    }
+}
+
+// Composition tree over the 256 lane tables, kept whole in LDS: level 0 = lane tables, level l node j
+// covers lanes [j*2^l, (j+1)*2^l).  Node (l, j) lives at row tree_row(l) + j.
+__device__ __forceinline__ int tree_row(int level) { return 2 * PWG - (2 * PWG >> level); }  // 0,256,384,...,510
+
+template <int BITS>
+__global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict__ stream,
+                                                       const Msv1ParseFrame* __restrict__ frames,
+                                                       const uint32_t* __restrict__ tile_frame,
+                                                       const uint32_t* __restrict__ tile_entry,
+                                                       const uint32_t* __restrict__ tile_block0,
+                                                       uint32_t* __restrict__ desc, Msv1FrameInfo* __restrict__ info,
+                                                       uint32_t nblocks, uint32_t s1_first_block) {
+    // one LDS arena: [tile bytes | composition tree | per-node entry]; once every lane knows where
+    // the chain enters its slots, the front of the arena is reused as the descriptor staging buffer
+    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, STAGE = 8192;
+    static_assert(BYTES_W + TREE_W >= STAGE, "staging overlay must fit in front of `enter`");
+    __shared__ __align__(16) uint32_t arena[BYTES_W + TREE_W + 2 * PWG];
+    uint32_t* lds_bytes = arena;
+    uint32_t (*tree)[9] = reinterpret_cast<uint32_t (*)[9]>(arena + BYTES_W);
+    uint32_t* enter = arena + BYTES_W + TREE_W;
+    uint32_t* stage = arena;
+    const uint32_t t = blockIdx.x;
+    const uint32_t f = tile_frame[t];
+    const Msv1ParseFrame fr = frames[f];
+    if (fr.host_parsed) return;
+    const uint32_t tile_byte0 = fr.beg + (t - fr.first_tile) * (TSLOTS * 2);
+    uint32_t w[17], cls[LSLOTS], tab[9];
+    load_lane_bytes(stream, tile_byte0, fr.end, lds_bytes, w);
+    const uint32_t p0 = tile_byte0 + threadIdx.x * (LSLOTS * 2);
+    lane_table<BITS>(w, p0, fr.end, cls, tab);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tree[threadIdx.x][e] = tab[e];
+    __syncthreads();
+    // up-sweep: every (node, entry) pair of a level is one work item
+    for (int l = 1; l <= 8; ++l) {
+        const int nodes = PWG >> l, lo = tree_row(l - 1), hi = tree_row(l);
+        for (int k = threadIdx.x; k < nodes * 9; k += PWG) {
+            const int j = k / 9, e = k - j * 9;
+            tree[hi + j][e] = compose(tree[lo + 2 * j][e], tree[lo + 2 * j + 1]);
+        }
+        __syncthreads();
+    }
+    // down-sweep of ONE value per node: where the real chain enters the node and with which block.
+    // packed as entry | block << 4 (block saturates at BSAT like everything else)
+    const uint32_t tb0 = tile_block0[t];
+    if (threadIdx.x == 0) enter[tree_row(8)] = pack(tile_entry[t], tb0);
+    __syncthreads();
+    for (int l = 8; l >= 1; --l) {
+        const int nodes = PWG >> l, hi = tree_row(l), lo = tree_row(l - 1);
+        if ((int)threadIdx.x < nodes) {
+            const uint32_t v = enter[hi + threadIdx.x];
+            enter[lo + 2 * threadIdx.x] = v;
+            enter[lo + 2 * threadIdx.x + 1] = add_blocks(tree[lo + 2 * threadIdx.x][v & 15u], v >> 4);
+        }
+        __syncthreads();
+    }
+    const uint32_t mine = enter[threadIdx.x];
+    // blocks this tile is responsible for: [tb0, span_end)
+    const uint32_t whole = add_blocks(tree[tree_row(8)][tile_entry[t]], tb0) >> 4;
+    const uint32_t span_end = whole < nblocks ? whole : nblocks;
+    const uint32_t span = span_end > tb0 ? span_end - tb0 : 0u;
+    const bool staged = span <= (uint32_t)STAGE;
+    __syncthreads();                                   // everyone has read tree/enter: the arena is free
+    uint32_t* gdesc = desc + fr.desc_base;
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i < span; i += PWG) stage[i] = MSV1_DESC_SKIP;
+    } else {
+        for (uint32_t i = tb0 + threadIdx.x; i < span_end; i += PWG) gdesc[i] = MSV1_DESC_SKIP;
+    }
+    __syncthreads();                                   // (vmcnt(0) too: the global fill has landed)
+    uint32_t pos = mine & 15u, blk = mine >> 4;
+    uint32_t ncoded = 0, nskipcodes = 0, flags = 0, s1 = 0, consumed = 0;
+#pragma unroll
+    for (int s = 0; s < LSLOTS; ++s) {
+        if (pos == (uint32_t)s && blk < nblocks) {
+            const uint32_t c = cls[s];
+            if (p0 + 2u * s < fr.end) {
+                if (c & 16u) {
+                    if (staged) stage[blk - tb0] = p0 + 2u * s;
+                    else gdesc[blk] = p0 + 2u * s;
+                    ++ncoded;
+                    s1 |= blk >= s1_first_block ? 1u : 0u;
+                } else if (c & 32u) flags |= MSV1_INFO_END_MARKER;
+                else ++nskipcodes;
+                const uint32_t nb = blk + (c >> 8);
+                blk = nb > BSAT ? BSAT : nb;
+                if (blk >= nblocks) consumed = p0 + 2u * s + 2u * (c & 15u) - fr.beg;
+            }
+            pos += c & 15u;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < span; i += PWG) gdesc[tb0 + i] = stage[i];   // coalesced write-out
+    }
+    // per-frame counters: one atomic per wave and counter
+    const unsigned long long any = __ballot(ncoded | nskipcodes | flags | s1 | consumed);
+    if (any) {
+        uint32_t a = ncoded, b = nskipcodes, c2 = flags | (s1 ? MSV1_INFO_S1 : 0u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor((int)a, o);
+            b += __shfl_xor((int)b, o);
+            c2 |= (uint32_t)__shfl_xor((int)c2, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd(&info[f].n_coded, a);
+            if (b) atomicAdd(&info[f].n_skip_codes, b);
+            if (c2) atomicOr(&info[f].flags, c2);
+        }
+        if (consumed) info[f].consumed = consumed;   // exactly one lane covers the last block
+    }
+}
+
+}  // namespace
+
+uint32_t msv1_parse_tile_bytes() { return TSLOTS * 2; }
+
+void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_frames, int nframes,
+                       const uint32_t* d_tile_frame, int ntiles, int max_tiles_per_frame, uint32_t* d_tile_tab,
+                       uint32_t* d_tile_entry, uint32_t* d_tile_block0, uint32_t* d_desc, Msv1FrameInfo* d_info,
+                       int insignificant_blocks, hipStream_t stream) {
+    if (nframes <= 0 || ntiles <= 0) return;
+    (void)hipMemsetAsync(d_info, 0, sizeof(Msv1FrameInfo) * nframes, stream);
+    const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
+    if (geo.bits == 16) {
+        hipLaunchKernelGGL(msv1_parse_tiles<16>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_frames, d_tile_frame, d_tile_tab);
+        hipLaunchKernelGGL(msv1_parse_chain, dim3(nframes), dim3(64), sizeof(uint32_t) * 9 * max_tiles_per_frame, stream,
+                           d_frames, d_tile_tab, d_tile_entry, d_tile_block0, d_info);
+        hipLaunchKernelGGL(msv1_parse_emit<16>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_frames, d_tile_frame, d_tile_entry,
+                           d_tile_block0, d_desc, d_info, (uint32_t)geo.nblocks, s1_first);
+    } else {
+        hipLaunchKernelGGL(msv1_parse_tiles<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_frames, d_tile_frame, d_tile_tab);
+        hipLaunchKernelGGL(msv1_parse_chain, dim3(nframes), dim3(64), sizeof(uint32_t) * 9 * max_tiles_per_frame, stream,
+                           d_frames, d_tile_tab, d_tile_entry, d_tile_block0, d_info);
+        hipLaunchKernelGGL(msv1_parse_emit<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_frames, d_tile_frame, d_tile_entry,
+                           d_tile_block0, d_desc, d_info, (uint32_t)geo.nblocks, s1_first);
+    }
+}
+
+}  // namespace jsp

@@ -20,8 +20,23 @@ def torch_mod():
     return torch
 
 
+PARSE_MODE = "host"
+
+
+@pytest.fixture(autouse=True, params=["host", "gpu"])
+def parse_mode(request):
+    """Every test in this file runs twice: descriptor tables from the sequential host parser and
+    from the on-GPU parse kernels (msv1_parse_kernels.hip).  Results must be identical."""
+    global PARSE_MODE
+    PARSE_MODE = request.param
+    yield request.param
+    PARSE_MODE = "host"
+
+
 def make_gpu(bits, w, h, pal=None):
-    return MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal or b"")
+    c = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal or b"")
+    c.set_option("msv1_parse", PARSE_MODE)
+    return c
 
 
 def dev_buf(n, fill=0):
@@ -166,12 +181,12 @@ def test_batch_matches_sequential_and_full_size_properties():
     torch = torch_mod()
     w, h, n = 1920, 1080, 6
     frames, keys, _ = sg.msv1_clip(2, w, h, n)
-    gpu = MSVideo1_16bit(w, h)
+    gpu = make_gpu(16, w, h)
     gpu.Preinit(36)
     dsts = [dev_buf(w * h, -1) for _ in range(n)]
     st = gpu.stage_batch(frames, dsts)
     info = st.info()
-    assert info["kernel_launches"] == 1
+    assert info["kernel_launches"] == (1 if PARSE_MODE == "host" else 4)
     assert info["units_coded"] == n * 129600 and info["units_copied"] == 0
     assert info["algorithmic_bytes"] == sum(len(f) for f in frames) + n * w * h * 4
     st.decode()
@@ -200,7 +215,7 @@ def test_batch_matches_sequential_and_full_size_properties():
 def test_batch_with_inter_frames_matches_oracle():
     w, h, n = 320, 240, 12
     frames, keys, _ = sg.msv1_clip(1, w, h, n, p_mix=sg.msv1_p_mix(0.7, 40.0), key_every=6)
-    gpu = MSVideo1_16bit(w, h)
+    gpu = make_gpu(16, w, h)
     gpu.Preinit(36)
     dsts = [dev_buf(w * h, 3) for _ in range(n)]
     st = gpu.stage_batch(frames, dsts, is_key=keys)
