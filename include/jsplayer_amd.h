@@ -152,6 +152,24 @@ int jsp_staged_get_info(const jsp_staged* s, jsp_staged_info* out);
  * the previous frame), significant[i] (valid after jsp_staged_decode + jsp_sync). */
 int jsp_staged_results(jsp_staged* s, int* status, int* adopted, int* significant);
 
+/* ---- what sits right after the codec in the reference's Manager, on the GPU --------------- */
+
+/* Manager.fill_bitmap_data (Manager.hx:325-390): RGB32 frame -> canvas pixels.  Modes: */
+enum {
+    JSP_DISPLAY_CANVAS = 0,        /* 0xFF000000 | B<<16 | G<<8 | R              (Manager.hx:379) */
+    JSP_DISPLAY_CANVAS_RGB15 = 1,  /* 0xFF000000 | c << 3  (ScreenPressor 16 bpp)  (Manager.hx:370) */
+    JSP_DISPLAY_SETPIXELS = 2,     /* 0xFF000000 | c                               (Manager.hx:351) */
+    JSP_DISPLAY_SETPIXELS_RGB15 = 3 /* c << 11                                     (Manager.hx:340) */
+};
+/* `frame`, `out`: device pointers, width*height ints.  flip_rows != 0 also undoes the bottom-up row
+ * order (the reference leaves that to its display matrix, Main.hx:318).  Asynchronous on `hip_stream`. */
+int jsp_display_convert(const int32_t* frame, int32_t* out, int width, int height, int mode, int flip_rows,
+                        void* hip_stream);
+/* The pixel loop of frames_differ_significantly (Manager.hx:413-419): *differ = any a[i] != b[i] for
+ * first_pixel <= i < npixels.  Device pointers; synchronous. */
+int jsp_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, size_t npixels, int* differ,
+                      void* hip_stream);
+
 /* Library/build identification: "jsplayer_amd <version> gfx950". */
 const char* jsp_version(void);
 

@@ -240,3 +240,28 @@ class ScreenPressor(_NativeCodec):
 
     def __init__(self, width: int, height: int, bits_per_pixel: int, device: int = 0):
         super().__init__(width, height, bits_per_pixel, None, device)
+
+
+# ---- the two Manager passes that follow the codec (Manager.hx:325-390, 413-419), on the GPU --------
+DISPLAY_CANVAS, DISPLAY_CANVAS_RGB15, DISPLAY_SETPIXELS, DISPLAY_SETPIXELS_RGB15 = 0, 1, 2, 3
+
+
+def display_convert(frame, out, width: int, height: int, mode: int = DISPLAY_CANVAS, flip_rows: bool = False,
+                    stream: int = 0) -> None:
+    """Manager.fill_bitmap_data on device tensors (int32, width*height)."""
+    lib = N.lib()
+    rc = lib.jsp_display_convert(C.c_void_p(_frame_ptr(frame, width * height)), C.c_void_p(_frame_ptr(out, width * height)),
+                                 width, height, mode, 1 if flip_rows else 0, C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise CodecError(N.last_error())
+
+
+def frames_differ(a, b, first_pixel: int, npixels: int, stream: int = 0) -> bool:
+    """The pixel compare of Manager.frames_differ_significantly on device tensors."""
+    lib = N.lib()
+    out = C.c_int(0)
+    rc = lib.jsp_frames_differ(C.c_void_p(_frame_ptr(a, npixels)), C.c_void_p(_frame_ptr(b, npixels)), first_pixel, npixels,
+                               C.byref(out), C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise CodecError(N.last_error())
+    return bool(out.value)

@@ -1,0 +1,112 @@
+// The two per-pixel passes of the reference's Manager that sit directly after the codec
+// (SURVEY.md §8f-1, §8f-3), as HBM-bound HIP kernels so a decoded frame never has to visit the CPU:
+//   display_convert : Manager.fill_bitmap_data (Manager.hx:325-390) — RGB32 0x00RRGGBB -> canvas pixels
+//   frames_differ   : the pixel loop of frames_differ_significantly (Manager.hx:413-419)
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/jsplayer_amd.h"
+#include "common.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t convert(uint32_t c, int mode) {
+    switch (mode) {
+        case JSP_DISPLAY_CANVAS: return 0xFF000000u | ((c & 0xFFu) << 16) | (c & 0xFF00u) | ((c >> 16) & 0xFFu);  // :379
+        case JSP_DISPLAY_CANVAS_RGB15: return 0xFF000000u | (c << 3);                                           // :370
+        case JSP_DISPLAY_SETPIXELS: return 0xFF000000u | c;                                                      // :351
+        default: return c << 11;                                                                                  // :340
+    }
+}
+
+__global__ __launch_bounds__(256) void display_convert_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                              int X, int Y, int mode, int flip, int vec) {
+    const int y = blockIdx.y;
+    const int ys = flip ? Y - 1 - y : y;
+    const uint32_t* s = src + (size_t)ys * X;
+    uint32_t* d = dst + (size_t)y * X;
+    if (vec) {
+        for (int x = (blockIdx.x * 256 + threadIdx.x) * 4; x < X; x += gridDim.x * 256 * 4) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(s + x));
+            __builtin_nontemporal_store(u32x4{convert(v.x, mode), convert(v.y, mode), convert(v.z, mode), convert(v.w, mode)},
+                                        reinterpret_cast<u32x4*>(d + x));
+        }
+    } else {
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < X; x += gridDim.x * 256) d[x] = convert(s[x], mode);
+    }
+}
+
+__global__ __launch_bounds__(256) void frames_differ_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                            size_t first, size_t n, uint32_t* __restrict__ flag) {
+    bool diff = false;
+    // 16-byte body when both pointers allow it, scalar head/tail otherwise
+    const size_t stride = (size_t)gridDim.x * 256;
+    const bool vec_ok = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    size_t lo = first, hi = n;
+    if (vec_ok) {
+        const size_t lo4 = (first + 3) & ~size_t(3), hi4 = n & ~size_t(3);
+        if (lo4 < hi4) {
+            for (size_t i = lo4 + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < hi4; i += stride * 4) {
+                const u32x4 p = *reinterpret_cast<const u32x4*>(a + i), q = *reinterpret_cast<const u32x4*>(b + i);
+                diff |= (p.x != q.x) | (p.y != q.y) | (p.z != q.z) | (p.w != q.w);
+            }
+            for (size_t i = first + (size_t)blockIdx.x * 256 + threadIdx.x; i < lo4; i += stride) diff |= a[i] != b[i];
+            lo = hi4;
+        }
+    }
+    for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += stride) diff |= a[i] != b[i];
+    if (__ballot(diff) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+}  // namespace
+
+extern "C" {
+
+int jsp_display_convert(const int32_t* frame, int32_t* out, int width, int height, int mode, int flip_rows,
+                        void* hip_stream) {
+    try {
+        if (!frame || !out || width <= 0 || height <= 0 || mode < 0 || mode > 3) throw std::runtime_error("bad argument");
+        const int vec = ((width & 3) == 0 && (((uintptr_t)frame | (uintptr_t)out) & 15) == 0) ? 1 : 0;
+        int gx = (width / (vec ? 4 : 1) + 255) / 256;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(display_convert_kernel, dim3(gx, height), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                           reinterpret_cast<const uint32_t*>(frame), reinterpret_cast<uint32_t*>(out), width, height, mode,
+                           flip_rows ? 1 : 0, vec);
+        JSP_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        jsp::set_error("%s", e.what());
+        return JSP_ERROR_OCCURED;
+    }
+}
+
+int jsp_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, size_t npixels, int* differ,
+                      void* hip_stream) {
+    try {
+        if (!a || !b || !differ) throw std::runtime_error("null argument");
+        *differ = 0;
+        if (first_pixel >= npixels) return 0;
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        uint32_t* d_flag = nullptr;
+        JSP_HIP(hipMalloc(reinterpret_cast<void**>(&d_flag), sizeof(uint32_t)));
+        JSP_HIP(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), s));
+        const size_t count = npixels - first_pixel;
+        int grid = (int)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(frames_differ_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(a),
+                           reinterpret_cast<const uint32_t*>(b), first_pixel, npixels, d_flag);
+        uint32_t h = 0;
+        JSP_HIP(hipMemcpyAsync(&h, d_flag, sizeof h, hipMemcpyDeviceToHost, s));
+        JSP_HIP(hipStreamSynchronize(s));
+        (void)hipFree(d_flag);
+        *differ = h ? 1 : 0;
+        return 0;
+    } catch (const std::exception& e) {
+        jsp::set_error("%s", e.what());
+        return JSP_ERROR_OCCURED;
+    }
+}
+}

@@ -42,7 +42,8 @@ def make_decoder(vi: VideoInfo, classes) -> object:
 def _differ(a, b, start: int) -> bool:
     if isinstance(a, np.ndarray):
         return bool(np.any(a[start:] != b[start:]))
-    return bool((a[start:] != b[start:]).any().item())  # torch tensors
+    from .codec import frames_differ   # device tensors: HIP reduction, the frames stay in HBM
+    return frames_differ(a, b, start, a.numel())
 
 
 class Manager:

@@ -99,3 +99,34 @@ def test_avi_clip_gpu_matches_cpu_reference_path(bits):
         b = gpu.worker(f, i, None)
         assert (a.key, a.buffer_index, a.significant_changes, a.state) == (b.key, b.buffer_index, b.significant_changes, b.state)
         assert np.array_equal(cpu.buffers[a.buffer_index], gpu.buffers[b.buffer_index].cpu().numpy()), i
+
+
+@pytest.mark.gpu
+def test_display_convert_and_frames_differ_kernels():
+    """Manager.fill_bitmap_data / frames_differ_significantly restated in numpy vs the HIP kernels."""
+    import torch
+    from jsplayer_amd import codec as cm
+    rng = np.random.default_rng(3)
+    for (w, h) in [(1920, 1080), (321, 7), (64, 48)]:
+        src = rng.integers(0, 1 << 24, size=w * h, dtype=np.uint32)
+        t = torch.from_numpy(src.view(np.int32)).cuda()
+        out = torch.empty_like(t)
+        for mode, fn in [(cm.DISPLAY_CANVAS, lambda c: 0xFF000000 | ((c & 0xFF) << 16) | (c & 0xFF00) | ((c >> 16) & 0xFF)),
+                         (cm.DISPLAY_CANVAS_RGB15, lambda c: 0xFF000000 | ((c << 3) & 0xFFFFFFFF)),
+                         (cm.DISPLAY_SETPIXELS, lambda c: 0xFF000000 | c),
+                         (cm.DISPLAY_SETPIXELS_RGB15, lambda c: (c << 11) & 0xFFFFFFFF)]:
+            for flip in (False, True):
+                cm.display_convert(t, out, w, h, mode, flip)
+                torch.cuda.synchronize()
+                exp = fn(src.astype(np.uint64)).astype(np.uint32).reshape(h, w)
+                if flip:
+                    exp = exp[::-1]
+                assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), exp), (w, h, mode, flip)
+        b = t.clone()
+        assert cm.frames_differ(t, b, 0, w * h) is False
+        b[w * h - 1] += 1
+        assert cm.frames_differ(t, b, 0, w * h) is True
+        assert cm.frames_differ(t, b, w * h - 1, w * h) is True
+        b[w * h - 1] -= 1
+        b[5] += 1
+        assert cm.frames_differ(t, b, 6, w * h) is False and cm.frames_differ(t, b, 5, w * h) is True
