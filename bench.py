@@ -37,6 +37,8 @@ WORKLOADS = {
     "msvideo1_16_1080p_inter70": dict(bits=16, w=1920, h=1080, frames=64, mix="m1", config_index=2, inter=0.70),
     # BASELINE.json configs[2]: ScreenPressor 1080p I-frames (host rANS -> GPU run expansion), 64 key frames
     "screenpressor_v4_1080p_iframes": dict(sp=True, version=4, w=1920, h=1080, frames=64, config_index=3, mode="intra"),
+    # throughput regime: 8 replicas of the 64 distinct key frames, 512 workgroups in one launch
+    "screenpressor_v4_1080p_iframes_x8": dict(sp=True, version=4, w=1920, h=1080, frames=64, config_index=3, mode="intra", replicas=8),
     "screenpressor_v2_1080p_iframes": dict(sp=True, version=2, w=1920, h=1080, frames=64, config_index=3, mode="intra"),
     # BASELINE.json configs[3]: ScreenPressor 1080p 300-frame clip, inter-frame kernel (frame 0 = key frame, untimed)
     "screenpressor_v4_1080p_pclip300": dict(sp=True, version=4, w=1920, h=1080, frames=300, config_index=4, mode="inter"),
@@ -130,6 +132,9 @@ def main():
     codec.Preinit(36)
     if spec.get("gpu_parse"):
         codec.set_option("msv1_parse", "gpu")
+    if spec.get("replicas"):
+        frames, keys = frames * spec["replicas"], keys * spec["replicas"]
+        nfr = len(frames)
     if spec.get("mode") == "inter":
         # the clip's key frame is decoded up front; the timed batch is the inter frames only
         first = torch.empty(w * h, dtype=torch.int32, device="cuda")

@@ -9,6 +9,8 @@
 // sp_pframe_kernel — P-frame: a workgroup covers 4 horizontally adjacent 16x16 blocks (64 px =
 //   256 contiguous bytes per row), lane = 16-byte chunk of a row: unchanged / base copy / motion
 //   from the previous frame in HBM, literal payload for data rectangles (ScreenPressor.hx:361-475).
+#include <cstdlib>
+
 #include "sp.h"
 
 namespace jsp::sp {
@@ -23,6 +25,22 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Pointers that reach a kernel inside a struct read from memory have no known address space, so
+// plain accesses through them become FLAT instructions — which count on lgkmcnt as well as vmcnt and
+// would tie every LDS wait of the row loop to the latency of the frame stores.  Say "global".
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+__device__ __forceinline__ void store4_global(uint32_t* p, const uint4& v) {
+    *(gu32x4*)p = u32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store1_global(uint32_t* p, uint32_t v) { *(gu32*)p = v; }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) uint32_t cgu32;
+typedef const __attribute__((address_space(1))) u32x2 cgu32x2;
+__device__ __forceinline__ uint32_t load1_global(const uint32_t* p) { return *(cgu32*)p; }
+__device__ __forceinline__ uint2 load2_global(const uint2* p) { const u32x2 v = *(cgu32x2*)p; return make_uint2(v.x, v.y); }
+
 __device__ __forceinline__ uint32_t add_bytes(uint32_t u, uint32_t d) {  // per byte, bytes 0..2
     return (((u & 0x00FF00FFu) + (d & 0x00FF00FFu)) & 0x00FF00FFu) | (((u & 0x0000FF00u) + (d & 0x0000FF00u)) & 0x0000FF00u);
 }
@@ -35,7 +53,7 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     const int tid = threadIdx.x;
     const size_t npx = (size_t)X * Y;
     if (fa.flat) {  // flat key frame: one colour (ScreenPressor.hx:132-155)
-        for (size_t i = tid; i < npx; i += IWG) dst[i] = fa.colour;
+        for (size_t i = tid; i < npx; i += IWG) store1_global(dst + i, fa.colour);
         return;
     }
     // LDS plan: two row buffers, the whole row index, and a window of run records {start, word}
@@ -46,7 +64,7 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     uint32_t* rowidx = lds + 2 * rowcap;              // Y + 1 entries
     uint32_t* lastpix = rowidx + ((Y + 1 + 3) & ~3);  // last pixel of each of the 4 most recent rows
     uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records
-    for (int k = tid; k <= Y; k += IWG) rowidx[k] = fa.row_run[k];
+    for (int k = tid; k <= Y; k += IWG) rowidx[k] = load1_global(fa.row_run + k);
     if (tid < 4) lastpix[tid] = 0;
     __syncthreads();
     const bool vec = (X & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
@@ -61,7 +79,7 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
         while (y_end < Y && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
         const int wn = (int)(rowidx[y_end] - w0) + 1;
         const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
-        for (int k = tid; k < wn; k += IWG) win[k] = gruns[k];
+        for (int k = tid; k < wn; k += IWG) win[k] = load2_global(gruns + k);
         __syncthreads();  // the run records arrive through vmcnt: full barrier once per window
         for (; y < y_end; ++y) {
             uint32_t* cur = (y & 1) ? rowbuf1 : rowbuf0;
@@ -120,14 +138,14 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
                 if (vec) {
                     const uint4 q = make_uint4(px[0], px[1], px[2], px[3]);
                     *reinterpret_cast<uint4*>(cur + x0) = q;
-                    *reinterpret_cast<uint4*>(dst + row0 + x0) = q;
+                    store4_global(dst + row0 + x0, q);
                     if (x0 + 4 == X) lastpix[y & 3] = px[3];
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (x0 + j < X) {
                             cur[x0 + j] = px[j];
-                            dst[row0 + x0 + j] = px[j];
+                            store1_global(dst + row0 + x0 + j, px[j]);
                             if (x0 + j == X - 1) lastpix[y & 3] = px[j];
                         }
                 }
@@ -137,17 +155,21 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     }
 }
 
-// Fast path (X a multiple of 4, X <= 4*WG): no per-pixel search at all.
+// Fast path (X a multiple of 4, X <= PPL*WG): no per-pixel search at all.
 //   scatter : one lane per run writes (run index + 1) at the run's first column of the row — and at
-//             every 256-pixel wave boundary the run covers — into a zeroed "head" row in LDS;
-//   resolve : a lane reads the 4 heads of its pixels, takes the running maximum (heads grow with the
+//             every wave boundary (64*PPL pixels) the run covers — into a zeroed "head" row in LDS;
+//   resolve : a lane reads the PPL heads of its pixels, takes the running maximum (heads grow with the
 //             column), and gets the carry from the nearest lower lane that saw a head through one
 //             ballot + one cross-lane read; the first lane of every wave always sees a head.
 // The scatter for row y+1 does not depend on row y's pixels, so it is issued before the single
-// end-of-row barrier: one barrier and about four LDS round trips per image row.
-template <int WG>
+// end-of-row barrier: one barrier and a handful of LDS round trips per image row.  The loop is bound
+// by VALU issue, so lanes take PPL = 8 pixels: half the waves, the per-lane overhead amortised.
+template <int WG, int PPL>
 __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
                                                             int run_cap) {
+    static_assert(PPL == 4 || PPL == 8, "4 or 8 pixels per lane");
+    constexpr int V = PPL / 4;                    // uint4 vectors per lane
+    constexpr uint32_t WAVE_PX = 64 * PPL;        // pixels one wave covers
     extern __shared__ __align__(16) uint32_t lds[];
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
@@ -155,10 +177,10 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
     const size_t npx = (size_t)X * Y;
     if (fa.flat) {
         for (size_t i = (size_t)tid * 4; i < npx; i += (size_t)WG * 4)
-            *reinterpret_cast<uint4*>(dst + i) = make_uint4(fa.colour, fa.colour, fa.colour, fa.colour);
+            store4_global(dst + i, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
         return;
     }
-    const int rowcap = (X + 4 + 3) & ~3;
+    const int rowcap = (X + 8 + 7) & ~7;
     uint32_t* rowbuf0 = lds;
     uint32_t* rowbuf1 = lds + rowcap;
     uint32_t* head0 = lds + 2 * rowcap;
@@ -166,26 +188,28 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
     uint32_t* rowidx = lds + 4 * rowcap;              // Y + 1 entries
     uint32_t* lastpix = rowidx + ((Y + 1 + 3) & ~3);
     uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records {start, word}
-    for (int k = tid; k <= Y; k += WG) rowidx[k] = fa.row_run[k];
+    for (int k = tid; k <= Y; k += WG) rowidx[k] = load1_global(fa.row_run + k);
     for (int k = tid; k < 2 * rowcap; k += WG) head0[k] = 0;   // head0 and head1 are contiguous
     if (tid < 4) lastpix[tid] = 0;
     __syncthreads();
-    const int x0 = tid * 4;
+    const int x0 = tid * PPL;
     const int lane = tid & 63;
+    const bool active = x0 < X;                       // X % 4 == 0; with PPL 8 the last lane may own 4 pixels
+    const bool half = PPL == 8 && active && x0 + 4 >= X;
 
-    auto scatter = [&](int yy, uint32_t w0, uint32_t* head) {
+    auto put_heads = [&](uint32_t* head, uint32_t r, uint32_t s, uint32_t e, uint32_t row0) {
+        const uint32_t col = s <= row0 ? 0u : s - row0;
+        if (col >= (uint32_t)X) return;              // the run that opens the next row
+        head[col] = r + 1u;
+        const uint32_t ecol = e - row0 < (uint32_t)X ? e - row0 : (uint32_t)X;
+        for (uint32_t p = (col / WAVE_PX + 1u) * WAVE_PX; p < ecol; p += WAVE_PX) head[p] = r + 1u;
+    };
+    auto scatter_all = [&](int yy, uint32_t w0, uint32_t* head, int first) {
         const uint2* rr = win + (int)(rowidx[yy] - w0);
         const int nr = (int)(rowidx[yy + 1] - rowidx[yy]) + 1;
         const uint32_t row0 = (uint32_t)((size_t)yy * X);
-        for (int r = tid; r < nr; r += WG) {
-            const uint32_t s = rr[r].x;
-            const uint32_t e = r + 1 < nr ? rr[r + 1].x : row0 + (uint32_t)X;
-            const uint32_t col = s <= row0 ? 0u : s - row0;
-            if (col >= (uint32_t)X) continue;            // the run that opens the next row
-            head[col] = (uint32_t)r + 1u;
-            const uint32_t ecol = e - row0 < (uint32_t)X ? e - row0 : (uint32_t)X;
-            for (uint32_t p = ((col >> 8) + 1u) << 8; p < ecol; p += 256u) head[p] = (uint32_t)r + 1u;
-        }
+        for (int r = first; r < nr; r += WG)
+            put_heads(head, (uint32_t)r, rr[r].x, r + 1 < nr ? rr[r + 1].x : row0 + (uint32_t)X, row0);
     };
 
     int y = 0;
@@ -195,9 +219,9 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
         while (y_end < Y && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
         const int wn = (int)(rowidx[y_end] - w0) + 1;
         const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
-        for (int k = tid; k < wn; k += WG) win[k] = gruns[k];
+        for (int k = tid; k < wn; k += WG) win[k] = load2_global(gruns + k);
         __syncthreads();  // run records arrive through vmcnt: full barrier once per window
-        scatter(y, w0, (y & 1) ? head1 : head0);
+        scatter_all(y, w0, (y & 1) ? head1 : head0, tid);
         lds_barrier();
         uint32_t ri0 = rowidx[y], ri1 = rowidx[y + 1];       // rolling copies of the row index
         for (; y < y_end; ++y) {
@@ -210,12 +234,17 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
             // ---- all loads of this row that do not depend on each other, issued together -------
             const uint32_t ri2 = more ? rowidx[y + 2] : ri1;
             const uint32_t wrap_left = y >= 2 ? lastpix[(y - 2) & 3] : 0u;
-            const bool active = x0 < X;
-            uint4 h = make_uint4(0, 0, 0, 0), q = make_uint4(0, 0, 0, 0);
+            uint4 h[V], q[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { h[v] = make_uint4(0, 0, 0, 0); q[v] = make_uint4(0, 0, 0, 0); }
             uint32_t uleft = 0;
             if (active) {
-                h = *reinterpret_cast<const uint4*>(head + x0);
-                q = *reinterpret_cast<const uint4*>(up + x0);
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (v == 0 || !half) {
+                        h[v] = *reinterpret_cast<const uint4*>(head + x0 + 4 * v);
+                        q[v] = *reinterpret_cast<const uint4*>(up + x0 + 4 * v);
+                    }
                 uleft = x0 > 0 ? up[x0 - 1] : wrap_left;
             }
             // first scatter item of the NEXT row (rows rarely have more runs than lanes)
@@ -229,52 +258,51 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
             const uint32_t row0 = (uint32_t)((size_t)y * X);
             // ---- resolve ---------------------------------------------------------------------
             if (active) {
-                *reinterpret_cast<uint4*>(head + x0) = make_uint4(0, 0, 0, 0);  // ready for row y+2
-                const uint32_t l0 = h.x, l1 = max(l0, h.y), l2 = max(l1, h.z), l3 = max(l2, h.w);
-                const unsigned long long seen = __ballot(l3 != 0u);
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (v == 0 || !half) *reinterpret_cast<uint4*>(head + x0 + 4 * v) = make_uint4(0, 0, 0, 0);  // for row y+2
+                uint32_t l[PPL];
+#pragma unroll
+                for (int v = 0; v < V; ++v) { l[4 * v] = h[v].x; l[4 * v + 1] = h[v].y; l[4 * v + 2] = h[v].z; l[4 * v + 3] = h[v].w; }
+#pragma unroll
+                for (int j = 1; j < PPL; ++j) l[j] = max(l[j], l[j - 1]);
+                const unsigned long long seen = __ballot(l[PPL - 1] != 0u);
                 const unsigned long long lower = seen & ((1ull << lane) - 1ull);
                 const int src = lower ? 63 - __clzll((long long)lower) : lane;
-                uint32_t carry = (uint32_t)__shfl((int)l3, src);
+                uint32_t carry = (uint32_t)__shfl((int)l[PPL - 1], src);
                 if (!lower) carry = 0;
-                // run of each pixel (lane 0 of a wave always has h.x != 0)
-                const uint32_t w_0 = rr[max(carry, l0) - 1u].y, w_1 = rr[max(carry, l1) - 1u].y,
-                               w_2 = rr[max(carry, l2) - 1u].y, w_3 = rr[max(carry, l3) - 1u].y;
-                const uint32_t u[5] = {uleft, q.x, q.y, q.z, q.w};
-                const uint32_t w[4] = {w_0, w_1, w_2, w_3};
-                uint32_t px[4];
+                // run of each pixel (lane 0 of a wave always has l[0] != 0)
+                uint32_t w[PPL];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < PPL; ++j) w[j] = rr[max(carry, l[j]) - 1u].y;
+                uint32_t u[PPL + 1];
+                u[0] = uleft;
+#pragma unroll
+                for (int v = 0; v < V; ++v) { u[4 * v + 1] = q[v].x; u[4 * v + 2] = q[v].y; u[4 * v + 3] = q[v].z; u[4 * v + 4] = q[v].w; }
+                uint32_t px[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
                     const uint32_t kind = w[j] >> 24, val = w[j] & 0xFFFFFFu;
                     const uint32_t above = kind == RUN_ABOVE_LEFT ? u[j] : u[j + 1];
                     uint32_t v = kind == RUN_ABOVE_PLUS ? add_bytes(above, val) : above;
                     if (y == 0) v = 0;                      // above the buffer: undefined -> 0
                     px[j] = kind == RUN_CONST ? val : v;
                 }
-                const uint4 o = make_uint4(px[0], px[1], px[2], px[3]);
-                *reinterpret_cast<uint4*>(cur + x0) = o;
-                *reinterpret_cast<uint4*>(dst + row0 + x0) = o;
-                if (x0 + 4 == X) lastpix[y & 3] = px[3];
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (v == 0 || !half) {
+                        const uint4 o = make_uint4(px[4 * v], px[4 * v + 1], px[4 * v + 2], px[4 * v + 3]);
+                        *reinterpret_cast<uint4*>(cur + x0 + 4 * v) = o;
+                        store4_global(dst + row0 + x0 + 4 * v, o);
+                    }
+                if (x0 + PPL == X) lastpix[y & 3] = px[PPL - 1];
+                else if (half) lastpix[y & 3] = px[3];
             }
             // ---- scatter the heads of row y+1 ------------------------------------------------
             if (more) {
                 const uint32_t nrow0 = row0 + (uint32_t)X;
-                if (tid < nr_next) {
-                    const uint32_t col = ns <= nrow0 ? 0u : ns - nrow0;
-                    if (col < (uint32_t)X) {
-                        head_next[col] = (uint32_t)tid + 1u;
-                        const uint32_t en = ne < nrow0 + (uint32_t)X ? ne : nrow0 + (uint32_t)X;
-                        for (uint32_t p = ((col >> 8) + 1u) << 8; p < en - nrow0; p += 256u) head_next[p] = (uint32_t)tid + 1u;
-                    }
-                }
-                for (int r = tid + WG; r < nr_next; r += WG) {   // rows with more runs than lanes
-                    const uint32_t s2 = rn[r].x;
-                    const uint32_t e2 = r + 1 < nr_next ? rn[r + 1].x : nrow0 + (uint32_t)X;
-                    const uint32_t col = s2 <= nrow0 ? 0u : s2 - nrow0;
-                    if (col >= (uint32_t)X) continue;
-                    head_next[col] = (uint32_t)r + 1u;
-                    const uint32_t ecol = e2 - nrow0 < (uint32_t)X ? e2 - nrow0 : (uint32_t)X;
-                    for (uint32_t p = ((col >> 8) + 1u) << 8; p < ecol; p += 256u) head_next[p] = (uint32_t)r + 1u;
-                }
+                if (tid < nr_next) put_heads(head_next, (uint32_t)tid, ns, ne < nrow0 + (uint32_t)X ? ne : nrow0 + (uint32_t)X, nrow0);
+                if (nr_next > WG) scatter_all(y + 1, w0, head_next, tid + WG);   // rows with more runs than lanes
             }
             ri0 = ri1;
             ri1 = ri2;
@@ -352,10 +380,10 @@ namespace {
 // LDS words needed besides the run window: row buffers (+ head rows on the fast path), row index,
 // last-pixel ring
 size_t iframe_fixed_words(const Geometry& g, bool fast) {
-    const size_t rowcap = ((size_t)g.X + 4 + 3) & ~size_t(3);
+    const size_t rowcap = fast ? (((size_t)g.X + 8 + 7) & ~size_t(7)) : (((size_t)g.X + 4 + 3) & ~size_t(3));
     return (fast ? 4 : 2) * rowcap + (((size_t)g.Y + 1 + 3) & ~size_t(3)) + 4;
 }
-bool iframe_fast(const Geometry& g) { return (g.X & 3) == 0 && g.X <= 4096; }
+bool iframe_fast(const Geometry& g) { return (g.X & 3) == 0 && g.X <= 8192; }
 // run records staged per window: what a 72 KiB budget leaves (two workgroups per CU), at least a row
 int iframe_run_cap(const Geometry& g) {
     const size_t fixed = iframe_fixed_words(g, iframe_fast(g));
@@ -379,17 +407,39 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hi
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_search_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512, 4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<256, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (iframe_fast(g) && g.aligned16) {
-        if (g.X <= 2048)
-            hipLaunchKernelGGL(sp_iframe_rows_kernel<512>, dim3(nframes), dim3(512), lds, stream, d_args, g.X, g.Y, cap);
-        else
-            hipLaunchKernelGGL(sp_iframe_rows_kernel<1024>, dim3(nframes), dim3(1024), lds, stream, d_args, g.X, g.Y, cap);
+        // One frame = one workgroup.  4 pixels per lane (8 waves per 1080p frame) wins both with 64
+        // frames in flight (0.96 vs 1.37 ms) and with 512 (1.43 vs 1.70 ms): the waves hide each
+        // other's LDS round trips.  8 pixels per lane is kept for frames wider than 4096 pixels and
+        // as a tuning knob (JSP_SP_IFRAME_PPL=8).
+        static const char* force = getenv("JSP_SP_IFRAME_PPL");
+        const bool wide = force && force[0] == '8';
+        const bool can4 = g.X <= 4096;
+        if (wide || !can4) {
+            if (g.X <= 2048)
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<256, 8>), dim3(nframes), dim3(256), lds, stream, d_args, g.X, g.Y, cap);
+            else if (g.X <= 4096)
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 8>), dim3(nframes), dim3(512), lds, stream, d_args, g.X, g.Y, cap);
+            else
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 8>), dim3(nframes), dim3(1024), lds, stream, d_args, g.X, g.Y, cap);
+        } else {
+            if (g.X <= 2048)
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 4>), dim3(nframes), dim3(512), lds, stream, d_args, g.X, g.Y, cap);
+            else
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 4>), dim3(nframes), dim3(1024), lds, stream, d_args, g.X, g.Y, cap);
+        }
     } else {
         hipLaunchKernelGGL(sp_iframe_rows_search_kernel, dim3(nframes), dim3(IWG), lds, stream, d_args, g.X, g.Y, cap);
     }
