@@ -30,8 +30,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Frame rows are written once and never read back by this launch: nontemporal stores keep them from
 // evicting the stream / descriptor lines out of L2 (measured: 168 -> 91 us per 64-frame batch together
 // with the LDS staging below, tools/msv1_lab.hip).
+// (dst/prev reach the kernel inside a struct read from memory: without the explicit global address
+// space the accesses would be FLAT instructions)
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+typedef const __attribute__((address_space(1))) u32x4 cgu32x4;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef const __attribute__((address_space(1))) uint32_t cgu32;
 __device__ __forceinline__ void store_row(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    __builtin_nontemporal_store(u32x4{a, b, c, d}, reinterpret_cast<u32x4*>(p));
+    __builtin_nontemporal_store(u32x4{a, b, c, d}, (gu32x4*)p);
+}
+__device__ __forceinline__ uint4 load_row(const uint32_t* p) {
+    const u32x4 v = *(cgu32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 template <int BITS, bool VEC>
@@ -83,10 +93,10 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
     if (o == MSV1_DESC_SKIP) {
         const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev) + di;
         if (VEC) {
-            uint4 r0 = *reinterpret_cast<const uint4*>(prev);
-            uint4 r1 = *reinterpret_cast<const uint4*>(prev + X);
-            uint4 r2 = *reinterpret_cast<const uint4*>(prev + 2 * (size_t)X);
-            uint4 r3 = *reinterpret_cast<const uint4*>(prev + 3 * (size_t)X);
+            uint4 r0 = load_row(prev);
+            uint4 r1 = load_row(prev + X);
+            uint4 r2 = load_row(prev + 2 * (size_t)X);
+            uint4 r3 = load_row(prev + 3 * (size_t)X);
             store_row(dst, r0.x, r0.y, r0.z, r0.w);
             store_row(dst + X, r1.x, r1.y, r1.z, r1.w);
             store_row(dst + 2 * (size_t)X, r2.x, r2.y, r2.z, r2.w);
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
 #pragma unroll
             for (int y = 0; y < 4; ++y)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) dst[(size_t)y * X + x] = prev[(size_t)y * X + x];
+                for (int x = 0; x < 4; ++x) *(gu32*)(dst + (size_t)y * X + x) = *(cgu32*)(prev + (size_t)y * X + x);
         }
         return;
     }
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
 #pragma unroll
         for (int y = 0; y < 4; ++y)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) dst[(size_t)y * X + x] = px[y * 4 + x];
+            for (int x = 0; x < 4; ++x) *(gu32*)(dst + (size_t)y * X + x) = px[y * 4 + x];
     }
 
     // stage-2 significance: does any pixel at or above row cmp_row_lo differ from prev?
@@ -180,12 +190,12 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
         for (int y = 0; y < 4; ++y) {
             if ((uint32_t)(by * 4 + y) >= fa.cmp_row_lo) {
                 if (VEC) {
-                    const uint4 p = *reinterpret_cast<const uint4*>(prev + (size_t)y * X);
+                    const uint4 p = load_row(prev + (size_t)y * X);
                     diff |= (p.x != px[y * 4]) | (p.y != px[y * 4 + 1]) | (p.z != px[y * 4 + 2]) |
                             (p.w != px[y * 4 + 3]);
                 } else {
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) diff |= prev[(size_t)y * X + x] != px[y * 4 + x];
+                    for (int x = 0; x < 4; ++x) diff |= *(cgu32*)(prev + (size_t)y * X + x) != px[y * 4 + x];
                 }
             }
         }
