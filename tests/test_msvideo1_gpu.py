@@ -234,3 +234,33 @@ def test_batch_with_inter_frames_matches_oracle():
             assert bool(adopted[i]) == (data is obufs[i])
         assert np.array_equal(obufs[i], to_np(dsts[i])), i
     st.close()
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_fuzz_many_random_streams(bits):
+    """A few thousand short random / mutated streams at random small sizes: oracle and HIP path must
+    agree on every pixel, every significant_changes flag and every buffer identity."""
+    rng = np.random.default_rng(1234 + bits)
+    total = 0
+    for case in range(12):
+        w, h = int(rng.integers(1, 17)) * 4 + int(rng.integers(0, 4)), int(rng.integers(1, 13)) * 4 + int(rng.integers(0, 4))
+        frames, keys, pal = sg.msv1_clip(3000 + case, w, h, 4, bits=bits, p_mix=sg.msv1_p_mix(0.5, 6.0))
+        srcs, ks = [frames[0]], [True]
+        for k in range(120):
+            kind = int(rng.integers(0, 4))
+            base = bytearray(frames[1 + k % 3])
+            if kind == 0:      # as generated
+                pass
+            elif kind == 1:    # random byte flips
+                for _ in range(int(rng.integers(1, 6))):
+                    if base:
+                        base[int(rng.integers(0, len(base)))] = int(rng.integers(0, 256))
+            elif kind == 2:    # truncated
+                base = base[: int(rng.integers(0, len(base) + 1))]
+            else:              # pure noise
+                base = bytearray(rng.integers(0, 256, size=int(rng.integers(0, 3 * len(base) + 8)), dtype=np.uint8).tobytes())
+            srcs.append(bytes(base))
+            ks.append(bool(rng.integers(0, 8) == 0))
+        total += len(srcs)
+        drive_pair(bits, w, h, srcs, ks, pal, lines=int(rng.integers(0, 12)))
+    assert total > 1400

@@ -140,3 +140,36 @@ def test_batch_of_key_frames_one_launch_and_p_clip():
     info = st.info()
     assert info["kernel_launches"] == 10
     st.close()
+
+
+@pytest.mark.parametrize("head", [0x12, 0x22, 0x32])
+def test_garbage_streams_never_fault(head):
+    """Random bytes behind a valid header: the reference itself raises, spins or paints noise on such
+    input ("invalid ScreenPressor streams"), so there is no parity claim — but the host
+    stage must hand the kernels only in-range descriptors and the codec must stay usable."""
+    w, h = 320, 240
+    rng = np.random.default_rng(head)
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    bufs = [dev_buf(w * h, 0) for _ in range(3)]
+    good, keys, frames = sg.sp_clip(970, w, h, 2, version=(head >> 4) + 1)
+    assert good[1] != b"\x00"
+    assert gpu.DecompressI(good[0], bufs[0]) == DecoderState.zero_state
+    for i in range(60):
+        junk = bytes([head if i % 3 else 1]) + rng.integers(0, 256, size=int(rng.integers(1, 400)), dtype=np.uint8).tobytes()
+        dst = next(b for b in bufs if b is not gpu.PreviousFrame())
+        if i % 2:
+            st = gpu.DecompressI(junk, dst)
+            assert st in (DecoderState.zero_state, DecoderState.error_occured)
+        else:
+            try:
+                gpu.DecompressP(junk, dst)
+            except CodecError:
+                pass
+    # a fresh coded key frame resets every model: decoding is exact again
+    dst = next(b for b in bufs if b is not gpu.PreviousFrame())
+    assert gpu.DecompressI(good[0], dst) == DecoderState.zero_state
+    assert np.array_equal(to_np(dst).view(np.uint32), frames[0])
+    dst2 = next(b for b in bufs if b is not gpu.PreviousFrame())
+    res = gpu.DecompressP(good[1], dst2)
+    assert res.data_pnt is dst2 and np.array_equal(to_np(dst2).view(np.uint32), frames[1])
