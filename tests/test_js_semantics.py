@@ -1,0 +1,72 @@
+"""The C++ oracle spells out JavaScript's out-of-range / NaN / typed-array behaviour by hand; here a
+plain typed-array decoder runs under a real JS engine (node) on the same truncated and garbage
+streams and must agree with it — frames, significant_changes, buffer identity, raised-or-not."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from jsplayer_amd import streamgen as sg
+from oracle_binding import OracleAbort, OracleMSVideo1
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
+
+
+def build_cases():
+    rng = np.random.default_rng(77)
+    cases = []
+    for bits in (16, 8):
+        for (w, h) in [(16, 8), (12, 12), (37, 23), (64, 48)]:
+            frames, keys, pal = sg.msv1_clip(4000 + bits + w, w, h, 4, bits=bits, p_mix=sg.msv1_p_mix(0.5, 5.0))
+            seq = [frames[0]]
+            for k in range(40):
+                base = bytearray(frames[1 + k % 3])
+                kind = k % 5
+                if kind == 1 and base:
+                    base = base[: int(rng.integers(0, len(base)))]
+                elif kind == 2 and base:
+                    base[int(rng.integers(0, len(base)))] = int(rng.integers(0, 256))
+                elif kind == 3:
+                    base = bytearray(rng.integers(0, 256, size=int(rng.integers(0, 60)), dtype=np.uint8).tobytes())
+                elif kind == 4:
+                    base = base + b"\x07"      # odd length: AVI pad byte
+                seq.append(bytes(base))
+            cases.append(dict(bits=bits, w=w, h=h, lines=int(rng.integers(0, 9)), prefill=0x00A5A5A5,
+                              palette=list(pal) if pal else [], frames=[list(f) for f in seq]))
+        # a skip code before any frame exists: the reference raises a TypeError
+        cases.append(dict(bits=bits, w=16, h=8, lines=0, prefill=7, palette=list(sg.random_palette(sg.SplitMix64(5))) if bits == 8 else [],
+                          frames=[[0x00, 0xFC, 0x01, 0x84] + [0] * 8, [0x00, 0xFC] * 8]))
+    return cases
+
+
+def test_oracle_agrees_with_a_real_js_engine():
+    cases = build_cases()
+    res = subprocess.run([NODE, os.path.join(HERE, "js", "msv1_js_semantics.js")], input=json.dumps(cases).encode(),
+                         stdout=subprocess.PIPE, check=True)
+    js = json.loads(res.stdout)
+    checked = 0
+    for cs, jres in zip(cases, js):
+        orc = OracleMSVideo1(cs["bits"], cs["w"], cs["h"], bytes(cs["palette"]) or None)
+        orc.Preinit(cs["lines"])
+        bufs = [np.full(cs["w"] * cs["h"], cs["prefill"], dtype=np.int32) for _ in range(3)]
+        for f, jr in zip(cs["frames"], jres):
+            dst = next(b for b in bufs if b is not orc.PreviousFrame())
+            try:
+                data, sig = orc.DecompressP(bytes(f), dst)
+                raised = False
+            except OracleAbort:
+                raised = True
+            assert raised == jr["raised"]
+            assert dst.tolist() == jr["dst"], (cs["bits"], cs["w"], cs["h"], len(f))
+            if not raised:
+                assert sig == jr["signif"]
+                assert (data is not dst) == jr["same"] or (data is dst and not jr["same"])
+                which = next((i for i, b in enumerate(bufs) if b is orc.PreviousFrame()), -1)
+                assert which == jr["which"]
+            checked += 1
+    assert checked > 300
