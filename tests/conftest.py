@@ -35,5 +35,7 @@ def _built():
     """Make sure the oracle and the native library exist (cheap no-op when already built)."""
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    if not os.path.exists(os.path.join(ROOT, "jsplayer_amd", "libjspgen.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "jsplayer_amd", "gen")])
     if not os.path.exists(os.path.join(ROOT, "jsplayer_amd", "libjsplayer_amd.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "jsplayer_amd", "csrc"), "-j8"])
