@@ -22,8 +22,10 @@ struct Msv1FrameArgs {
     uint32_t stream_end;   // absolute offset one past this frame's last stream byte
     uint32_t desc_base;    // index of this frame's first descriptor
     uint32_t cmp_row_lo;   // first pixel row taking part in the stage-2 compare; ~0u = none
-    uint32_t pad;
+    uint32_t pad;          // flags: MSV1_FRAME_USES_PREV
 };
+
+constexpr uint32_t MSV1_FRAME_USES_PREV = 1u;  // some block copies from / compares with the previous frame
 
 struct Msv1Geometry {
     int bits;  // 16 or 8

@@ -321,6 +321,7 @@ struct Msv1Codec : jsp_codec {
                 st->significant[i] = f.key ? 0 : sg;
                 if (pr.changes) st->adopted[i] = 1;
             }
+            if (dependent && prev_dev) fa.pad |= MSV1_FRAME_USES_PREV;
             st->info.units_coded += pr.n_coded;
             st->info.units_copied += pr.n_skipped;
             st->info.stream_bytes += pr.consumed;

@@ -60,6 +60,21 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
     const bool live = blk < nblocks;
     const uint32_t o = live ? desc[fa.desc_base + blk] : MSV1_DESC_UNTOUCHED;
     const bool coded = o < MSV1_DESC_UNTOUCHED;
+    const int by = blk / nbx;
+    const int bx = blk - by * nbx;
+    const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
+    // Inter frames: the block's pixels in the previous frame are needed either way (copied by skipped
+    // blocks, compared by coded ones), so fetch them now, independent of the descriptor -> slice ->
+    // decode chain; a short one-frame launch is latency bound and this removes a round trip.
+    const bool preload = VEC && live && (fa.pad & MSV1_FRAME_USES_PREV);
+    uint4 pr0 = make_uint4(0, 0, 0, 0), pr1 = pr0, pr2 = pr0, pr3 = pr0;
+    if (preload) {
+        const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev) + di;
+        pr0 = load_row(prev);
+        pr1 = load_row(prev + X);
+        pr2 = load_row(prev + 2 * (size_t)X);
+        pr3 = load_row(prev + 3 * (size_t)X);
+    }
 
     // Stage the workgroup's slice of the code stream in LDS with coalesced 16-byte reads.  Codes are
     // in raster order, so the slice runs from the first coded lane's offset to the last coded lane's
@@ -85,22 +100,21 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
     __syncthreads();
     if (o == MSV1_DESC_UNTOUCHED) return;
 
-    const int by = blk / nbx;
-    const int bx = blk - by * nbx;
-    const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst) + di;
 
     if (o == MSV1_DESC_SKIP) {
         const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev) + di;
         if (VEC) {
-            uint4 r0 = load_row(prev);
-            uint4 r1 = load_row(prev + X);
-            uint4 r2 = load_row(prev + 2 * (size_t)X);
-            uint4 r3 = load_row(prev + 3 * (size_t)X);
-            store_row(dst, r0.x, r0.y, r0.z, r0.w);
-            store_row(dst + X, r1.x, r1.y, r1.z, r1.w);
-            store_row(dst + 2 * (size_t)X, r2.x, r2.y, r2.z, r2.w);
-            store_row(dst + 3 * (size_t)X, r3.x, r3.y, r3.z, r3.w);
+            if (!preload) {
+                pr0 = load_row(prev);
+                pr1 = load_row(prev + X);
+                pr2 = load_row(prev + 2 * (size_t)X);
+                pr3 = load_row(prev + 3 * (size_t)X);
+            }
+            store_row(dst, pr0.x, pr0.y, pr0.z, pr0.w);
+            store_row(dst + X, pr1.x, pr1.y, pr1.z, pr1.w);
+            store_row(dst + 2 * (size_t)X, pr2.x, pr2.y, pr2.z, pr2.w);
+            store_row(dst + 3 * (size_t)X, pr3.x, pr3.y, pr3.z, pr3.w);
         } else {
 #pragma unroll
             for (int y = 0; y < 4; ++y)
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
         for (int y = 0; y < 4; ++y) {
             if ((uint32_t)(by * 4 + y) >= fa.cmp_row_lo) {
                 if (VEC) {
-                    const uint4 p = load_row(prev + (size_t)y * X);
+                    const uint4 p = preload ? (y == 0 ? pr0 : y == 1 ? pr1 : y == 2 ? pr2 : pr3) : load_row(prev + (size_t)y * X);
                     diff |= (p.x != px[y * 4]) | (p.y != px[y * 4 + 1]) | (p.z != px[y * 4 + 2]) |
                             (p.w != px[y * 4 + 3]);
                 } else {
@@ -199,7 +213,11 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
                 }
             }
         }
-        if (__ballot(diff) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(diff)) - 1)
+        // one word per frame: thousands of waves OR-ing the same address serialise (measured: 24 us per
+        // inter frame, almost all of it here), so look before setting — an agent-scope load is enough,
+        // a stale 0 only costs one more atomic
+        if (__ballot(diff) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(diff)) - 1 &&
+            __hip_atomic_load(fa.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
             atomicOr(fa.signif, 1u);
     }
 }
@@ -230,7 +248,8 @@ __global__ __launch_bounds__(WG) void msv1_edge_compare_kernel(const Msv1FrameAr
             diff |= fa.dst[k] != fa.prev[k];
         }
     }
-    if (__ballot(diff) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(diff)) - 1)
+    if (__ballot(diff) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(diff)) - 1 &&
+        __hip_atomic_load(fa.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         atomicOr(fa.signif, 1u);
 }
 
