@@ -215,7 +215,7 @@ def main():
                 "kernel": ("sp_iframe_rows_kernel" if spec.get("mode") == "intra" else "sp_pframe_kernel")
                           if spec.get("sp") else ("msv1_parse_tiles + msv1_parse_chain + msv1_parse_emit + "
                                                   "msv1_blocks_kernel (whole step)" if spec.get("gpu_parse")
-                                                  else "msv1_blocks_kernel"),
+                                                  else ("msv1_blocks_temporal_kernel" if "inter" in spec else "msv1_blocks_kernel")),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -26,6 +26,7 @@ struct Msv1FrameArgs {
 };
 
 constexpr uint32_t MSV1_FRAME_USES_PREV = 1u;  // some block copies from / compares with the previous frame
+constexpr uint32_t MSV1_FRAME_NOOP = 2u;       // early-out frame: no block is written
 
 struct Msv1Geometry {
     int bits;  // 16 or 8
@@ -81,6 +82,11 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
                         const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
                         bool vec_ok, hipStream_t stream);
+// Inter-frame group in one launch: workgroup = spatial tile, frames walked in registers (needs X%4==0,
+// 16-byte aligned buffers, and frames that write all of their blocks or none).
+void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
+                                 const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
+                                 hipStream_t stream);
 // Stage-2 compare over the pixels no block covers (X&3 / Y&3 remainders), MSVideo1.hx:197-203.
 void msv1_launch_edge_compare(const Msv1Geometry& geo, const Msv1FrameArgs* d_frames, int nframes,
                               hipStream_t stream);

@@ -22,6 +22,7 @@ struct Msv1Staged : jsp_staged {
     struct Group {
         int first, count;
         bool edge_compare;
+        bool temporal;   // inter-frame group: one launch, frames walked in registers per spatial tile
     };
     std::vector<Group> groups;
     bool need_signif = false;  // some frame asked for the stage-2 compare
@@ -49,9 +50,14 @@ struct Msv1Staged : jsp_staged {
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
         for (const Group& g : groups) {
-            msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p),
-                               static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count,
-                               d_palette, vec_ok, stream);
+            if (g.temporal)
+                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
+                                            static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette,
+                                            stream);
+            else
+                msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p),
+                                   static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count,
+                                   d_palette, vec_ok, stream);
             if (g.edge_compare) msv1_launch_edge_compare(geo, frames + g.first, g.count, stream);
         }
         JSP_HIP(hipGetLastError());
@@ -252,8 +258,8 @@ struct Msv1Codec : jsp_codec {
 
         // ---- per-frame protocol decisions, in stream order ------------------------------------
         bool vec_ok = (X & 3) == 0;
-        std::unordered_set<const void*> group_dsts;
-        bool group_closed = true;  // true: the next frame must open a new launch group
+        struct Attr { bool dependent, noop, special, edge; };
+        std::vector<Attr> attr(nf, Attr{false, false, false, false});
         int last_gpu_frame = -1;
         bool pframes_dirty = false;
         for (int i = 0; i < nf; ++i) {
@@ -326,18 +332,11 @@ struct Msv1Codec : jsp_codec {
             st->info.units_copied += pr.n_skipped;
             st->info.stream_bytes += pr.consumed;
 
-            // launch grouping: frames that read nothing join the running group unless their dst
-            // is already written by it; a frame that reads its predecessor gets its own launch
-            const bool edge = fa.cmp_row_lo != 0xFFFFFFFFu && ((X & 3) || (Y & 3));
-            const bool writes = !pr.early_out;
-            if (dependent || group_closed || (writes && group_dsts.count(f.dst))) {
-                st->groups.push_back({i, 1, edge});
-                group_dsts.clear();
-                group_closed = dependent;  // nothing may share a launch with a frame that reads
-            } else {
-                st->groups.back().count++;
-            }
-            if (writes) group_dsts.insert(f.dst);
+            attr[i].dependent = dependent;
+            attr[i].noop = pr.early_out;
+            attr[i].special = pr.aborted || (pr.n_untouched > 0 && !pr.early_out);
+            attr[i].edge = fa.cmp_row_lo != 0xFFFFFFFFu && ((X & 3) || (Y & 3));
+            if (pr.early_out) fa.pad |= MSV1_FRAME_NOOP;
             if (st->adopted[i]) prev_dev = f.dst;
         }
         if (st->gpu_parse && last_gpu_frame >= 0 && block_changes_stale) {
@@ -345,6 +344,42 @@ struct Msv1Codec : jsp_codec {
             last_full_frame.assign(g.src, g.src + g.n);
         }
         st->vec_ok = vec_ok;
+        // ---- launch plan ---------------------------------------------------------------------
+        // "special" frames (abort, partially written) run alone with the per-frame kernel.  Between
+        // them: a run of frames none of which reads its predecessor is one launch with grid.y = frame;
+        // a run containing inter frames is one launch of the temporal kernel (tile per workgroup,
+        // frames walked in registers) when the buffers allow 16-byte rows, else one launch per frame.
+        {
+            int i = 0;
+            while (i < nf) {
+                if (attr[i].special) { st->groups.push_back({i, 1, attr[i].edge, false}); ++i; continue; }
+                int j = i;
+                bool any_dep = false;
+                while (j < nf && !attr[j].special) { any_dep |= attr[j].dependent; ++j; }
+                std::unordered_set<const void*> seen;
+                if (any_dep && vec_ok) {
+                    // every access to a tile, in whichever buffer, comes from the same workgroup in
+                    // program order, so buffers may even repeat inside the group
+                    bool edge = false;
+                    for (int k = i; k < j; ++k) edge |= attr[k].edge;
+                    st->groups.push_back({i, j - i, edge, true});
+                } else {
+                    bool closed = true;
+                    for (int k = i; k < j; ++k) {
+                        const bool writes = !attr[k].noop;
+                        if (attr[k].dependent || closed || (writes && seen.count(frames[k].dst))) {
+                            st->groups.push_back({k, 1, attr[k].edge, false});
+                            seen.clear();
+                            closed = attr[k].dependent;
+                        } else {
+                            st->groups.back().count++;
+                        }
+                        if (writes) seen.insert(frames[k].dst);
+                    }
+                }
+                i = j;
+            }
+        }
         st->need_signif = false;
         for (int v : st->significant) st->need_signif |= v < 0;
         st->info.frames = nf;

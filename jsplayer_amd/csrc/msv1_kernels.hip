@@ -222,6 +222,142 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
     }
 }
 
+// Inter-frame batches in ONE launch.  A block's pixels depend only on the same block of earlier
+// frames, so a workgroup takes a spatial tile of 256 blocks and walks the frames in order, keeping
+// the tile's current pixels in registers: a skipped block is a plain re-store of what the lane already
+// holds (no previous-frame read, no launch boundary between frames), the stage-2 compare is a register
+// compare.  Frames of the group must write all their blocks or none (no UNTOUCHED sentinels apart
+// from no-op frames) — msv1_codec.cpp forms the groups.
+template <int BITS>
+__global__ __launch_bounds__(WG) void msv1_blocks_temporal_kernel(
+    const uint8_t* __restrict__ stream, const uint32_t* __restrict__ desc,
+    const Msv1FrameArgs* __restrict__ frames, int nframes, const int32_t* __restrict__ palette, int nblocks,
+    int nbx, int X) {
+    constexpr int NW = WG / 64;
+    constexpr int MAXCODE = 18;
+    __shared__ __align__(16) uint8_t sbuf[WG * MAXCODE + 64];
+    __shared__ uint32_t s_wlo[NW], s_whi[NW];
+    __shared__ uint32_t s_pal[BITS == 8 ? 256 : 1];
+    if (BITS == 8) s_pal[threadIdx.x] = (uint32_t)palette[threadIdx.x];
+    const int blk = blockIdx.x * WG + threadIdx.x;
+    const bool live = blk < nblocks;
+    const int by = blk / nbx;
+    const int bx = blk - by * nbx;
+    const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
+    uint32_t px[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) px[i] = 0;
+    bool have = false;  // px holds the pixels of the latest written frame
+    uint32_t o_next = live ? desc[frames[0].desc_base + blk] : MSV1_DESC_UNTOUCHED;
+    for (int f = 0; f < nframes; ++f) {
+        const Msv1FrameArgs fa = frames[f];
+        const uint32_t o = o_next;
+        if (f + 1 < nframes) o_next = live ? desc[frames[f + 1].desc_base + blk] : MSV1_DESC_UNTOUCHED;
+        if (fa.pad & MSV1_FRAME_NOOP) continue;       // early-out frame: nothing is written
+        const bool coded = o < MSV1_DESC_UNTOUCHED;
+        // the first written frame of the group may need the frame before the group
+        if (!have && live && (fa.pad & MSV1_FRAME_USES_PREV)) {
+            const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev) + di;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const uint4 r = load_row(prev + (size_t)y * X);
+                px[y * 4] = r.x; px[y * 4 + 1] = r.y; px[y * 4 + 2] = r.z; px[y * 4 + 3] = r.w;
+            }
+        }
+        have = true;
+        {
+            const unsigned long long m = __ballot(coded);
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            if (m == 0ull) {
+                if (lane == 0) { s_wlo[wv] = 0xFFFFFFFFu; s_whi[wv] = 0u; }
+            } else {
+                if (lane == __ffsll((long long)m) - 1) s_wlo[wv] = o;
+                if (lane == 63 - __clzll((long long)m)) s_whi[wv] = o + MAXCODE;
+            }
+        }
+        __syncthreads();
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { lo = min(lo, s_wlo[k]); hi = max(hi, s_whi[k]); }
+        lo &= ~15u;
+        hi = hi < fa.stream_end ? hi : fa.stream_end;
+        for (uint32_t p = lo + threadIdx.x * 16u; p < hi; p += WG * 16u)
+            *reinterpret_cast<uint4*>(sbuf + (p - lo)) = *reinterpret_cast<const uint4*>(stream + p);
+        __syncthreads();
+        bool diff = false;
+        if (coded) {
+            const uint8_t* __restrict__ code = sbuf;
+            const uint32_t end = hi > lo ? hi - lo : 0u;
+            const uint32_t r = o - lo;
+            const bool b_ok = r + 1u < end;
+            const uint32_t w = b_ok ? (uint32_t) * reinterpret_cast<const uint16_t*>(code + r)
+                                    : (r < end ? (uint32_t)code[r] : 0u);
+            const uint32_t b = w >> 8;
+            uint32_t c[8];
+            uint32_t flags;
+            if (BITS == 16) {
+                if (b_ok && b < 0x80u) {
+                    flags = w ^ 0xFFFFu;
+                    const uint32_t q0 = ld16(code, r + 2u, end);
+                    const uint32_t q1 = ld16(code, r + 4u, end);
+                    c[0] = rgb555_to_rgb32(q0);
+                    c[1] = rgb555_to_rgb32(q1);
+                    if (q0 & 0x8000u) {
+#pragma unroll
+                        for (int k = 2; k < 8; ++k) c[k] = rgb555_to_rgb32(ld16(code, r + 2u + 2u * k, end));
+                    } else {
+                        c[2] = c[4] = c[6] = c[0];
+                        c[3] = c[5] = c[7] = c[1];
+                    }
+                } else {
+                    flags = 0;
+                    const uint32_t v = rgb555_to_rgb32(w);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) c[k] = v;
+                }
+            } else {
+                if (b_ok && b < 0x80u) {
+                    flags = w;
+                    const uint32_t i0 = (r + 2u < end) ? s_pal[code[r + 2u]] : 0u;
+                    const uint32_t i1 = (r + 3u < end) ? s_pal[code[r + 3u]] : 0u;
+                    c[0] = c[2] = c[4] = c[6] = i1;
+                    c[1] = c[3] = c[5] = c[7] = i0;
+                } else if (b_ok && b >= 0x90u) {
+                    flags = w ^ 0xFFFFu;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) c[k] = (r + 2u + k < end) ? s_pal[code[r + 2u + k]] : 0u;
+                } else {
+                    flags = 0;
+                    const uint32_t v = (r < end) ? s_pal[w & 0xFFu] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) c[k] = v;
+                }
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int q = ((y & 2) << 1) + (x & 2);
+                    const uint32_t v = ((flags >> (y * 4 + x)) & 1u) ? c[q + 1] : c[q];
+                    if (fa.cmp_row_lo != 0xFFFFFFFFu && (uint32_t)(by * 4 + y) >= fa.cmp_row_lo) diff |= v != px[y * 4 + x];
+                    px[y * 4 + x] = v;
+                }
+        }
+        if (o != MSV1_DESC_UNTOUCHED) {  // coded or skipped: the block is (re)written in this frame's buffer
+            uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst) + di;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) store_row(dst + (size_t)y * X, px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]);
+        }
+        if (fa.cmp_row_lo != 0xFFFFFFFFu) {
+            const unsigned long long dm = __ballot(diff);
+            if (dm != 0ull && (threadIdx.x & 63) == __ffsll((long long)dm) - 1 &&
+                __hip_atomic_load(fa.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                atomicOr(fa.signif, 1u);
+        }
+        // (the next iteration's first barrier comes after its ballot; sbuf is only rewritten after it)
+    }
+}
+
 // Pixels outside the block grid (x >= 4*nbx or y >= 4*nby) are never written by the decoder, but
 // the reference's compare loop still covers them (MSVideo1.hx:197-203).
 __global__ __launch_bounds__(WG) void msv1_edge_compare_kernel(const Msv1FrameArgs* __restrict__ frames,
@@ -275,6 +411,19 @@ void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const 
             hipLaunchKernelGGL((msv1_blocks_kernel<8, false>), grid, block, 0, stream, d_stream, d_desc,
                                d_frames, d_palette, geo.nblocks, geo.nbx, geo.X);
     }
+}
+
+void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
+                                 const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
+                                 hipStream_t stream) {
+    if (geo.nblocks <= 0 || nframes <= 0) return;
+    dim3 grid((geo.nblocks + WG - 1) / WG), block(WG);
+    if (geo.bits == 16)
+        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<16>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+                           d_palette, geo.nblocks, geo.nbx, geo.X);
+    else
+        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<8>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+                           d_palette, geo.nblocks, geo.nbx, geo.X);
 }
 
 void msv1_launch_edge_compare(const Msv1Geometry& geo, const Msv1FrameArgs* d_frames, int nframes,
