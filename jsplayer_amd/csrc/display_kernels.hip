@@ -91,8 +91,17 @@ int jsp_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, si
         *differ = 0;
         if (first_pixel >= npixels) return 0;
         hipStream_t s = static_cast<hipStream_t>(hip_stream);
-        uint32_t* d_flag = nullptr;
-        JSP_HIP(hipMalloc(reinterpret_cast<void**>(&d_flag), sizeof(uint32_t)));
+        // one result word per host thread and device, allocated once (the call is synchronous)
+        struct Scratch { int device = -1; uint32_t* word = nullptr; };
+        thread_local Scratch scratch;
+        int dev = 0;
+        JSP_HIP(hipGetDevice(&dev));
+        if (scratch.device != dev) {
+            scratch.word = nullptr;
+            JSP_HIP(hipMalloc(reinterpret_cast<void**>(&scratch.word), sizeof(uint32_t)));
+            scratch.device = dev;
+        }
+        uint32_t* d_flag = scratch.word;
         JSP_HIP(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), s));
         const size_t count = npixels - first_pixel;
         int grid = (int)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048);
@@ -101,7 +110,6 @@ int jsp_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, si
         uint32_t h = 0;
         JSP_HIP(hipMemcpyAsync(&h, d_flag, sizeof h, hipMemcpyDeviceToHost, s));
         JSP_HIP(hipStreamSynchronize(s));
-        (void)hipFree(d_flag);
         *differ = h ? 1 : 0;
         return 0;
     } catch (const std::exception& e) {

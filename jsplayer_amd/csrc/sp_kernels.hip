@@ -10,6 +10,7 @@
 //   256 contiguous bytes per row), lane = 16-byte chunk of a row: unchanged / base copy / motion
 //   from the previous frame in HBM, literal payload for data rectangles (ScreenPressor.hx:361-475).
 #include <cstdlib>
+#include <mutex>
 
 #include "sp.h"
 
@@ -403,8 +404,8 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hi
     const int cap = iframe_run_cap(g);
     // frame buffers handed to the fast path must be 16-byte aligned (checked by the caller: the
     // codec routes misaligned buffers to the search kernel through g.X & 3 semantics is not enough)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_search_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512, 4>),
@@ -417,8 +418,7 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hi
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     if (iframe_fast(g) && g.aligned16) {
         // One frame = one workgroup.  4 pixels per lane (8 waves per 1080p frame) wins both with 64
         // frames in flight (0.96 vs 1.37 ms) and with 512 (1.43 vs 1.70 ms): the waves hide each
