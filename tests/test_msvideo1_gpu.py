@@ -264,3 +264,10 @@ def test_fuzz_many_random_streams(bits):
         total += len(srcs)
         drive_pair(bits, w, h, srcs, ks, pal, lines=int(rng.integers(0, 12)))
     assert total > 1400
+
+
+@pytest.mark.parametrize("size", [(3, 3), (2, 9), (7, 4), (3840, 2160)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_degenerate_and_4k_sizes(size):
+    w, h = size
+    frames, keys, pal = sg.msv1_clip(90, w, h, 3, p_mix=sg.msv1_p_mix(0.5, 30.0))
+    drive_pair(16, w, h, frames, keys, pal)

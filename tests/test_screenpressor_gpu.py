@@ -173,3 +173,12 @@ def test_garbage_streams_never_fault(head):
     dst2 = next(b for b in bufs if b is not gpu.PreviousFrame())
     res = gpu.DecompressP(good[1], dst2)
     assert res.data_pnt is dst2 and np.array_equal(to_np(dst2).view(np.uint32), frames[1])
+
+
+@pytest.mark.parametrize("size", [(2052, 40), (4096, 36), (4104, 33), (5000, 20)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_wide_frames_use_the_other_kernel_instantiations(size):
+    """Widths beyond 2048 / 4096 pixels select the 1024-lane and the 8-pixels-per-lane instantiations
+    of the row kernel (and 5000 is not a multiple of 16: partial blocks on the right edge)."""
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(980, w, h, 4, version=4, rects=30, gradients=8)
+    drive_pair(w, h, 24, chunks, keys, frames)
