@@ -201,13 +201,14 @@ struct Msv1Codec : jsp_codec {
             const size_t padded = (frames[i].n + 15) & ~size_t(15);
             std::memset(h_stream + beg[i] + frames[i].n, 0, padded - frames[i].n);
         }
+        // uploads are queued on the codec's stream and waited for once, where the host needs them
         double h2d_ms = 0;
-        auto timed_upload = [&](void* d, const void* h, size_t bytes) {
-            if (!bytes) return;
-            const double t = now_ms();
-            JSP_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+        auto upload = [&](void* d, const void* h, size_t bytes) {
+            if (bytes) JSP_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+        };
+        auto wait_uploads = [&](double since) {
             JSP_HIP(hipStreamSynchronize(stream));
-            h2d_ms += now_ms() - t;
+            h2d_ms += now_ms() - since;
         };
 
         // ---- on-GPU parse: upload the raw bytes, parse, read the per-frame counters back --------
@@ -244,15 +245,15 @@ struct Msv1Codec : jsp_codec {
             st->d_tile_block0.reserve(sizeof(uint32_t) * std::max(ntiles, 1));
             st->d_info.reserve(sizeof(Msv1FrameInfo) * nf);
             st->h_info.reserve(sizeof(Msv1FrameInfo) * nf);
-            timed_upload(st->d_stream.p, h_stream, total_stream);
-            timed_upload(st->d_pframes.p, h_pf, sizeof(Msv1ParseFrame) * nf);
-            timed_upload(st->d_tile_frame.p, h_tf, sizeof(uint32_t) * ntiles);
-            const double tp = now_ms();
+            const double tu = now_ms();
+            upload(st->d_stream.p, h_stream, total_stream);
+            upload(st->d_pframes.p, h_pf, sizeof(Msv1ParseFrame) * nf);
+            upload(st->d_tile_frame.p, h_tf, sizeof(uint32_t) * ntiles);
             st->launch_parse(stream);
             JSP_HIP(hipGetLastError());
             JSP_HIP(hipMemcpyAsync(st->h_info.p, st->d_info.p, sizeof(Msv1FrameInfo) * nf, hipMemcpyDeviceToHost, stream));
-            JSP_HIP(hipStreamSynchronize(stream));
-            gpu_parse_ms = now_ms() - tp;
+            JSP_HIP(hipStreamSynchronize(stream));   // the one wait of the staging pass: counters are needed now
+            gpu_parse_ms = now_ms() - tu;             // uploads + parse, not separable without more waits
             h_info = static_cast<const Msv1FrameInfo*>(st->h_info.p);
         }
 
@@ -293,7 +294,7 @@ struct Msv1Codec : jsp_codec {
                 if (st->gpu_parse) {  // this frame's table comes from the host from now on
                     h_pf[i].host_parsed = 1;
                     pframes_dirty = true;
-                    timed_upload(static_cast<uint32_t*>(st->d_desc.p) + (size_t)i * nblk, desc, sizeof(uint32_t) * geo.nblocks);
+                    upload(static_cast<uint32_t*>(st->d_desc.p) + (size_t)i * nblk, desc, sizeof(uint32_t) * geo.nblocks);
                 }
             }
             Msv1FrameArgs& fa = h_frames[i];
@@ -389,16 +390,20 @@ struct Msv1Codec : jsp_codec {
         st->info.algorithmic_bytes = st->info.stream_bytes + 64 * st->info.units_coded + 128 * st->info.units_copied;
         // with the on-GPU parse every replay also runs tiles + chain + emit
         st->info.kernel_launches = st->groups.size() + (st->gpu_parse ? 3 : 0);
-        st->info.host_stage_ms = now_ms() - t0 - h2d_ms - gpu_parse_ms;
+        st->info.host_stage_ms = now_ms() - t0 - gpu_parse_ms;
 
         if (nf) {
+            // queued behind whatever is on the stream; jsp_staged_decode queues behind them in turn.
+            // (The pinned staging buffers belong to the staged batch and outlive the copies.)
+            const double tu = now_ms();
             if (!st->gpu_parse) {
-                timed_upload(st->d_stream.p, h_stream, total_stream);
-                timed_upload(st->d_desc.p, h_desc, sizeof(uint32_t) * nblk * nf);
+                upload(st->d_stream.p, h_stream, total_stream);
+                upload(st->d_desc.p, h_desc, sizeof(uint32_t) * nblk * nf);
             } else if (pframes_dirty) {
-                timed_upload(st->d_pframes.p, h_pf, sizeof(Msv1ParseFrame) * nf);
+                upload(st->d_pframes.p, h_pf, sizeof(Msv1ParseFrame) * nf);
             }
-            timed_upload(st->d_frames.p, h_frames, sizeof(Msv1FrameArgs) * nf);
+            upload(st->d_frames.p, h_frames, sizeof(Msv1FrameArgs) * nf);
+            if (nf > 1) wait_uploads(tu);   // batches: report the upload time; single frames skip the wait
         }
         st->info.h2d_ms = h2d_ms;
         st->info.device_parse_ms = gpu_parse_ms;
