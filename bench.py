@@ -155,15 +155,16 @@ def main():
 
     for _ in range(args.warmup):
         staged.decode()
-    barrier()
+    barrier()                                 # all ranks ready, device idle
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
         staged.decode()
     ev1.record(stream)
-    barrier()
+    torch.cuda.synchronize()                  # this rank's K steps are done
     elapsed = time.perf_counter() - t0
+    barrier()                                 # closing bracket; the job's time is the max over ranks (below)
     gpu_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
     status, adopted, _ = staged.results()
     assert all(s == 0 for s in status)
