@@ -3,6 +3,7 @@
 // descriptor tables it emits can be checked on a machine without a GPU.  Not part of the product
 // and not linked into libjsplayer_amd.so.
 #include <cstring>
+#include "../../jsplayer_amd/csrc/msv1.h"
 #include "../../jsplayer_amd/csrc/sp.h"
 
 using namespace jsp::sp;
@@ -29,9 +30,27 @@ int hs_decode(void* p, int key, const uint8_t* src, size_t n, uint64_t* meta) {
 }
 void hs_fetch(void* p, uint32_t* runs /*2 per run*/, uint32_t* rows, uint8_t* blocks /*16 B each*/, uint32_t* payload) {
     const FrameOut& o = ((Shim*)p)->out;
-    if (runs) std::memcpy(runs, o.runs.data(), o.runs.size() * sizeof(IRun));
-    if (rows) std::memcpy(rows, o.row_run.data(), o.row_run.size() * 4);
-    if (blocks) std::memcpy(blocks, o.blocks.data(), o.blocks.size() * sizeof(PBlock));
-    if (payload) std::memcpy(payload, o.payload.data(), o.payload.size() * 4);
+    if (runs && !o.runs.empty()) std::memcpy(runs, o.runs.data(), o.runs.size() * sizeof(IRun));
+    if (rows && !o.row_run.empty()) std::memcpy(rows, o.row_run.data(), o.row_run.size() * 4);
+    if (blocks && !o.blocks.empty()) std::memcpy(blocks, o.blocks.data(), o.blocks.size() * sizeof(PBlock));
+    if (payload && !o.payload.empty()) std::memcpy(payload, o.payload.data(), o.payload.size() * 4);
+}
+
+// MSVideo1 host parser (msv1_host.cpp): descriptors + the facts it settles without pixels.
+// out: [early_out, changes, s1, aborted, n_coded, n_skipped, n_untouched, consumed]
+void hs_msv1_parse(int bits, int w, int h, const uint8_t* src, size_t n, int have_prev, int lines, uint32_t* desc,
+                   uint8_t* block_changes, uint64_t* out) {
+    jsp::Msv1Geometry g{bits, w, h, w >> 2, h >> 2, (w >> 2) * (h >> 2)};
+    std::vector<uint8_t> bc(block_changes, block_changes + (g.nby > 0 ? g.nby : 0));
+    jsp::Msv1Parse pr;
+    const size_t sjs = (size_t)(g.nblocks / 1023) * 2 + 10;
+    jsp::msv1_parse(g, src, n, have_prev != 0, sjs, (lines + 3) >> 2, 0, desc, bc, pr);
+    if (!bc.empty()) std::memcpy(block_changes, bc.data(), bc.size());
+    out[0] = pr.early_out; out[1] = pr.changes; out[2] = pr.s1; out[3] = pr.aborted;
+    out[4] = pr.n_coded; out[5] = pr.n_skipped; out[6] = pr.n_untouched; out[7] = pr.consumed;
+}
+int hs_msv1_is_key(int bits, int w, int h, const uint8_t* src, size_t n) {
+    jsp::Msv1Geometry g{bits, w, h, w >> 2, h >> 2, (w >> 2) * (h >> 2)};
+    return jsp::msv1_is_key_frame(g, src, n);
 }
 }

@@ -146,3 +146,50 @@ def test_8bit_significance_quirk():
     o2.Preinit(4)
     data, signif = o2.DecompressP(frames[0], bufs[0])
     assert signif is True
+
+
+def test_product_host_parser_agrees_with_oracle_on_cpu():
+    """msv1_host.cpp (the product's sequential parser) through the test shim: IsKeyFrame, the
+    no-pixel facts (early-out, changes, abort) and the block counts against the oracle, on valid,
+    truncated and random streams.  (Pixels are compared on the GPU.)"""
+    import ctypes as C
+    import hoststage_binding as hs
+    L = hs.lib()
+    L.hs_msv1_parse.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hs_msv1_is_key.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(21)
+    checked = 0
+    for bits in (16, 8):
+        for (w, h) in [(16, 8), (37, 23), (64, 48)]:
+            frames, keys, pal = sg.msv1_clip(8200 + bits, w, h, 4, bits=bits, p_mix=sg.msv1_p_mix(0.5, 5.0))
+            nblocks, nby = (w >> 2) * (h >> 2), h >> 2
+            orc = OracleMSVideo1(bits, w, h, pal)
+            orc.Preinit(4)
+            bufs = [np.zeros(w * h, np.int32) for _ in range(3)]
+            bc = np.zeros(max(nby, 1), np.uint8)
+            for k in range(150):
+                b = bytearray(frames[k % 4])
+                if k % 3 == 1 and b:
+                    b = b[: int(rng.integers(0, len(b)))]
+                if k % 3 == 2:
+                    b = bytearray(rng.integers(0, 256, size=int(rng.integers(0, 80)), dtype=np.uint8).tobytes())
+                src = bytes(b)
+                assert bool(L.hs_msv1_is_key(bits, w, h, src, len(src))) == orc.IsKeyFrame(src)
+                have_prev = orc.PreviousFrame() is not None
+                desc = np.zeros(max(nblocks, 1), np.uint32)
+                out = np.zeros(8, np.uint64)
+                L.hs_msv1_parse(bits, w, h, src, len(src), int(have_prev), 4, desc.ctypes.data, bc.ctypes.data, out.ctypes.data)
+                early, changes, s1, aborted = (bool(v) for v in out[:4])
+                dst = next(x for x in bufs if x is not orc.PreviousFrame())
+                try:
+                    data, sig = orc.DecompressP(src, dst)
+                    assert not aborted
+                    assert (data is dst) == changes
+                    if not early:
+                        assert int(out[4] + out[5] + out[6]) == nblocks
+                    if not have_prev:
+                        assert sig == s1      # without a previous frame stage 1 decides alone
+                except OracleAbort:
+                    assert aborted
+                checked += 1
+    assert checked == 900
