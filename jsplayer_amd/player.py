@@ -77,10 +77,12 @@ class Manager:
             self.holds[oldest] = None
         return oldest
 
-    def worker(self, frame: bytes, index: int, prev_key_bytes: Optional[bytes]) -> DecodedFrame:
-        """One decode tick for compressed frame `index` (Manager.hx:454-539)."""
+    def worker(self, frame: bytes, index: int, prev_key_bytes: Optional[bytes], key: Optional[bool] = None) -> DecodedFrame:
+        """One decode tick for compressed frame `index` (Manager.hx:454-539).  `key` = the flag the loader
+        attached to the frame (an AVI index's, DataLoader.hx:373-401); None = scan the bytes."""
         dec = self.decoder
-        key = index == 0 or dec.IsKeyFrame(frame)          # DataLoaderAVISeq.hx:45
+        if key is None:
+            key = index == 0 or dec.IsKeyFrame(frame)      # DataLoaderAVISeq.hx:45
         prev = dec.PreviousFrame()
         prev_idx = self._slot_of(prev) if prev is not None else -1
         self.frame_of_interest = index                       # sequential playback keeps up with decode
@@ -117,11 +119,12 @@ class Manager:
         self.next_frame_to_decode = index + 1
         return out
 
-    def play(self, frames: Sequence[bytes], on_frame: Optional[Callable[[DecodedFrame, object], None]] = None):
+    def play(self, frames: Sequence[bytes], on_frame: Optional[Callable[[DecodedFrame, object], None]] = None,
+             key_flags: Optional[Sequence[bool]] = None):
         prev_key = None
         for i, f in enumerate(frames):
-            was_key = i == 0 or self.decoder.IsKeyFrame(f)
-            d = self.worker(f, i, prev_key if was_key and i > 0 and self._last_was_key else None)
+            was_key = bool(key_flags[i]) if key_flags is not None else (i == 0 or self.decoder.IsKeyFrame(f))
+            d = self.worker(f, i, prev_key if was_key and i > 0 and self._last_was_key else None, was_key)
             self._last_was_key = was_key
             prev_key = f if was_key else prev_key
             if on_frame:

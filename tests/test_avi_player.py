@@ -130,3 +130,49 @@ def test_display_convert_and_frames_differ_kernels():
         b[w * h - 1] -= 1
         b[5] += 1
         assert cm.frames_differ(t, b, 6, w * h) is False and cm.frames_differ(t, b, 5, w * h) is True
+
+
+@pytest.mark.parametrize("per_ix", [0, 7, 1000])
+def test_index_key_flags_and_random_access(per_ix):
+    """idx1 (per_ix=0) and OpenDML indx/ix00: offsets, sizes (odd ones keep their pad byte), key flags and an
+    empty frame come back through the index exactly as written; the sequential walk sees the same blobs."""
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in (10, 33, 0, 64, 7, 7, 128, 1, 90, 2, 31)]
+    keys = [True, False, False, True, False, False, False, True, False, False, False]
+    blob = avi.write_avi(64, 48, frames, fourcc=b"SCPR", bpp=24, key_flags=keys, opendml_frames_per_ix=per_ix)
+    index = avi.read_index(blob)
+    assert [e.key for e in index] == keys and [e.size for e in index] == [len(f) for f in frames]
+    for e, f in zip(index, frames):
+        assert blob[e.offset:e.offset + 4] == b"00dc" and blob[e.offset + 8:e.offset + 8 + len(f)] == f
+    vi, got, got_keys = avi.read_avi_indexed(blob)
+    assert got_keys == keys and vi.nframes == len(frames)
+    assert got == [f + (b"\0" if len(f) & 1 else b"") for f in frames]
+    assert avi.read_avi(blob)[1] == got                    # ix00 chunks inside movi are not frames
+
+
+def test_no_index_falls_back_to_sequential_walk():
+    frames = [b"\x01\x02", b"\x03\x04\x05\x06"]
+    blob = avi.write_avi(16, 8, frames)
+    cut = blob[:blob.index(b"idx1")]
+    cut = cut[:4] + (len(cut) - 8).to_bytes(4, "little") + cut[8:]
+    assert avi.read_index(cut) is None
+    _, got, keys = avi.read_avi_indexed(cut)
+    assert got == frames and keys == [True, False]
+
+
+def test_indexed_playback_matches_sequential_playback():
+    """The same ScreenPressor clip played from the OpenDML index (key flags from the index) and from the
+    sequential walk (key flags from IsKeyFrame) shows the same pictures, frame for frame."""
+    chunks, keys, frames = sg.sp_clip(6, 64, 48, 9, version=3, unchanged_at=(2,), key_every=4)
+    blob = avi.write_avi(64, 48, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys, opendml_frames_per_ix=4)
+    vi, got, idx_keys = avi.read_avi_indexed(blob)
+    assert idx_keys == [bool(k) for k in keys]
+    shown = []
+    for flags in (idx_keys, None):
+        mgr = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
+        pics = []
+        mgr.play(got, on_frame=lambda d, buf: pics.append(buf.copy()), key_flags=flags)
+        shown.append(pics)
+    assert len(shown[0]) == 9
+    for a, b, f in zip(shown[0], shown[1], frames):
+        assert np.array_equal(a, b) and np.array_equal(a.view(np.uint32), f)
