@@ -108,7 +108,10 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *   "msv1_parse" = "host" (default) | "gpu" : MSVideo1 only.  "gpu" builds the per-block descriptor
  *       table with the on-GPU parse kernels (raw frame bytes are all the device needs; a replay of a
  *       staged batch re-runs the parse); frames the parse flags as special fall back to the host
- *       parser one by one, so results are identical either way. */
+ *       parser one by one, so results are identical either way.
+ *   "sp_band_rows" = "auto" (default) | "0" | "<n>" : ScreenPressor only.  Key frames are rebuilt by one
+ *       workgroup per band of n rows (0 = the whole frame is one band; auto = sized so a batch fills
+ *       the GPU); the host stage hands each band the row above it.  Results do not depend on it. */
 int jsp_set_option(jsp_codec* c, const char* key, const char* value);
 /* Block until everything queued by this codec has finished. */
 int jsp_sync(jsp_codec* c);

@@ -4,7 +4,10 @@
 // so the host stage keeps a shadow of the current and previous frame while it decodes symbols;
 // what it hands to the GPU is a compact description from which the frame is materialised in HBM:
 //   I-frame  : run table (8 B per run) + one row index per image row; the kernel expands the runs
-//              row by row, resolving "copy from the row above" predictors through LDS;
+//              row by row, resolving "copy from the row above" predictors through LDS.  The frame is
+//              cut into horizontal bands, one workgroup each; the host stage — which holds every
+//              reconstructed pixel anyway — supplies the row above each band ("seed"), so bands do
+//              not wait for each other;
 //   P-frame  : one 16-byte record per 16x16 block (unchanged / motion / sub-rectangle / data) and
 //              literal pixels for the data rectangles only; the kernel copies, motion-compensates
 //              and patches against the previous frame in HBM.
@@ -62,6 +65,8 @@ struct FrameOut {
     uint32_t flat_colour = 0;
     std::vector<IRun> runs;          // Intra (with a sentinel run at start = X*Y)
     std::vector<uint32_t> row_run;   // Intra: Y+1 entries, index of the run holding pixel y*X
+    std::vector<uint32_t> seeds;     // Intra: per band after the first, seed_stride(X) words (see IFrameArgs)
+    int band_rows = 0;               // Intra: rows per band the seeds were cut for
     std::vector<PBlock> blocks;      // Inter
     std::vector<uint32_t> payload;   // Inter: literal pixels of the data rectangles
     uint64_t prev_pixels = 0;        // Inter: pixels fetched from the previous frame
@@ -82,6 +87,8 @@ public:
     void decode_p(const uint8_t* src, size_t n, FrameOut& out);
     const Geometry& geo() const { return g_; }
     bool has_prev() const { return has_prev_; }
+    // rows per band of the following key frames (0 = whole frame is one band, no seeds)
+    void set_band_rows(int rows) { band_rows_ = rows < 0 ? 0 : rows; }
 
 private:
     int32_t literal();
@@ -99,22 +106,32 @@ private:
     int insignificant_blocks_ = 0;
     std::vector<int32_t> bts_;
     int stall_ = 0;
+    int band_rows_ = 0;
 };
 
 // ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------
-struct IFrameArgs {    // one per frame of an intra launch (grid.x = frame)
+struct IFrameArgs {    // one per frame of an intra launch (grid.x = frame, grid.y = band)
     int32_t* dst;
     const IRun* runs;
     const uint32_t* row_run;
+    // band b >= 1 starts at row y0 = b * band_rows and finds at seeds + (b-1) * seed_stride(X):
+    // word 0 = pixel (X-1, y0-2) (what "above-left" of column 0 reads, linear index i-X-1), words 1..X = row y0-1
+    const uint32_t* seeds;
     uint32_t nruns;
     uint32_t flat;     // 1: fill with `colour`
     uint32_t colour;
     uint32_t pad;
 };
-void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hipStream_t stream);
+inline size_t seed_stride(int X) { return (size_t)X + 1; }
+inline int band_count(int Y, int band_rows) { return band_rows > 0 && band_rows < Y ? (Y + band_rows - 1) / band_rows : 1; }
+// Rows per band for a launch of `nframes` key frames: enough workgroups to fill the chip several
+// times over, but bands tall enough that the seed rows stay a few percent of the frame.
+int choose_band_rows(const Geometry& g, int nframes);
+// band_rows <= 0 or >= Y: one band per frame
+void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream);
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,
                    const uint32_t* d_payload, hipStream_t stream);
-size_t iframe_lds_bytes(const Geometry& g);
+size_t iframe_lds_bytes(const Geometry& g, int band_rows = 0);
 constexpr int kMaxIntraWidth = 8192;  // LDS plan of the row-wavefront kernel
 
 }  // namespace jsp::sp

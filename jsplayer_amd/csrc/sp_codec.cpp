@@ -1,6 +1,8 @@
 // ScreenPressor behind the IVideoCodec-shaped C ABI: host entropy stage (sp_host.cpp) + HIP
 // reconstruction (sp_kernels.hip).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <unordered_set>
 
 #include "codec.h"
@@ -15,17 +17,18 @@ struct SpStaged : jsp_staged {
     struct Op {
         enum Kind { Intra, Inter } kind;
         int first, count;      // Intra: range in the IFrameArgs array
+        int band_rows;         // Intra: rows per band (0 = one band)
         int32_t* dst;          // Inter
         const int32_t* prev;
         size_t block_off, payload_off;
     };
     std::vector<Op> ops;
-    DeviceBuffer d_runs, d_rows, d_iargs, d_blocks, d_payload;
+    DeviceBuffer d_runs, d_rows, d_seeds, d_iargs, d_blocks, d_payload;
 
     void decode(hipStream_t stream) override {
         for (const Op& op : ops) {
             if (op.kind == Op::Intra)
-                launch_iframes(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, stream);
+                launch_iframes(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, op.band_rows, stream);
             else
                 launch_pframe(geo, op.dst, op.prev, static_cast<const PBlock*>(d_blocks.p) + op.block_off,
                               static_cast<const uint32_t*>(d_payload.p) + op.payload_off, stream);
@@ -48,6 +51,18 @@ struct SpCodec : jsp_codec {
     int is_key_frame(const uint8_t* src, size_t n) override { return HostDecoder::is_key_frame(src, n) ? 1 : 0; }
     int needs_index() override { return 0; }
     bool may_leave_pixels(const jsp_frame_in&) override { return false; }
+    int opt_band_rows = -1;   // -1: chosen per batch (choose_band_rows); 0: one band per frame; n: n rows per band
+    int set_option(const char* key, const char* value) override {
+        if (std::strcmp(key, "sp_band_rows") == 0) {
+            if (std::strcmp(value, "auto") == 0) { opt_band_rows = -1; return 0; }
+            char* end = nullptr;
+            const long v = std::strtol(value, &end, 10);
+            if (end == value || *end || v < 0 || v > 1 << 20) return -1;
+            opt_band_rows = (int)v;
+            return 0;
+        }
+        return -1;
+    }
 
     jsp_staged* stage(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse) override {
         activate();
@@ -69,9 +84,13 @@ struct SpCodec : jsp_codec {
         st->info = jsp_staged_info{};
 
         std::vector<IRun> runs;
-        std::vector<uint32_t> rows;
+        std::vector<uint32_t> rows, seeds;
         std::vector<IFrameArgs> iargs;
-        std::vector<size_t> iarg_run_off, iarg_row_off;
+        std::vector<size_t> iarg_run_off, iarg_row_off, iarg_seed_off;
+        int nkey = 0;
+        for (const auto& f : frames) nkey += f.key ? 1 : 0;
+        const int band_rows = opt_band_rows >= 0 ? opt_band_rows : choose_band_rows(g, nkey);   // one cut for the whole batch
+        host.set_band_rows(band_rows);
         std::vector<PBlock> blocks;
         std::vector<uint32_t> payload;
         std::unordered_set<const void*> group_dsts;
@@ -98,13 +117,15 @@ struct SpCodec : jsp_codec {
                     a.nruns = (uint32_t)fo.runs.size();
                     iarg_run_off.push_back(runs.size());
                     iarg_row_off.push_back(rows.size());
+                    iarg_seed_off.push_back(seeds.size());
                     runs.insert(runs.end(), fo.runs.begin(), fo.runs.end());
                     rows.insert(rows.end(), fo.row_run.begin(), fo.row_run.end());
+                    seeds.insert(seeds.end(), fo.seeds.begin(), fo.seeds.end());
                     const bool join = !st->ops.empty() && st->ops.back().kind == SpStaged::Op::Intra &&
                                       !group_dsts.count(f.dst);
                     if (join) st->ops.back().count++;
                     else {
-                        st->ops.push_back({SpStaged::Op::Intra, (int)iargs.size(), 1, nullptr, nullptr, 0, 0});
+                        st->ops.push_back({SpStaged::Op::Intra, (int)iargs.size(), 1, band_rows, nullptr, nullptr, 0, 0});
                         group_dsts.clear();
                     }
                     group_dsts.insert(f.dst);
@@ -116,7 +137,7 @@ struct SpCodec : jsp_codec {
                     break;
                 }
                 case FrameKind::Inter: {
-                    st->ops.push_back({SpStaged::Op::Inter, 0, 0, f.dst, prev_dev, blocks.size(), payload.size()});
+                    st->ops.push_back({SpStaged::Op::Inter, 0, 0, 0, f.dst, prev_dev, blocks.size(), payload.size()});
                     group_dsts.clear();
                     blocks.insert(blocks.end(), fo.blocks.begin(), fo.blocks.end());
                     payload.insert(payload.end(), fo.payload.begin(), fo.payload.end());
@@ -134,25 +155,28 @@ struct SpCodec : jsp_codec {
         st->info.frames = nf;
         st->info.pixels = (uint64_t)g.X * g.Y * nf;
         st->info.kernel_launches = st->ops.size();
-        st->info.descriptor_bytes = runs.size() * sizeof(IRun) + rows.size() * 4 + iargs.size() * sizeof(IFrameArgs) +
+        st->info.descriptor_bytes = runs.size() * sizeof(IRun) + rows.size() * 4 + seeds.size() * 4 + iargs.size() * sizeof(IFrameArgs) +
                                     blocks.size() * sizeof(PBlock) + payload.size() * 4;
         st->info.host_stage_ms = now_ms() - t0;
 
         const double t1 = now_ms();
         st->d_runs.reserve(std::max<size_t>(runs.size(), 1) * sizeof(IRun));
         st->d_rows.reserve(std::max<size_t>(rows.size(), 1) * 4);
+        st->d_seeds.reserve(std::max<size_t>(seeds.size(), 1) * 4);
         st->d_iargs.reserve(std::max<size_t>(iargs.size(), 1) * sizeof(IFrameArgs));
         st->d_blocks.reserve(std::max<size_t>(blocks.size(), 1) * sizeof(PBlock));
         st->d_payload.reserve(std::max<size_t>(payload.size(), 1) * 4 + 16);
         for (size_t k = 0; k < iargs.size(); ++k) {
             iargs[k].runs = static_cast<const IRun*>(st->d_runs.p) + iarg_run_off[k];
             iargs[k].row_run = static_cast<const uint32_t*>(st->d_rows.p) + iarg_row_off[k];
+            iargs[k].seeds = static_cast<const uint32_t*>(st->d_seeds.p) + iarg_seed_off[k];
         }
         auto up = [&](DeviceBuffer& d, const void* h, size_t bytes) {
             if (bytes) JSP_HIP(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream));
         };
         up(st->d_runs, runs.data(), runs.size() * sizeof(IRun));
         up(st->d_rows, rows.data(), rows.size() * 4);
+        up(st->d_seeds, seeds.data(), seeds.size() * 4);
         up(st->d_iargs, iargs.data(), iargs.size() * sizeof(IFrameArgs));
         up(st->d_blocks, blocks.data(), blocks.size() * sizeof(PBlock));
         up(st->d_payload, payload.data(), payload.size() * 4);

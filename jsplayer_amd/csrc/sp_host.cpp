@@ -181,6 +181,13 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             while (r + 1 < runs.size() && runs[r + 1].start <= first) ++r;
             out.row_run[y] = (uint32_t)r;
         }
+        if (band_rows_ > 0 && band_rows_ < g_.Y) {  // the row above every band after the first, from the shadow
+            out.band_rows = band_rows_;
+            for (long y0 = band_rows_; y0 < g_.Y; y0 += band_rows_) {
+                out.seeds.push_back(y0 >= 2 ? (uint32_t)dst[(y0 - 1) * X - 1] : 0u);
+                out.seeds.insert(out.seeds.end(), dst + (y0 - 1) * X, dst + y0 * X);
+            }
+        }
         out.kind = FrameKind::Intra;
         out.adopted = true;
         out.stream_bytes = ec_->consumed();

@@ -1,6 +1,7 @@
 // ScreenPressor reconstruction kernels for gfx950 (MI355X).  Integer work, HBM-bound, no MFMA.
 //
-// sp_iframe_rows_kernel — one workgroup per I-frame (grid.x = frame; many frames fill the chip).
+// sp_iframe_rows_kernel — one workgroup per band of an I-frame (grid.x = frame, grid.y = band; the row
+//   above a band comes from the host stage's seed rows, so bands are independent).
 //   The run table resolves every pixel to either a constant or "the pixel one row up (same column or
 //   one to the left), plus a per-run delta" (ScreenPressor.hx:242-273; the gradient predictor
 //   telescopes inside a run).  Rows are produced top of the buffer downwards; the previous row lives
@@ -47,14 +48,16 @@ __device__ __forceinline__ uint32_t add_bytes(uint32_t u, uint32_t d) {  // per 
 }
 
 __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
-                                                                    int run_cap) {
+                                                                    int run_cap, int band_rows) {
     extern __shared__ __align__(16) uint32_t lds[];
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
     const int tid = threadIdx.x;
-    const size_t npx = (size_t)X * Y;
+    const int yb = (int)blockIdx.y * band_rows;       // this workgroup's rows: [yb, ye)
+    if (yb >= Y) return;
+    const int ye = yb + band_rows < Y ? yb + band_rows : Y;
     if (fa.flat) {  // flat key frame: one colour (ScreenPressor.hx:132-155)
-        for (size_t i = tid; i < npx; i += IWG) store1_global(dst + i, fa.colour);
+        for (size_t i = (size_t)yb * X + tid; i < (size_t)ye * X; i += IWG) store1_global(dst + i, fa.colour);
         return;
     }
     // LDS plan: two row buffers, the whole row index, and a window of run records {start, word}
@@ -62,22 +65,32 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     const int rowcap = (X + 4 + 3) & ~3;
     uint32_t* rowbuf0 = lds;
     uint32_t* rowbuf1 = lds + rowcap;
-    uint32_t* rowidx = lds + 2 * rowcap;              // Y + 1 entries
-    uint32_t* lastpix = rowidx + ((Y + 1 + 3) & ~3);  // last pixel of each of the 4 most recent rows
+    uint32_t* rowidx_lds = lds + 2 * rowcap;          // ye - yb + 1 entries: rows yb .. ye
+    uint32_t* lastpix = rowidx_lds + ((ye - yb + 1 + 3) & ~3);  // last pixel of each of the 4 most recent rows
     uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records
-    for (int k = tid; k <= Y; k += IWG) rowidx[k] = load1_global(fa.row_run + k);
-    if (tid < 4) lastpix[tid] = 0;
+    const uint32_t* rowidx = rowidx_lds - yb;         // indexed by absolute row
+    for (int k = tid; k <= ye - yb; k += IWG) rowidx_lds[k] = load1_global(fa.row_run + yb + k);
+    if (yb > 0) {  // the row above the band and the two wrap pixels, from the host stage's seed
+        const uint32_t* sd = fa.seeds + (size_t)(blockIdx.y - 1) * ((size_t)X + 1);
+        uint32_t* upbuf = (yb & 1) ? rowbuf0 : rowbuf1;
+        for (int k = tid; k < X; k += IWG) upbuf[k] = load1_global(sd + 1 + k);
+        if (tid == 0) {
+            lastpix[yb & 3] = 0; lastpix[(yb + 1) & 3] = 0;
+            lastpix[(yb + 2) & 3] = load1_global(sd);        // (yb-2) & 3
+            lastpix[(yb + 3) & 3] = load1_global(sd + X);    // (yb-1) & 3
+        }
+    } else if (tid < 4) lastpix[tid] = 0;
     __syncthreads();
     const bool vec = (X & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
     int hint = 0;  // this lane's run index relative to the row start, carried from row to row:
                    // neighbouring rows of screen content are cut into runs almost identically
-    int y = 0;
-    while (y < Y) {
+    int y = yb;
+    while (y < ye) {
         // window: rows y .. y_end-1 whose runs rowidx[y] .. rowidx[y_end] fit in run_cap records
         // (a single row always fits: run_cap >= X + 2)
         const uint32_t w0 = rowidx[y];
         int y_end = y + 1;
-        while (y_end < Y && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
+        while (y_end < ye && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
         const int wn = (int)(rowidx[y_end] - w0) + 1;
         const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
         for (int k = tid; k < wn; k += IWG) win[k] = load2_global(gruns + k);
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
 // by VALU issue, so lanes take PPL = 8 pixels: half the waves, the per-lane overhead amortised.
 template <int WG, int PPL>
 __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
-                                                            int run_cap) {
+                                                            int run_cap, int band_rows) {
     static_assert(PPL == 4 || PPL == 8, "4 or 8 pixels per lane");
     constexpr int V = PPL / 4;                    // uint4 vectors per lane
     constexpr uint32_t WAVE_PX = 64 * PPL;        // pixels one wave covers
@@ -175,9 +188,11 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
     const int tid = threadIdx.x;
-    const size_t npx = (size_t)X * Y;
+    const int yb = (int)blockIdx.y * band_rows;       // this workgroup's rows: [yb, ye)
+    if (yb >= Y) return;
+    const int ye = yb + band_rows < Y ? yb + band_rows : Y;
     if (fa.flat) {
-        for (size_t i = (size_t)tid * 4; i < npx; i += (size_t)WG * 4)
+        for (size_t i = (size_t)yb * X + (size_t)tid * 4; i < (size_t)ye * X; i += (size_t)WG * 4)
             store4_global(dst + i, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
         return;
     }
@@ -186,12 +201,22 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
     uint32_t* rowbuf1 = lds + rowcap;
     uint32_t* head0 = lds + 2 * rowcap;
     uint32_t* head1 = lds + 3 * rowcap;
-    uint32_t* rowidx = lds + 4 * rowcap;              // Y + 1 entries
-    uint32_t* lastpix = rowidx + ((Y + 1 + 3) & ~3);
+    uint32_t* rowidx_lds = lds + 4 * rowcap;          // ye - yb + 1 entries: rows yb .. ye
+    uint32_t* lastpix = rowidx_lds + ((ye - yb + 1 + 3) & ~3);
     uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records {start, word}
-    for (int k = tid; k <= Y; k += WG) rowidx[k] = load1_global(fa.row_run + k);
+    const uint32_t* rowidx = rowidx_lds - yb;         // indexed by absolute row
+    for (int k = tid; k <= ye - yb; k += WG) rowidx_lds[k] = load1_global(fa.row_run + yb + k);
     for (int k = tid; k < 2 * rowcap; k += WG) head0[k] = 0;   // head0 and head1 are contiguous
-    if (tid < 4) lastpix[tid] = 0;
+    if (yb > 0) {  // the row above the band and the two wrap pixels, from the host stage's seed
+        const uint32_t* sd = fa.seeds + (size_t)(blockIdx.y - 1) * ((size_t)X + 1);
+        uint32_t* upbuf = (yb & 1) ? rowbuf0 : rowbuf1;
+        for (int k = tid; k < X; k += WG) upbuf[k] = load1_global(sd + 1 + k);
+        if (tid == 0) {
+            lastpix[yb & 3] = 0; lastpix[(yb + 1) & 3] = 0;
+            lastpix[(yb + 2) & 3] = load1_global(sd);        // (yb-2) & 3
+            lastpix[(yb + 3) & 3] = load1_global(sd + X);    // (yb-1) & 3
+        }
+    } else if (tid < 4) lastpix[tid] = 0;
     __syncthreads();
     const int x0 = tid * PPL;
     const int lane = tid & 63;
@@ -213,11 +238,11 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __
             put_heads(head, (uint32_t)r, rr[r].x, r + 1 < nr ? rr[r + 1].x : row0 + (uint32_t)X, row0);
     };
 
-    int y = 0;
-    while (y < Y) {
+    int y = yb;
+    while (y < ye) {
         const uint32_t w0 = rowidx[y];
         int y_end = y + 1;
-        while (y_end < Y && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
+        while (y_end < ye && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
         const int wn = (int)(rowidx[y_end] - w0) + 1;
         const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
         for (int k = tid; k < wn; k += WG) win[k] = load2_global(gruns + k);
@@ -378,32 +403,54 @@ __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ d
 }  // namespace
 
 namespace {
-// LDS words needed besides the run window: row buffers (+ head rows on the fast path), row index,
-// last-pixel ring
-size_t iframe_fixed_words(const Geometry& g, bool fast) {
+int rows_in_band(const Geometry& g, int band_rows) { return band_rows > 0 && band_rows < g.Y ? band_rows : g.Y; }
+// LDS words needed besides the run window: row buffers (+ head rows on the fast path), the band's
+// slice of the row index, last-pixel ring
+size_t iframe_fixed_words(const Geometry& g, bool fast, int band_rows) {
     const size_t rowcap = fast ? (((size_t)g.X + 8 + 7) & ~size_t(7)) : (((size_t)g.X + 4 + 3) & ~size_t(3));
-    return (fast ? 4 : 2) * rowcap + (((size_t)g.Y + 1 + 3) & ~size_t(3)) + 4;
+    return (fast ? 4 : 2) * rowcap + (((size_t)rows_in_band(g, band_rows) + 1 + 3) & ~size_t(3)) + 4;
 }
 bool iframe_fast(const Geometry& g) { return (g.X & 3) == 0 && g.X <= 8192; }
-// run records staged per window: what a 72 KiB budget leaves (two workgroups per CU), at least a row
-int iframe_run_cap(const Geometry& g) {
-    const size_t fixed = iframe_fixed_words(g, iframe_fast(g));
-    const size_t budget_words = (72 * 1024) / 4;
+size_t iframe_lds_budget() {  // bytes per workgroup the run window may grow into (JSP_SP_IFRAME_LDS_KB)
+    static const size_t kb = [] {
+        const char* e = getenv("JSP_SP_IFRAME_LDS_KB");
+        const long v = e ? atol(e) : 0;
+        return (size_t)(v >= 16 && v <= 160 ? v : 52);
+    }();
+    return kb * 1024;
+}
+// run records staged per window: what the budget leaves (three workgroups per CU), at least a row
+int iframe_run_cap(const Geometry& g, int band_rows) {
+    const size_t fixed = iframe_fixed_words(g, iframe_fast(g), band_rows);
+    const size_t budget_words = iframe_lds_budget() / 4;
     size_t cap = budget_words > fixed ? (budget_words - fixed) / 2 : 0;
     if (cap < (size_t)g.X + 2) cap = (size_t)g.X + 2;
     return (int)cap;
 }
 }  // namespace
-size_t iframe_lds_bytes(const Geometry& g) {
-    return sizeof(uint32_t) * (iframe_fixed_words(g, iframe_fast(g)) + 2 * (size_t)iframe_run_cap(g));
+size_t iframe_lds_bytes(const Geometry& g, int band_rows) {
+    return sizeof(uint32_t) * (iframe_fixed_words(g, iframe_fast(g), band_rows) + 2 * (size_t)iframe_run_cap(g, band_rows));
 }
 
-void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hipStream_t stream) {
+int choose_band_rows(const Geometry& g, int nframes) {
+    static const int forced = [] { const char* e = getenv("JSP_SP_IFRAME_BAND_ROWS"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    if (nframes <= 0) return 0;
+    // ~1500 workgroups per launch (256 CUs x 3 resident, twice over) when the batch allows it; bands of at
+    // least 24 rows keep the seed rows (one per band) near 4 % of the frame
+    const int want = (1536 + nframes - 1) / nframes;
+    int rows = (g.Y + want - 1) / (want > 0 ? want : 1);
+    if (rows < 24) rows = 24;
+    return rows >= g.Y ? 0 : rows;
+}
+
+void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream) {
     if (nframes <= 0) return;
-    const size_t lds = iframe_lds_bytes(g);
-    const int cap = iframe_run_cap(g);
-    // frame buffers handed to the fast path must be 16-byte aligned (checked by the caller: the
-    // codec routes misaligned buffers to the search kernel through g.X & 3 semantics is not enough)
+    if (band_rows <= 0 || band_rows >= g.Y) band_rows = g.Y;
+    const int bands = (g.Y + band_rows - 1) / band_rows;
+    const size_t lds = iframe_lds_bytes(g, band_rows);
+    const int cap = iframe_run_cap(g, band_rows);
+    const dim3 grid(nframes, bands);
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_search_kernel),
@@ -420,28 +467,27 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, hi
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (iframe_fast(g) && g.aligned16) {
-        // One frame = one workgroup.  4 pixels per lane (8 waves per 1080p frame) wins both with 64
-        // frames in flight (0.96 vs 1.37 ms) and with 512 (1.43 vs 1.70 ms): the waves hide each
-        // other's LDS round trips.  8 pixels per lane is kept for frames wider than 4096 pixels and
+        // 4 pixels per lane (8 waves per 1080p row) beat 8 pixels per lane both with 64 and with 512
+        // workgroups in flight: the waves hide each other's LDS round trips.  8 pixels per lane is kept for frames wider than 4096 pixels and
         // as a tuning knob (JSP_SP_IFRAME_PPL=8).
         static const char* force = getenv("JSP_SP_IFRAME_PPL");
         const bool wide = force && force[0] == '8';
         const bool can4 = g.X <= 4096;
         if (wide || !can4) {
             if (g.X <= 2048)
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<256, 8>), dim3(nframes), dim3(256), lds, stream, d_args, g.X, g.Y, cap);
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<256, 8>), grid, dim3(256), lds, stream, d_args, g.X, g.Y, cap, band_rows);
             else if (g.X <= 4096)
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 8>), dim3(nframes), dim3(512), lds, stream, d_args, g.X, g.Y, cap);
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 8>), grid, dim3(512), lds, stream, d_args, g.X, g.Y, cap, band_rows);
             else
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 8>), dim3(nframes), dim3(1024), lds, stream, d_args, g.X, g.Y, cap);
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 8>), grid, dim3(1024), lds, stream, d_args, g.X, g.Y, cap, band_rows);
         } else {
             if (g.X <= 2048)
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 4>), dim3(nframes), dim3(512), lds, stream, d_args, g.X, g.Y, cap);
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 4>), grid, dim3(512), lds, stream, d_args, g.X, g.Y, cap, band_rows);
             else
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 4>), dim3(nframes), dim3(1024), lds, stream, d_args, g.X, g.Y, cap);
+                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 4>), grid, dim3(1024), lds, stream, d_args, g.X, g.Y, cap, band_rows);
         }
     } else {
-        hipLaunchKernelGGL(sp_iframe_rows_search_kernel, dim3(nframes), dim3(IWG), lds, stream, d_args, g.X, g.Y, cap);
+        hipLaunchKernelGGL(sp_iframe_rows_search_kernel, grid, dim3(IWG), lds, stream, d_args, g.X, g.Y, cap, band_rows);
     }
 }
 

@@ -18,6 +18,12 @@ extern "C" {
 void* hs_create(int w, int h, int bpp) { return new Shim(w, h, bpp); }
 void hs_destroy(void* p) { delete (Shim*)p; }
 void hs_preinit(void* p, int lines) { ((Shim*)p)->host.preinit(lines); }
+void hs_set_band_rows(void* p, int rows) { ((Shim*)p)->host.set_band_rows(rows); }
+size_t hs_seed_words(void* p) { return ((Shim*)p)->out.seeds.size(); }
+void hs_fetch_seeds(void* p, uint32_t* seeds) {
+    const FrameOut& o = ((Shim*)p)->out;
+    if (seeds && !o.seeds.empty()) std::memcpy(seeds, o.seeds.data(), o.seeds.size() * 4);
+}
 // returns status; fills meta: [kind, adopted, significant, prev_cleared, nruns, nrows, nblocks, npayload, flat_colour]
 int hs_decode(void* p, int key, const uint8_t* src, size_t n, uint64_t* meta) {
     auto* s = (Shim*)p;

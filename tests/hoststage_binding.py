@@ -29,6 +29,10 @@ def lib():
         L.hs_preinit.argtypes = [C.c_void_p, C.c_int]
         L.hs_decode.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]
         L.hs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hs_set_band_rows.argtypes = [C.c_void_p, C.c_int]
+        L.hs_seed_words.restype = C.c_size_t
+        L.hs_seed_words.argtypes = [C.c_void_p]
+        L.hs_fetch_seeds.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -42,6 +46,10 @@ class HostStage:
     def preinit(self, lines):
         self.L.hs_preinit(self.h, lines)
 
+    def set_band_rows(self, rows):
+        self.band_rows = rows
+        self.L.hs_set_band_rows(self.h, rows)
+
     def decode(self, key: bool, src: bytes):
         meta = np.zeros(12, dtype=np.uint64)
         src = bytes(src)
@@ -54,7 +62,10 @@ class HostStage:
         blocks = np.zeros((m[6], 16), dtype=np.uint8)
         payload = np.zeros(m[7], dtype=np.uint32)
         self.L.hs_fetch(self.h, runs.ctypes.data, rows.ctypes.data, blocks.ctypes.data, payload.ctypes.data)
-        out.update(runs=runs, rows=rows, blocks=blocks, payload=payload)
+        seeds = np.zeros(self.L.hs_seed_words(self.h), dtype=np.uint32)
+        self.L.hs_fetch_seeds(self.h, seeds.ctypes.data)
+        out.update(runs=runs, rows=rows, blocks=blocks, payload=payload, seeds=seeds,
+                   band_rows=getattr(self, "band_rows", 0))
         return out
 
     def close(self):
@@ -72,13 +83,16 @@ def _add_bytes(u, d):
 
 
 def expand_iframe(desc, X, Y):
-    """What sp_iframe_rows_kernel computes from the run table (row wavefront)."""
+    """What sp_iframe_rows_kernel computes from the run table (row wavefront).  With band seeds every
+    band is expanded on its own, from nothing but its seed row — as its workgroup does."""
     if desc["kind"] == KIND_FLAT:
         return np.full(X * Y, desc["flat_colour"], dtype=np.uint32)
     runs, rows = desc["runs"], desc["rows"]
     starts, words = runs[:, 0].astype(np.int64), runs[:, 1]
     out = np.zeros((Y, X), dtype=np.uint32)
     xs = np.arange(X)
+    band_rows = desc.get("band_rows", 0) if len(desc.get("seeds", ())) else 0
+    seeds = desc.get("seeds")
     for y in range(Y):
         r0, r1 = int(rows[y]), int(rows[y + 1])
         idx = y * X + xs
@@ -87,10 +101,17 @@ def expand_iframe(desc, X, Y):
         kind, val = w >> 24, w & 0xFFFFFF
         v = val.copy()
         if y > 0:
-            up = out[y - 1]
+            band_first = band_rows > 0 and y % band_rows == 0
+            sd = seeds[(y // band_rows - 1) * (X + 1):(y // band_rows) * (X + 1)] if band_first else None
+            up = sd[1:] if band_first else out[y - 1]
             left = np.empty(X, dtype=np.uint32)
             left[1:] = up[:-1]
-            left[0] = out[y - 2, X - 1] if y >= 2 else 0
+            if band_first:
+                left[0] = sd[0]
+            elif band_rows > 0 and y % band_rows == 1 and y > 1:
+                left[0] = seeds[(y // band_rows - 1) * (X + 1) + X]      # last pixel of the seed row
+            else:
+                left[0] = out[y - 2, X - 1] if y >= 2 else 0
             v = np.where(kind == RUN_ABOVE, up, v)
             v = np.where(kind == RUN_ABOVE_PLUS, _add_bytes(up, val), v)
             v = np.where(kind == RUN_ABOVE_LEFT, left, v)

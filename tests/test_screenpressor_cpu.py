@@ -60,10 +60,12 @@ def test_is_key_frame_and_headers():
     assert o.DecompressI(bytes([0x11, 1, 2, 3]), dst) == 3
 
 
-def drive_host_stage(w, h, bpp, chunks, keys, frames, lines=36):
+def drive_host_stage(w, h, bpp, chunks, keys, frames, lines=36, band_rows=0):
     """Host stage -> descriptors -> numpy kernel emulation, against the oracle frame by frame."""
     host = hs.HostStage(w, h, bpp)
     host.preinit(lines)
+    if band_rows:
+        host.set_band_rows(band_rows)
     got, sigs = oracle_decode_clip(w, h, bpp, chunks, keys, lines)
     prev = None
     for i, (c, k) in enumerate(zip(chunks, keys)):
@@ -90,6 +92,27 @@ def test_host_stage_descriptors_match_oracle(version, size, bpp):
     chunks, keys, frames = sg.sp_clip(500 + version, w, h, 10, bpp=bpp, version=version, key_every=6,
                                       flat_at=(4,), unchanged_at=(2,))
     drive_host_stage(w, h, bpp, chunks, keys, frames, lines=4)
+
+
+@pytest.mark.parametrize("band_rows", [1, 2, 5, 8, 47, 48, 1000])
+def test_key_frame_bands_expand_from_their_seed_rows(band_rows):
+    """Key frames cut into bands: every band rebuilt from its seed row alone gives the oracle's picture;
+    the seed words are the rows above the bands (and the pixel column 0's above-left predictor wraps to)."""
+    w, h = 100, 48
+    chunks, keys, frames = sg.sp_clip(640, w, h, 4, version=4, key_every=2)
+    drive_host_stage(w, h, 24, chunks, keys, frames, lines=4, band_rows=band_rows)
+    host = hs.HostStage(w, h, 24)
+    host.preinit(4)
+    host.set_band_rows(band_rows)
+    d = host.decode(True, chunks[0])
+    nb = (h + band_rows - 1) // band_rows if band_rows < h else 1
+    assert d["seeds"].size == (nb - 1) * (w + 1)
+    pic = frames[0].reshape(h, w)
+    for b in range(1, nb):
+        sd = d["seeds"][(b - 1) * (w + 1):b * (w + 1)]
+        y0 = b * band_rows
+        assert np.array_equal(sd[1:], pic[y0 - 1])
+        assert sd[0] == (pic[y0 - 2, w - 1] if y0 >= 2 else 0)
 
 
 def test_host_stage_rejects_what_the_reference_cannot_survive():

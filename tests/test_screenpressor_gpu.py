@@ -20,10 +20,12 @@ def to_np(t):
     return t.cpu().numpy() if hasattr(t, "cpu") else t
 
 
-def drive_pair(w, h, bpp, chunks, keys, frames=None, lines=36, nbuf=3, host=False):
+def drive_pair(w, h, bpp, chunks, keys, frames=None, lines=36, nbuf=3, host=False, band_rows=None):
     orc, gpu = OracleScreenPressor(w, h, bpp), ScreenPressor(w, h, bpp)
     orc.Preinit(lines)
     gpu.Preinit(lines)
+    if band_rows is not None:
+        gpu.set_option("sp_band_rows", str(band_rows))
     obufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) for _ in range(nbuf)]
     gbufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) if host else dev_buf(w * h, 0x00A5A5A5) for _ in range(nbuf)]
     for i, (src, key) in enumerate(zip(chunks, keys)):
@@ -68,6 +70,38 @@ def test_clip_parity_device(version, size):
     chunks, keys, frames = sg.sp_clip(900 + version, w, h, n, version=version, key_every=7, flat_at=(5,),
                                       unchanged_at=(2,))
     drive_pair(w, h, 24, chunks, keys, frames)
+
+
+@pytest.mark.parametrize("band_rows", [0, 1, 3, 16, 25, "auto"])
+@pytest.mark.parametrize("size", [(64, 48), (100, 52), (37, 23), (320, 240), (2052, 40), (5000, 20)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+def test_key_frame_bands(size, band_rows):
+    """Key frames rebuilt band by band (one workgroup each, started from the host stage's seed rows) give
+    the same pictures whatever the band height: both row kernels, flat frames, frames after inter frames."""
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(990, w, h, 7, version=4, key_every=3, flat_at=(4,), rects=40, gradients=10)
+    drive_pair(w, h, 24, chunks, keys, frames, band_rows=band_rows)
+
+
+def test_key_frame_bands_1080p_batch():
+    """A batch of 1080p key frames in one launch, banded automatically and with an odd band height."""
+    w, h = 1920, 1080
+    chunks, keys, frames = sg.sp_clip(991, w, h, 3, version=4, key_every=1)
+    for rows in ("auto", "37"):
+        gpu = ScreenPressor(w, h, 24)
+        gpu.Preinit(36)
+        gpu.set_option("sp_band_rows", rows)
+        dsts = [dev_buf(w * h, -1) for _ in range(3)]
+        st = gpu.stage_batch(chunks, dsts, is_key=keys)
+        assert st.info()["kernel_launches"] == 1
+        st.decode()
+        gpu.sync()
+        for d, img in zip(dsts, frames):
+            assert np.array_equal(to_np(d).view(np.uint32), img)
+        st.close()
+        gpu.StopAndClean()
+    with pytest.raises(CodecError):
+        ScreenPressor(64, 48, 24).set_option("sp_band_rows", "minus one")
 
 
 @pytest.mark.parametrize("version", [2, 4])
