@@ -42,7 +42,8 @@ def main():
         "hbm_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024,
     }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name in (f"{tag}_traffic.json", "traffic_latest.json"):
+    # tag "scratch": print only (the caller redirects); otherwise also refresh what bench.py reads
+    for name in (() if tag == "scratch" else (f"{tag}_traffic.json", "traffic_latest.json")):
         json.dump(out, open(os.path.join(root, "profiles", name), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
