@@ -25,16 +25,16 @@ namespace jsp::sp {
 
 // ---- I-frame descriptors --------------------------------------------------------------------
 // kind: how the pixels of the run are produced
-enum RunKind : uint32_t {
-    RUN_CONST = 0,      // colour in the low 24 bits (literal runs, "repeat previous pixel" runs, flat)
-    RUN_ABOVE = 2,      // pixel i takes pixel i-X
-    RUN_ABOVE_LEFT = 5, // pixel i takes pixel i-X-1
-    RUN_ABOVE_PLUS = 4, // pixel i takes pixel i-X plus a per-run byte-wise delta (gradient predictor,
-                        // which telescopes inside a run: p[i]-p[i-X] = p[i0-1]-p[i0-1-X])
+enum RunKind : uint32_t {   // bit 0: the pixel starts from the row above; bit 1: ... from one column to the left of it
+    RUN_CONST = 0,       // colour in the low 24 bits (literal runs, "repeat previous pixel" runs)
+    RUN_ABOVE = 1,       // pixel i takes pixel i-X plus the byte-wise addend in the low 24 bits: 0 for the plain
+                         // "copy above" predictor, the per-run delta for the gradient predictor, which
+                         // telescopes inside a run: p[i]-p[i-X] = p[i0-1]-p[i0-1-X]
+    RUN_ABOVE_LEFT = 3,  // pixel i takes pixel i-X-1 (addend 0)
 };
 struct IRun {
     uint32_t start;  // linear pixel index of the first pixel
-    uint32_t word;   // low 24 bits: colour or delta; bits 24..26: RunKind
+    uint32_t word;   // low 24 bits: colour or addend; bits 24..25: RunKind; bits 26..31 zero
 };
 
 // ---- P-frame descriptors --------------------------------------------------------------------

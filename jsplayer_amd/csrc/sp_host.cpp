@@ -158,7 +158,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
                         const uint32_t a = (uint32_t)rd(di - 1), b = (uint32_t)rd(di - 1 - X);
                         const uint32_t d = (((a & 0xFF) - (b & 0xFF)) & 0xFF) | (((a & 0xFF00) - (b & 0xFF00)) & 0xFF00) |
                                            (((a & 0xFF0000) - (b & 0xFF0000)) & 0xFF0000);
-                        emit(di, cnt, RUN_ABOVE_PLUS, d);
+                        emit(di, cnt, RUN_ABOVE, d);
                         for (int c = 0; c < cnt; ++c, ++di) {
                             const uint32_t u = (uint32_t)rd(di - X);
                             clr = (int32_t)((((u & 0xFF) + (d & 0xFF)) & 0xFF) | (((u & 0xFF00) + (d & 0xFF00)) & 0xFF00) |

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(HERE, "hoststage", "libhoststage.so")
 _lib = None
 
-RUN_CONST, RUN_ABOVE, RUN_ABOVE_PLUS, RUN_ABOVE_LEFT = 0, 2, 4, 5
+RUN_CONST, RUN_ABOVE, RUN_ABOVE_LEFT = 0, 1, 3
 PB_SUBRECT, PB_MOTION, PB_DATA = 1, 2, 4
 KIND_NONE, KIND_FLAT, KIND_INTRA, KIND_INTER = 0, 1, 2, 3
 
@@ -112,8 +112,7 @@ def expand_iframe(desc, X, Y):
                 left[0] = seeds[(y // band_rows - 1) * (X + 1) + X]      # last pixel of the seed row
             else:
                 left[0] = out[y - 2, X - 1] if y >= 2 else 0
-            v = np.where(kind == RUN_ABOVE, up, v)
-            v = np.where(kind == RUN_ABOVE_PLUS, _add_bytes(up, val), v)
+            v = np.where(kind == RUN_ABOVE, _add_bytes(up, val), v)
             v = np.where(kind == RUN_ABOVE_LEFT, left, v)
         else:
             v = np.where(kind == RUN_CONST, v, 0)
