@@ -32,6 +32,7 @@ enum RunKind : uint32_t {   // bit 0: the pixel starts from the row above; bit 1
                          // telescopes inside a run: p[i]-p[i-X] = p[i0-1]-p[i0-1-X]
     RUN_ABOVE_LEFT = 3,  // pixel i takes pixel i-X-1 (addend 0)
 };
+constexpr long kRunSplit = 256;  // records never cross a multiple of this many columns (= one wave x 4 pixels)
 struct IRun {
     uint32_t start;  // linear pixel index of the first pixel
     uint32_t word;   // low 24 bits: colour or addend; bits 24..25: RunKind; bits 26..31 zero
@@ -63,8 +64,9 @@ struct FrameOut {
     bool prev_cleared = false; // the call ended with prevFrame == null (RenewI ran, decode failed)
     bool significant = false;
     uint32_t flat_colour = 0;
-    std::vector<IRun> runs;          // Intra (with a sentinel run at start = X*Y)
-    std::vector<uint32_t> row_run;   // Intra: Y+1 entries, index of the run holding pixel y*X
+    std::vector<IRun> runs;          // Intra: run pieces (see kRunSplit), with a sentinel at start = X*Y
+    uint64_t stream_runs = 0;        // Intra: runs the stream coded (what A = 8R + 4P counts)
+    std::vector<uint32_t> row_run;   // Intra: Y+1 entries, index of the record that starts at pixel y*X
     std::vector<uint32_t> seeds;     // Intra: per band after the first, seed_stride(X) words (see IFrameArgs)
     int band_rows = 0;               // Intra: rows per band the seeds were cut for
     std::vector<PBlock> blocks;      // Inter

@@ -130,7 +130,7 @@ struct SpCodec : jsp_codec {
                     }
                     group_dsts.insert(f.dst);
                     iargs.push_back(a);
-                    const uint64_t r = fo.runs.empty() ? 0 : fo.runs.size() - 1;
+                    const uint64_t r = fo.stream_runs;
                     st->info.runs += r;
                     st->info.units_coded += npx;
                     st->info.algorithmic_bytes += 8 * r + 4 * npx;  // A = 8R + 4P

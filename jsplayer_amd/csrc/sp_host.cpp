@@ -105,9 +105,22 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
         };
         auto& runs = out.runs;
         runs.clear();
+        // One record per piece of a run: runs are cut at row starts and at every kRunSplit-th column, so a
+        // row's records are exactly those that start inside it and none crosses the span of one wave of
+        // the row kernel (which then scatters each record with a single store, no clamping, no loop).
         auto emit = [&](long start, int cnt, uint32_t kind, uint32_t payload) {
             if (cnt <= 0 || start >= end) return;
-            runs.push_back({(uint32_t)start, (payload & 0xFFFFFFu) | (kind << 24)});
+            ++out.stream_runs;
+            const uint32_t word = (payload & 0xFFFFFFu) | (kind << 24);
+            const long stop = start + cnt < end ? start + cnt : end;
+            long col = start % X;
+            for (long i = start; i < stop;) {
+                runs.push_back({(uint32_t)i, word});
+                const long next_col = (col / kRunSplit + 1) * kRunSplit;
+                const long step = (next_col < X ? next_col : X) - col;
+                i += step;
+                col = next_col < X ? next_col : 0;
+            }
         };
         auto rd = [&](long i) -> int32_t { return (i >= 0 && i < end) ? dst[i] : 0; };
         auto fill = [&](long at, int cnt, int32_t v) {

@@ -402,23 +402,23 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_reg_kernel(const IFrameArgs
         }
         // what wave w (w >= 1) reads as "left of my first pixel" in row yb: pixel (w*WAVE_PX - 1, yb - 1)
         if (tid >= 1 && tid < NW && tid * (int)WAVE_PX < X) edge[((yb + 1) & 1) * EDGE_W + tid] = load1_global(sd + tid * WAVE_PX);
+        // The seed pixels must have landed before the row loop: a vmcnt wait on their first use INSIDE the
+        // loop would also wait, every row, for the previous row's frame store (loads and stores share vmcnt).
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
     }
     __syncthreads();
 
-    auto put_heads = [&](uint32_t* head, uint32_t word, uint32_t s, uint32_t e, uint32_t row0) {
-        const uint32_t col = s <= row0 ? 0u : s - row0;
-        if (col >= (uint32_t)X) return;              // the run that opens the next row
-        head[col] = word | HEAD_PRESENT;
-        const uint32_t ecol = e - row0 < (uint32_t)X ? e - row0 : (uint32_t)X;
-        for (uint32_t p = (col / WAVE_PX + 1u) * WAVE_PX; p < ecol; p += WAVE_PX) head[p] = word | HEAD_PRESENT;
-    };
-    auto scatter_all = [&](int yy, uint32_t w0, uint32_t* head, int first) {
+    // The host stage cuts runs at row starts and at every 256th column (sp.h kRunSplit), so the records of
+    // row yy are exactly rowidx[yy] .. rowidx[yy+1]-1, each starts inside the row, and none crosses a wave's
+    // span: scattering a record is one store.
+    static_assert(WAVE_PX % kRunSplit == 0, "a wave's span must be a whole number of run pieces");
+    auto scatter_from = [&](int yy, uint32_t w0, uint32_t* head, int first) {
         const uint2* rr = win + (int)(rowidx[yy] - w0);
-        const int nr = (int)(rowidx[yy + 1] - rowidx[yy]) + 1;
+        const int nr = (int)(rowidx[yy + 1] - rowidx[yy]);
         const uint32_t row0 = (uint32_t)((size_t)yy * X);
         for (int r = first; r < nr; r += WG) {
             const uint2 rec = rr[r];
-            put_heads(head, rec.y, rec.x, r + 1 < nr ? rr[r + 1].x : row0 + (uint32_t)X, row0);
+            head[rec.x - row0] = rec.y | HEAD_PRESENT;
         }
     };
 
@@ -431,15 +431,16 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_reg_kernel(const IFrameArgs
         const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
         for (int k = tid; k < wn; k += WG) win[k] = load2_global(gruns + k);
         __syncthreads();  // run records arrive through vmcnt: full barrier once per window
-        scatter_all(y, w0, (y & 1) ? head1 : head0, tid);
+        scatter_from(y, w0, (y & 1) ? head1 : head0, tid);
         lds_barrier();
-        uint32_t ri1 = rowidx[y + 1];                         // rolling copy of the row index
+        // rolling copies of the row index, read one row ahead so the LDS latency is off the row's critical path
+        uint32_t ri1 = rowidx[y + 1], ri2 = y + 1 < y_end ? rowidx[y + 2] : ri1;
         for (; y < y_end; ++y) {
             uint32_t* head = (y & 1) ? head1 : head0;
             uint32_t* head_next = (y & 1) ? head0 : head1;
             const bool more = y + 1 < y_end;
             // ---- loads of this row that do not depend on each other, issued together --------------
-            const uint32_t ri2 = more ? rowidx[y + 2] : ri1;
+            const uint32_t ri3 = y + 2 < y_end ? rowidx[y + 3] : ri2;
             // left of this wave's first pixel, one row up: wave 0 wraps to pixel (X-1, y-2)
             const uint32_t eg = wave == 0 ? lastpix[(y + 2) & 3] : edge[((y + 1) & 1) * EDGE_W + wave];
             uint4 hv[V];
@@ -450,13 +451,9 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_reg_kernel(const IFrameArgs
                 for (int v = 0; v < V; ++v) hv[v] = *reinterpret_cast<const uint4*>(head + x0 + 4 * v);
             }
             const uint2* rn = win + (int)(ri1 - w0);
-            const int nr_next = more ? (int)(ri2 - ri1) + 1 : 0;
+            const int nr_next = more ? (int)(ri2 - ri1) : 0;
             uint2 nrec = make_uint2(0, 0);
-            uint32_t ne = 0;
-            if (tid < nr_next) {
-                nrec = rn[tid];
-                ne = tid + 1 < nr_next ? rn[tid + 1].x : 0xFFFFFFFFu;
-            }
+            if (tid < nr_next) nrec = rn[tid];
             const uint32_t row0 = (uint32_t)((size_t)y * X);
             uint32_t u0 = lane_to_the_left(p[PPL - 1]);
             if (lane == 0) u0 = eg;
@@ -496,12 +493,10 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_reg_kernel(const IFrameArgs
                 if (x0 + PPL == X) lastpix[y & 3] = q[PPL - 1];
             }
             // ---- scatter the heads of row y+1 ------------------------------------------------------
-            if (more) {
-                const uint32_t nrow0 = row0 + (uint32_t)X;
-                if (tid < nr_next) put_heads(head_next, nrec.y, nrec.x, ne < nrow0 + (uint32_t)X ? ne : nrow0 + (uint32_t)X, nrow0);
-                if (nr_next > WG) scatter_all(y + 1, w0, head_next, tid + WG);   // rows with more runs than lanes
-            }
+            if (tid < nr_next) head_next[nrec.x - (row0 + (uint32_t)X)] = nrec.y | HEAD_PRESENT;
+            if (nr_next > WG) scatter_from(y + 1, w0, head_next, tid + WG);   // rows with more records than lanes
             ri1 = ri2;
+            ri2 = ri3;
             lds_barrier();
         }
     }
