@@ -236,7 +236,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("sp_iframe_rows_kernel" if spec.get("mode") == "intra" else "sp_pframe_kernel")
+                "kernel": ("sp_iframe_rows_reg_kernel" if spec.get("mode") == "intra" else "sp_pframe_group_kernel")
                           if spec.get("sp") else ("msv1_parse_tiles + msv1_parse_chain + msv1_parse_emit + "
                                                   "msv1_blocks_kernel (whole step)" if spec.get("gpu_parse")
                                                   else ("msv1_blocks_temporal_kernel" if "inter" in spec else "msv1_blocks_kernel")),

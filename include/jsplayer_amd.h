@@ -111,7 +111,11 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       parser one by one, so results are identical either way.
  *   "sp_band_rows" = "auto" (default) | "0" | "<n>" : ScreenPressor only.  Key frames are rebuilt by one
  *       workgroup per band of n rows (0 = the whole frame is one band; auto = sized so a batch fills
- *       the GPU); the host stage hands each band the row above it.  Results do not depend on it. */
+ *       the GPU); the host stage hands each band the row above it.  Results do not depend on it.
+ *   "sp_inter_fusion" = "on" (default) | "off" : ScreenPressor only.  In a staged batch, consecutive inter
+ *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
+ *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its
+ *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame. */
 int jsp_set_option(jsp_codec* c, const char* key, const char* value);
 /* Block until everything queued by this codec has finished. */
 int jsp_sync(jsp_codec* c);

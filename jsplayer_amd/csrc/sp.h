@@ -71,8 +71,9 @@ struct FrameOut {
     int band_rows = 0;               // Intra: rows per band the seeds were cut for
     std::vector<PBlock> blocks;      // Inter
     std::vector<uint32_t> payload;   // Inter: literal pixels of the data rectangles
-    uint64_t prev_pixels = 0;        // Inter: pixels fetched from the previous frame
-    uint64_t data_pixels = 0;        // Inter: pixels taken from the payload
+    uint64_t prev_pixels = 0;        // Inter: pixels the stream takes from the previous frame
+    uint64_t data_pixels = 0;        // Inter: pixels the stream codes (data rectangles)
+    uint64_t motion_pixels = 0;      // Inter: part of prev_pixels that is motion-compensated
     uint64_t stream_bytes = 0;
     const char* error = nullptr;
 };
@@ -91,6 +92,10 @@ public:
     bool has_prev() const { return has_prev_; }
     // rows per band of the following key frames (0 = whole frame is one band, no seeds)
     void set_band_rows(int rows) { band_rows_ = rows < 0 ? 0 : rows; }
+    // Rewrites the motion rectangles of the inter frame just decoded as literal rectangles (pixels from
+    // the shadow frame appended to the payload): no block of `out` then reads the previous frame anywhere
+    // but at its own position, which is what lets consecutive inter frames share one launch.
+    void literalise_motion(FrameOut& out) const;
 
 private:
     int32_t literal();
@@ -133,6 +138,15 @@ int choose_band_rows(const Geometry& g, int nframes);
 void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream);
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,
                    const uint32_t* d_payload, hipStream_t stream);
+// A run of consecutive inter frames without motion blocks (see literalise_motion) in ONE launch: a lane
+// keeps its 4 pixels in registers from frame to frame, so the previous frame is read from HBM once.
+struct PGroupFrame {   // one per frame of the group, in decode order
+    int32_t* dst;
+    uint32_t block_off;    // first PBlock of the frame in d_blocks
+    uint32_t payload_off;  // base of the frame's literal pixels in d_payload
+};
+void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev,
+                         const PBlock* d_blocks, const uint32_t* d_payload, bool aligned16, hipStream_t stream);
 size_t iframe_lds_bytes(const Geometry& g, int band_rows = 0);
 constexpr int kMaxIntraWidth = 8192;  // LDS plan of the row-wavefront kernel
 

@@ -15,20 +15,24 @@ using namespace jsp::sp;
 struct SpStaged : jsp_staged {
     Geometry geo{};
     struct Op {
-        enum Kind { Intra, Inter } kind;
-        int first, count;      // Intra: range in the IFrameArgs array
+        enum Kind { Intra, Inter, InterGroup } kind;
+        int first, count;      // Intra: range in the IFrameArgs array; InterGroup: range in the PGroupFrame array
         int band_rows;         // Intra: rows per band (0 = one band)
         int32_t* dst;          // Inter
-        const int32_t* prev;
+        const int32_t* prev;   // Inter, InterGroup: the frame before the (first) frame
         size_t block_off, payload_off;
     };
     std::vector<Op> ops;
-    DeviceBuffer d_runs, d_rows, d_seeds, d_iargs, d_blocks, d_payload;
+    DeviceBuffer d_runs, d_rows, d_seeds, d_iargs, d_blocks, d_payload, d_gframes;
 
     void decode(hipStream_t stream) override {
         for (const Op& op : ops) {
             if (op.kind == Op::Intra)
                 launch_iframes(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, op.band_rows, stream);
+            else if (op.kind == Op::InterGroup)
+                launch_pframe_group(geo, static_cast<const PGroupFrame*>(d_gframes.p) + op.first, op.count, op.prev,
+                                    static_cast<const PBlock*>(d_blocks.p), static_cast<const uint32_t*>(d_payload.p),
+                                    geo.aligned16, stream);
             else
                 launch_pframe(geo, op.dst, op.prev, static_cast<const PBlock*>(d_blocks.p) + op.block_off,
                               static_cast<const uint32_t*>(d_payload.p) + op.payload_off, stream);
@@ -52,7 +56,13 @@ struct SpCodec : jsp_codec {
     int needs_index() override { return 0; }
     bool may_leave_pixels(const jsp_frame_in&) override { return false; }
     int opt_band_rows = -1;   // -1: chosen per batch (choose_band_rows); 0: one band per frame; n: n rows per band
+    bool opt_inter_fusion = true;   // consecutive inter frames of a staged batch share one launch
     int set_option(const char* key, const char* value) override {
+        if (std::strcmp(key, "sp_inter_fusion") == 0) {
+            if (std::strcmp(value, "on") == 0) { opt_inter_fusion = true; return 0; }
+            if (std::strcmp(value, "off") == 0) { opt_inter_fusion = false; return 0; }
+            return -1;
+        }
         if (std::strcmp(key, "sp_band_rows") == 0) {
             if (std::strcmp(value, "auto") == 0) { opt_band_rows = -1; return 0; }
             char* end = nullptr;
@@ -93,6 +103,11 @@ struct SpCodec : jsp_codec {
         host.set_band_rows(band_rows);
         std::vector<PBlock> blocks;
         std::vector<uint32_t> payload;
+        std::vector<PGroupFrame> gframes;
+        // Inter frames are fused per launch when the batch has several of them; a frame that moves more
+        // than a quarter of its pixels keeps its motion blocks (literal pixels for them would rival the
+        // frame in size) and gets a launch of its own.
+        const bool fuse_inter = opt_inter_fusion && nf - nkey >= 2;
         std::unordered_set<const void*> group_dsts;
         FrameOut fo;
         for (int i = 0; i < nf; ++i) {
@@ -137,8 +152,16 @@ struct SpCodec : jsp_codec {
                     break;
                 }
                 case FrameKind::Inter: {
-                    st->ops.push_back({SpStaged::Op::Inter, 0, 0, 0, f.dst, prev_dev, blocks.size(), payload.size()});
                     group_dsts.clear();
+                    if (fuse_inter && fo.motion_pixels * 4 <= npx && blocks.size() < (1u << 31) && payload.size() < (1u << 31)) {
+                        host.literalise_motion(fo);
+                        if (st->ops.empty() || st->ops.back().kind != SpStaged::Op::InterGroup)
+                            st->ops.push_back({SpStaged::Op::InterGroup, (int)gframes.size(), 0, 0, nullptr, prev_dev, 0, 0});
+                        st->ops.back().count++;
+                        gframes.push_back({f.dst, (uint32_t)blocks.size(), (uint32_t)payload.size()});
+                    } else {
+                        st->ops.push_back({SpStaged::Op::Inter, 0, 0, 0, f.dst, prev_dev, blocks.size(), payload.size()});
+                    }
                     blocks.insert(blocks.end(), fo.blocks.begin(), fo.blocks.end());
                     payload.insert(payload.end(), fo.payload.begin(), fo.payload.end());
                     st->info.units_coded += fo.data_pixels;
@@ -156,7 +179,7 @@ struct SpCodec : jsp_codec {
         st->info.pixels = (uint64_t)g.X * g.Y * nf;
         st->info.kernel_launches = st->ops.size();
         st->info.descriptor_bytes = runs.size() * sizeof(IRun) + rows.size() * 4 + seeds.size() * 4 + iargs.size() * sizeof(IFrameArgs) +
-                                    blocks.size() * sizeof(PBlock) + payload.size() * 4;
+                                    blocks.size() * sizeof(PBlock) + payload.size() * 4 + gframes.size() * sizeof(PGroupFrame);
         st->info.host_stage_ms = now_ms() - t0;
 
         const double t1 = now_ms();
@@ -166,6 +189,7 @@ struct SpCodec : jsp_codec {
         st->d_iargs.reserve(std::max<size_t>(iargs.size(), 1) * sizeof(IFrameArgs));
         st->d_blocks.reserve(std::max<size_t>(blocks.size(), 1) * sizeof(PBlock));
         st->d_payload.reserve(std::max<size_t>(payload.size(), 1) * 4 + 16);
+        st->d_gframes.reserve(std::max<size_t>(gframes.size(), 1) * sizeof(PGroupFrame));
         for (size_t k = 0; k < iargs.size(); ++k) {
             iargs[k].runs = static_cast<const IRun*>(st->d_runs.p) + iarg_run_off[k];
             iargs[k].row_run = static_cast<const uint32_t*>(st->d_rows.p) + iarg_row_off[k];
@@ -180,6 +204,7 @@ struct SpCodec : jsp_codec {
         up(st->d_iargs, iargs.data(), iargs.size() * sizeof(IFrameArgs));
         up(st->d_blocks, blocks.data(), blocks.size() * sizeof(PBlock));
         up(st->d_payload, payload.data(), payload.size() * 4);
+        up(st->d_gframes, gframes.data(), gframes.size() * sizeof(PGroupFrame));
         JSP_HIP(hipStreamSynchronize(stream));  // the host vectors go out of scope below
         st->info.h2d_ms = now_ms() - t1;
         guard.release();

@@ -307,6 +307,7 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
                     pb.mx = (int16_t)mx;
                     pb.my = (int16_t)my;
                     out.prev_pixels += (uint64_t)(x2 - x1) * (y2 - y1);
+                    out.motion_pixels += (uint64_t)(x2 - x1) * (y2 - y1);
                 } else {  // data: run stream confined to the rectangle, :406-466
                     int x = x1, y = y1, pt = 0;
                     while (y < y2) {
@@ -361,6 +362,22 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
         out.status = 2;
         out.error = a.why;
     }
+}
+
+void HostDecoder::literalise_motion(FrameOut& out) const {
+    if (out.kind != FrameKind::Inter || out.motion_pixels == 0) return;
+    const int32_t* pic = shadow_[cur_ ^ 1].data();   // decode_p swapped: this is the frame just decoded
+    const long X = g_.X;
+    for (int by = 0; by < g_.nby; ++by)
+        for (int bx = 0; bx < g_.nbx; ++bx) {
+            PBlock& pb = out.blocks[(size_t)by * g_.nbx + bx];
+            if (!(pb.flags & PB_MOTION)) continue;
+            pb.flags = (uint8_t)((pb.flags & ~PB_MOTION) | PB_DATA);
+            pb.mx = pb.my = 0;
+            pb.payload = (uint32_t)out.payload.size();
+            for (int y = by * 16 + pb.y1; y < by * 16 + pb.y2; ++y)
+                for (int x = bx * 16 + pb.x1; x < bx * 16 + pb.x2; ++x) out.payload.push_back((uint32_t)pic[(long)y * X + x]);
+        }
 }
 
 }  // namespace jsp::sp

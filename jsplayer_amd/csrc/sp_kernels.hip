@@ -565,6 +565,95 @@ __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ d
             if (x0 + j < X) dst[i0 + j] = px[j];
 }
 
+// Consecutive inter frames, one launch: same lane <-> pixel mapping as sp_pframe_kernel, frames iterated
+// inside the kernel with the lane's 4 pixels carried in registers.  No block of these frames is
+// motion-compensated (the host stage turned such rectangles into literal ones), so a lane never needs a
+// pixel another lane produced: no synchronisation between frames, the previous frame is read once, every
+// frame of the group costs its block records, its literal pixels and one 16-byte store per lane.
+// The records of GROUP_CHUNK frames (4 blocks + the frame's destination each) are staged in LDS first:
+// read from LDS they count on lgkmcnt, so the frame loop never waits on vmcnt — where a load would queue
+// behind the acknowledgement of every frame store issued before it — except for the rare literal pixels.
+constexpr int GROUP_CHUNK = 128;
+struct GroupSlot {       // LDS image of one frame of the chunk, 80 bytes
+    PBlock pb[4];
+    uint32_t* dst;
+    uint32_t payload_off;
+    uint32_t pad;
+};
+static_assert(sizeof(GroupSlot) == 80, "GroupSlot layout");
+
+__global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame* __restrict__ frames, int nframes,
+                                                              const uint32_t* __restrict__ prev,
+                                                              const PBlock* __restrict__ blocks,
+                                                              const uint32_t* __restrict__ payload, int X, int Y, int nbx,
+                                                              int vec) {
+    __shared__ __align__(16) GroupSlot slots[GROUP_CHUNK];
+    const int ly = threadIdx.x >> 4;
+    const int chunk = threadIdx.x & 15;
+    const int kb = chunk >> 2;                // which of the workgroup's 4 blocks
+    const int bx = blockIdx.x * 4 + kb;
+    const int by = blockIdx.y;
+    const int y = by * 16 + ly;
+    const int x0 = bx * 16 + (chunk & 3) * 4;
+    const bool mine = bx < nbx && y < Y && x0 < X;   // lanes past the frame edge still help staging
+    const size_t i0 = (size_t)y * X + x0;
+    const bool full = vec && x0 + 4 <= X;
+    const int cx0 = (chunk & 3) * 4;          // chunk origin relative to the block
+    uint32_t px[4] = {0, 0, 0, 0};
+    if (mine) {
+        if (full) {
+            const uint4 q = *reinterpret_cast<const uint4*>(prev + i0);
+            px[0] = q.x; px[1] = q.y; px[2] = q.z; px[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < X) px[j] = prev[i0 + j];
+        }
+    }
+    // Loads and stores share vmcnt, so every wait on a load inside the frame loop would also wait for the
+    // frame stores before it.  Settle the previous-frame pixels here, and the literal pixels right where
+    // they are fetched (rare), so that the stores of untouched lanes stream without any wait.
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt/lgkmcnt untouched
+    const int nb_here = nbx - (int)blockIdx.x * 4 < 4 ? nbx - (int)blockIdx.x * 4 : 4;   // blocks this workgroup covers
+    for (int f0 = 0; f0 < nframes; f0 += GROUP_CHUNK) {
+        const int nf = nframes - f0 < GROUP_CHUNK ? nframes - f0 : GROUP_CHUNK;
+        __syncthreads();                      // the previous chunk's slots are no longer read
+        for (int t = threadIdx.x; t < nf * 5; t += PWG) {
+            const int f = t / 5, k = t - f * 5;
+            const PGroupFrame gf = frames[f0 + f];
+            if (k < 4) {
+                if (k < nb_here) slots[f].pb[k] = blocks[(size_t)gf.block_off + (size_t)by * nbx + blockIdx.x * 4 + k];
+            } else {
+                slots[f].dst = reinterpret_cast<uint32_t*>(gf.dst);
+                slots[f].payload_off = gf.payload_off;
+            }
+        }
+        __syncthreads();
+        if (!mine) continue;
+        for (int f = 0; f < nf; ++f) {
+            const PBlock pb = slots[f].pb[kb];
+            uint32_t* out = slots[f].dst + i0;
+            const bool touched = pb.flags != 0 && ly >= pb.y1 && ly < pb.y2 && cx0 < pb.x2 && cx0 + 4 > pb.x1;
+            if (touched) {
+                const int w = pb.x2 - pb.x1;
+                const uint32_t* lit = payload + slots[f].payload_off + pb.payload + (uint32_t)((ly - pb.y1) * w) - pb.x1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rx = cx0 + j;
+                    if (rx >= pb.x1 && rx < pb.x2 && x0 + j < X) px[j] = load1_global(lit + rx);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            if (full) store4_global(out, make_uint4(px[0], px[1], px[2], px[3]));   // (nontemporal: no gain, measured)
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x0 + j < X) store1_global(out + j, px[j]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -686,6 +775,15 @@ void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const P
                      (reinterpret_cast<uintptr_t>(prev) & 15) == 0) ? 1 : 0;
     dim3 grid((g.nbx + 3) / 4, g.nby);
     hipLaunchKernelGGL(sp_pframe_kernel, grid, dim3(PWG), 0, stream, reinterpret_cast<uint32_t*>(dst),
+                       reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec);
+}
+
+void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev,
+                         const PBlock* d_blocks, const uint32_t* d_payload, bool aligned16, hipStream_t stream) {
+    if (nframes <= 0) return;
+    const int vec = ((g.X & 3) == 0 && aligned16 && (reinterpret_cast<uintptr_t>(prev) & 15) == 0) ? 1 : 0;
+    dim3 grid((g.nbx + 3) / 4, g.nby);
+    hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), 0, stream, d_frames, nframes,
                        reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec);
 }
 

@@ -377,8 +377,10 @@ def desktop_next(rng: SplitMix64, img: np.ndarray, bpp: int = 24, p_motion: floa
 
 def sp_clip(config_index: int, width: int, height: int, nframes: int, bpp: int = 24, version: int = 4,
             key_every: int = 0, flat_at: Sequence[int] = (), unchanged_at: Sequence[int] = (),
-            **frame_kw) -> Tuple[List[bytes], List[bool], List[np.ndarray]]:
-    """Encode a synthetic clip.  Returns (chunks, is_key, expected frames as uint32 arrays)."""
+            p_mix_at: Optional[dict] = None, **frame_kw) -> Tuple[List[bytes], List[bool], List[np.ndarray]]:
+    """Encode a synthetic clip.  Returns (chunks, is_key, expected frames as uint32 arrays).
+    `p_mix_at` = {frame index: dict(unchanged=..., motion=...)} overrides the block mix of single inter
+    frames (the rest of the blocks splits evenly into repainted and sub-rectangle blocks)."""
     rng = SplitMix64(SEED_BASE + config_index)
     enc = SpEncoder(width, height, bpp, version)
     chunks, keys, frames = [], [], []
@@ -397,7 +399,12 @@ def sp_clip(config_index: int, width: int, height: int, nframes: int, bpp: int =
             chunks.append(enc.encode_p(img))
             keys.append(False)
         else:
-            img, hints = desktop_next(rng, img, bpp)
+            mix = (p_mix_at or {}).get(i)
+            if mix:
+                rest = max(0.0, 1.0 - mix["unchanged"] - mix["motion"])
+                img, hints = desktop_next(rng, img, bpp, p_motion=mix["motion"], p_data=rest / 2, p_sub=rest / 2)
+            else:
+                img, hints = desktop_next(rng, img, bpp)
             chunks.append(enc.encode_p(img, hints))
             keys.append(False)
         frames.append(img.reshape(-1).copy())

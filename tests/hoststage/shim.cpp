@@ -34,6 +34,12 @@ int hs_decode(void* p, int key, const uint8_t* src, size_t n, uint64_t* meta) {
     meta[8] = o.flat_colour; meta[9] = o.prev_pixels; meta[10] = o.data_pixels; meta[11] = o.stream_bytes;
     return o.status;
 }
+// rewrite the motion rectangles of the inter frame just decoded as literal ones; meta as hs_decode
+void hs_literalise_motion(void* p, uint64_t* meta) {
+    auto* s = (Shim*)p;
+    s->host.literalise_motion(s->out);
+    meta[6] = s->out.blocks.size(); meta[7] = s->out.payload.size();
+}
 void hs_fetch(void* p, uint32_t* runs /*2 per run*/, uint32_t* rows, uint8_t* blocks /*16 B each*/, uint32_t* payload) {
     const FrameOut& o = ((Shim*)p)->out;
     if (runs && !o.runs.empty()) std::memcpy(runs, o.runs.data(), o.runs.size() * sizeof(IRun));

@@ -30,6 +30,7 @@ def lib():
         L.hs_decode.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]
         L.hs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_set_band_rows.argtypes = [C.c_void_p, C.c_int]
+        L.hs_literalise_motion.argtypes = [C.c_void_p, C.c_void_p]
         L.hs_seed_words.restype = C.c_size_t
         L.hs_seed_words.argtypes = [C.c_void_p]
         L.hs_fetch_seeds.argtypes = [C.c_void_p, C.c_void_p]
@@ -66,6 +67,17 @@ class HostStage:
         self.L.hs_fetch_seeds(self.h, seeds.ctypes.data)
         out.update(runs=runs, rows=rows, blocks=blocks, payload=payload, seeds=seeds,
                    band_rows=getattr(self, "band_rows", 0))
+        return out
+
+    def literalise_motion(self, desc):
+        """HostDecoder::literalise_motion on the frame just decoded: new block table + payload."""
+        meta = np.zeros(12, dtype=np.uint64)
+        self.L.hs_literalise_motion(self.h, meta.ctypes.data)
+        blocks = np.zeros((int(meta[6]), 16), dtype=np.uint8)
+        payload = np.zeros(int(meta[7]), dtype=np.uint32)
+        self.L.hs_fetch(self.h, None, None, blocks.ctypes.data, payload.ctypes.data)
+        out = dict(desc)
+        out.update(blocks=blocks, payload=payload)
         return out
 
     def close(self):

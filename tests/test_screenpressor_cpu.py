@@ -115,6 +115,35 @@ def test_key_frame_bands_expand_from_their_seed_rows(band_rows):
         assert sd[0] == (pic[y0 - 2, w - 1] if y0 >= 2 else 0)
 
 
+@pytest.mark.parametrize("version", [2, 4])
+def test_motion_rectangles_as_literals(version):
+    """literalise_motion (what lets inter frames share a launch): afterwards no block is motion-compensated,
+    the payload grew by exactly the moved pixels, and the block table still expands to the oracle's frame."""
+    w, h = 100, 52
+    chunks, keys, frames = sg.sp_clip(650 + version, w, h, 6, version=version,
+                                      p_mix_at={2: dict(unchanged=0.3, motion=0.6), 4: dict(unchanged=0.5, motion=0.3)})
+    host = hs.HostStage(w, h, 24)
+    host.preinit(4)
+    prev, moved_any = None, 0
+    for i, (c, k) in enumerate(zip(chunks, keys)):
+        d = host.decode(k, c)
+        if d["kind"] == hs.KIND_INTRA:
+            cur = hs.expand_iframe(d, w, h)
+        elif d["kind"] == hs.KIND_NONE:      # nothing changed in this small frame
+            cur = prev
+        else:
+            moved = sum((int(b[3]) - int(b[1])) * (int(b[4]) - int(b[2])) for b in d["blocks"] if b[0] & hs.PB_MOTION)
+            lit = host.literalise_motion(d)
+            assert not any(b[0] & hs.PB_MOTION for b in lit["blocks"])
+            assert lit["payload"].size == d["payload"].size + moved
+            cur = hs.expand_pframe(lit, prev, w, h)
+            assert np.array_equal(cur, hs.expand_pframe(d, prev, w, h))
+            moved_any += moved
+        assert np.array_equal(cur, frames[i]), i
+        prev = cur
+    assert moved_any > 1000
+
+
 def test_host_stage_rejects_what_the_reference_cannot_survive():
     host = hs.HostStage(16, 16, 24)
     assert host.decode(True, bytes([0x13, 0, 0, 0]))["status"] == 2

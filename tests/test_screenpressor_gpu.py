@@ -172,7 +172,65 @@ def test_batch_of_key_frames_one_launch_and_p_clip():
     for d, img in zip(dsts, frames):
         assert np.array_equal(to_np(d).view(np.uint32), img)
     info = st.info()
-    assert info["kernel_launches"] == 10
+    assert info["kernel_launches"] == 2        # the key frame, then all nine inter frames in one launch
+    st.close()
+    # the same clip with inter-frame fusion off: one launch per frame, same pictures
+    gpu3 = ScreenPressor(w, h, 24)
+    gpu3.Preinit(36)
+    gpu3.set_option("sp_inter_fusion", "off")
+    dsts = [dev_buf(w * h, -1) for _ in range(10)]
+    st = gpu3.stage_batch(chunks, dsts, is_key=keys)
+    assert st.info()["kernel_launches"] == 10
+    st.decode()
+    gpu3.sync()
+    for d, img in zip(dsts, frames):
+        assert np.array_equal(to_np(d).view(np.uint32), img)
+    st.close()
+
+
+@pytest.mark.parametrize("size", [(640, 360), (100, 52), (37, 23), (2052, 40)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("version", [2, 4])
+def test_fused_inter_frames(size, version):
+    """A staged clip whose inter frames share launches: heavy-motion frames (more than a quarter of the
+    pixels moved) break the run and keep their motion blocks, unchanged frames sit inside it, key frames
+    split it, and frame buffers are reused round-robin as a player's pool would."""
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(970 + version, w, h, 16, version=version, key_every=9, unchanged_at=(3, 11),
+                                      p_mix_at={5: dict(unchanged=0.30, motion=0.60), 6: dict(unchanged=0.05, motion=0.90)})
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    # distinct buffers: every frame can be checked
+    dsts = [dev_buf(w * h, -1) for _ in range(16)]
+    st = gpu.stage_batch(chunks, dsts, is_key=keys)
+    launches = st.info()["kernel_launches"]
+    for _ in range(2):                       # replayable
+        st.decode()
+    gpu.sync()
+    status, adopted, _ = st.results()
+    assert status == [0] * 16
+    for i, (d, img) in enumerate(zip(dsts, frames)):
+        if adopted[i]:
+            assert np.array_equal(to_np(d).view(np.uint32), img), f"frame {i}"
+    assert not adopted[3] and not adopted[11]
+    assert launches < 12                     # 2 key frames + a few groups/breakers, not one per frame
+    st.close()
+    gpu.StopAndClean()
+    # a pool of three buffers used as a player would (never the buffer holding the previous frame; a frame
+    # that changes nothing does not consume one): afterwards each buffer holds the last frame decoded into it
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    pool = [dev_buf(w * h, -1) for _ in range(3)]
+    order, k = [], 0
+    for i in range(16):
+        order.append(pool[k % 3])
+        k += 1 if adopted[i] else 0
+    st = gpu.stage_batch(chunks, order, is_key=keys)
+    st.decode()
+    gpu.sync()
+    assert st.results()[1] == adopted
+    for b in pool:
+        mine = [i for i in range(16) if adopted[i] and order[i] is b]
+        assert mine and np.array_equal(to_np(b).view(np.uint32), frames[mine[-1]]), f"frame {mine[-1]}"
     st.close()
 
 
