@@ -136,7 +136,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # under torch.distributed.run the RCCL group is set up whatever N is (N = 1 included: same code path)
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

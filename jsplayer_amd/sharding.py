@@ -22,7 +22,7 @@ def reduce_counters(frames: int, pixels: int, elapsed_s: float, device=None) -> 
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return int(frames), int(pixels), float(elapsed_s)
     counts = torch.tensor([int(frames), int(pixels)], dtype=torch.int64, device=device)
     tmax = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
