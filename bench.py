@@ -204,13 +204,11 @@ def main():
         kernel_us = gpu_ms * 1e3 / launches                   # average per launch, HIP events
         alg_per_launch = info["algorithmic_bytes"] / info["kernel_launches"]
         achieved = alg_per_launch / (kernel_us * 1e-6) / 1e9  # GB/s
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        traffic = None       # measured HBM bytes per launch (PMC passes kept under profiles/), if this workload has them
+        tpath = os.path.join(ROOT, "profiles", "traffic_by_workload.json")
         if os.path.exists(tpath):
             try:
-                t = json.load(open(tpath))
-                if t.get("workload") == args.workload:
-                    traffic = t.get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))["hbm_bytes_per_launch"].get(args.workload)
             except Exception:
                 traffic = None
         out = {
