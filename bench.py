@@ -259,6 +259,11 @@ def main():
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, all_frames, all_keys, pal)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            try:
+                with open("/proc/cpuinfo") as f:
+                    out["cpu_baseline"]["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     staged.close()
     codec.StopAndClean()
