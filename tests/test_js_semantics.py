@@ -70,3 +70,73 @@ def test_oracle_agrees_with_a_real_js_engine():
                 assert which == jr["which"]
             checked += 1
     assert checked > 300
+
+
+# ---- ScreenPressor, range-coder (version 2) streams ---------------------------------------------------
+def build_sp_cases():
+    from jsplayer_amd import streamgen as sg2
+    rng = np.random.default_rng(78)
+    cases = []
+    for (w, h, bpp) in [(64, 48, 24), (37, 23, 24), (64, 48, 16), (100, 52, 24)]:
+        chunks, keys, _ = sg2.sp_clip(4100 + w + bpp, w, h, 7, bpp=bpp, version=2, key_every=4, flat_at=(5,),
+                                      unchanged_at=(2,))
+        clip = [dict(key=bool(k), bytes=list(c)) for c, k in zip(chunks, keys)]
+        cases.append(dict(w=w, h=h, bpp=bpp, lines=4, prefill=0x00A5A5A5, frames=clip))        # the valid clip
+        for k in range(45):
+            victim = 1 + k % 6                       # never frame 0: the models must exist (this JS file is v2 only)
+            b = bytearray(chunks[victim])
+            kind = k % 5
+            if kind == 0 and len(b) > 1:
+                b = b[: int(rng.integers(1, len(b)))]                                     # truncated
+            elif kind == 1 and len(b) > 1:
+                b[int(rng.integers(1, len(b)))] ^= int(rng.integers(1, 256))              # one byte flipped
+            elif kind == 2:
+                b = bytearray([b[0] if b else 0x12]) + bytearray(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8).tobytes())
+            elif kind == 3:
+                b = bytearray(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8).tobytes())
+                b[0] = int(rng.choice([0x12, 0x11, 0x13, 0x10, 0x02, 0x01]))             # heads of this version only
+            else:
+                b = bytearray()
+            seq = clip[:victim] + [dict(key=bool(keys[victim]), bytes=list(b))] + clip[victim + 1:] + clip[4:]
+            cases.append(dict(w=w, h=h, bpp=bpp, lines=int(rng.integers(0, 40)), prefill=int(rng.integers(0, 1 << 24)), frames=seq))
+    # a flat key frame before any coded one: the reference dereferences a null coder
+    cases.append(dict(w=16, h=16, bpp=24, lines=0, prefill=5, frames=[dict(key=True, bytes=[0x11, 1, 2, 3]), dict(key=False, bytes=[1, 2, 3])]))
+    return cases
+
+
+def test_screenpressor_oracle_agrees_with_a_real_js_engine():
+    from oracle_binding import OracleScreenPressor
+    cases = build_sp_cases()
+    res = subprocess.run([NODE, os.path.join(HERE, "js", "sp_js_semantics.js")], input=json.dumps(cases).encode(),
+                         stdout=subprocess.PIPE, check=True, timeout=300)
+    js = json.loads(res.stdout)
+    checked = aborted = hung = 0
+    for ci, (cs, jres) in enumerate(zip(cases, js)):
+        orc = OracleScreenPressor(cs["w"], cs["h"], cs["bpp"])
+        orc.Preinit(cs["lines"])
+        bufs = [np.full(cs["w"] * cs["h"], cs["prefill"], dtype=np.int32) for _ in range(3)]
+        for fi, (f, jr) in enumerate(zip(cs["frames"], jres)):
+            dst = next(b for b in bufs if b is not orc.PreviousFrame())
+            where = (ci, fi, cs["w"], cs["h"], cs["bpp"], len(f["bytes"]))
+            if f["key"]:
+                rc = orc.DecompressI(bytes(f["bytes"]), dst)
+                assert (rc == 3) == (jr["raised"] or jr["hang"]), where
+                if rc != 3:
+                    assert rc == jr["state"], where
+            else:
+                try:
+                    data, sig = orc.DecompressP(bytes(f["bytes"]), dst)
+                    assert not (jr["raised"] or jr["hang"]), where
+                    assert sig == jr["signif"], where
+                    assert (data is not dst) == jr["same"], where
+                except OracleAbort:
+                    assert jr["raised"] or jr["hang"], where
+            if jr["hang"]:
+                hung += 1
+                break                                 # the reference would still be spinning
+            aborted += 1 if jr["raised"] else 0
+            assert dst.tolist() == jr["dst"], where
+            which = next((i for i, b in enumerate(bufs) if b is orc.PreviousFrame()), -1)
+            assert which == jr["which"], where
+            checked += 1
+    assert checked > 1500 and aborted > 0 and hung > 0
