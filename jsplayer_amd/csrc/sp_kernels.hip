@@ -1,15 +1,20 @@
 // ScreenPressor reconstruction kernels for gfx950 (MI355X).  Integer work, HBM-bound, no MFMA.
 //
-// sp_iframe_rows_kernel — one workgroup per band of an I-frame (grid.x = frame, grid.y = band; the row
-//   above a band comes from the host stage's seed rows, so bands are independent).
-//   The run table resolves every pixel to either a constant or "the pixel one row up (same column or
-//   one to the left), plus a per-run delta" (ScreenPressor.hx:242-273; the gradient predictor
-//   telescopes inside a run).  Rows are produced top of the buffer downwards; the previous row lives
-//   in LDS, so the row-to-row dependency never touches HBM: per row one coalesced read of the run
-//   records that intersect it and one 16-byte store per lane.
-// sp_pframe_kernel — P-frame: a workgroup covers 4 horizontally adjacent 16x16 blocks (64 px =
-//   256 contiguous bytes per row), lane = 16-byte chunk of a row: unchanged / base copy / motion
-//   from the previous frame in HBM, literal payload for data rectangles (ScreenPressor.hx:361-475).
+// Key frames (grid.x = frame, grid.y = band; the row above a band comes from the host stage's seed rows,
+// so bands are independent workgroups).  The run table resolves every pixel to either a constant or "the
+// pixel one row up (same column or one to the left) plus a per-run addend" (ScreenPressor.hx:242-273; the
+// gradient predictor telescopes inside a run).  Rows are produced top of the band downwards; the
+// row-to-row dependency never touches HBM.  Three kernels, picked by geometry (iframe_variant):
+//   sp_iframe_rows_reg_kernel    X % 4 == 0, X <= 4096: row above in registers, run words scattered
+//                                through LDS, one LDS-only barrier per row — the one 1080p uses;
+//   sp_iframe_rows_kernel        X % 4 == 0, X <= 8192: row above in LDS (8 pixels per lane beyond 4096);
+//   sp_iframe_rows_search_kernel any width / alignment: per-lane run search.
+// Inter frames:
+//   sp_pframe_kernel             one frame: a workgroup covers 4 horizontally adjacent 16x16 blocks (256
+//                                contiguous bytes per row), lane = 16-byte chunk of a row: unchanged / base
+//                                copy / motion from the previous frame in HBM, literal payload for data
+//                                rectangles (ScreenPressor.hx:361-475);
+//   sp_pframe_group_kernel       consecutive inter frames in one launch, pixels carried in registers.
 #include <cstdlib>
 #include <mutex>
 
@@ -175,8 +180,9 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
 //             column), and gets the carry from the nearest lower lane that saw a head through one
 //             ballot + one cross-lane read; the first lane of every wave always sees a head.
 // The scatter for row y+1 does not depend on row y's pixels, so it is issued before the single
-// end-of-row barrier: one barrier and a handful of LDS round trips per image row.  The loop is bound
-// by VALU issue, so lanes take PPL = 8 pixels: half the waves, the per-lane overhead amortised.
+// end-of-row barrier: one barrier and a handful of LDS round trips per image row.  PPL = 4 pixels per lane
+// is the faster setting wherever it fits (more waves to overlap each wave's serial row step); PPL = 8
+// serves rows wider than 4096 pixels.
 template <int WG, int PPL>
 __global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
                                                             int run_cap, int band_rows) {
