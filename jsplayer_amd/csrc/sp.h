@@ -32,7 +32,7 @@ enum RunKind : uint32_t {   // bit 0: the pixel starts from the row above; bit 1
                          // telescopes inside a run: p[i]-p[i-X] = p[i0-1]-p[i0-1-X]
     RUN_ABOVE_LEFT = 3,  // pixel i takes pixel i-X-1 (addend 0)
 };
-constexpr long kRunSplit = 256;  // records never cross a multiple of this many columns (= one wave x 4 pixels)
+constexpr long kRunSplit = 256;  // row-major layout: records never cross a multiple of this many columns (= one wave x 4 pixels)
 struct IRun {
     uint32_t start;  // linear pixel index of the first pixel
     uint32_t word;   // low 24 bits: colour or addend; bits 24..25: RunKind; bits 26..31 zero
@@ -69,6 +69,11 @@ struct FrameOut {
     std::vector<uint32_t> row_run;   // Intra: Y+1 entries, index of the record that starts at pixel y*X
     std::vector<uint32_t> seeds;     // Intra: per band after the first, seed_stride(X) words (see IFrameArgs)
     int band_rows = 0;               // Intra: rows per band the seeds were cut for
+    // Intra, tile layout (set_iframe_layout with a span): `runs` is then ordered tile by tile (band-major,
+    // then column span, then row, then column; no sentinel) and these two tables describe the tiles
+    int span_px = 0;
+    std::vector<uint32_t> tile_idx;  // per tile band_rows+1 offsets into runs: first record of each of its rows, then the end
+    std::vector<uint32_t> left;      // per tile band_rows words: the pixel left of the span's first pixel, one row up
     std::vector<PBlock> blocks;      // Inter
     std::vector<uint32_t> payload;   // Inter: literal pixels of the data rectangles
     uint64_t prev_pixels = 0;        // Inter: pixels the stream takes from the previous frame
@@ -91,7 +96,9 @@ public:
     const Geometry& geo() const { return g_; }
     bool has_prev() const { return has_prev_; }
     // rows per band of the following key frames (0 = whole frame is one band, no seeds)
-    void set_band_rows(int rows) { band_rows_ = rows < 0 ? 0 : rows; }
+    void set_band_rows(int rows) { band_rows_ = rows < 0 ? 0 : rows; span_px_ = 0; }
+    // bands AND column spans: key frames come out as independent tiles (see FrameOut::tile_idx); span 0 = row-major
+    void set_iframe_layout(int band_rows, int span_px) { band_rows_ = band_rows < 0 ? 0 : band_rows; span_px_ = span_px < 0 ? 0 : span_px; }
     // Rewrites the motion rectangles of the inter frame just decoded as literal rectangles (pixels from
     // the shadow frame appended to the payload): no block of `out` then reads the previous frame anywhere
     // but at its own position, which is what lets consecutive inter frames share one launch.
@@ -113,7 +120,7 @@ private:
     int insignificant_blocks_ = 0;
     std::vector<int32_t> bts_;
     int stall_ = 0;
-    int band_rows_ = 0;
+    int band_rows_ = 0, span_px_ = 0;
 };
 
 // ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------
@@ -124,6 +131,9 @@ struct IFrameArgs {    // one per frame of an intra launch (grid.x = frame, grid
     // band b >= 1 starts at row y0 = b * band_rows and finds at seeds + (b-1) * seed_stride(X):
     // word 0 = pixel (X-1, y0-2) (what "above-left" of column 0 reads, linear index i-X-1), words 1..X = row y0-1
     const uint32_t* seeds;
+    // tile layout only (launch_iframe_tiles): FrameOut::tile_idx / FrameOut::left of this frame
+    const uint32_t* tile_idx;
+    const uint32_t* left;
     uint32_t nruns;
     uint32_t flat;     // 1: fill with `colour`
     uint32_t colour;
@@ -134,6 +144,11 @@ inline int band_count(int Y, int band_rows) { return band_rows > 0 && band_rows 
 // Rows per band for a launch of `nframes` key frames: enough workgroups to fill the chip several
 // times over, but bands tall enough that the seed rows stay a few percent of the frame.
 int choose_band_rows(const Geometry& g, int nframes);
+// Tile layout: one WAVE per tile (band x 256-column span), no workgroup barrier at all.  Usable when
+// iframe_tiles_ok(g): X % 4 == 0 and every frame buffer of the launch 16-byte aligned.
+bool iframe_tiles_ok(const Geometry& g);
+int iframe_tile_span(const Geometry& g);   // columns per tile (256 or 512): what set_iframe_layout must be given
+void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream);
 // band_rows <= 0 or >= Y: one band per frame
 void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream);
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,

@@ -18,16 +18,19 @@ struct SpStaged : jsp_staged {
         enum Kind { Intra, Inter, InterGroup } kind;
         int first, count;      // Intra: range in the IFrameArgs array; InterGroup: range in the PGroupFrame array
         int band_rows;         // Intra: rows per band (0 = one band)
+        bool tiles;            // Intra: tile layout (one wave per band x span), else row-major
         int32_t* dst;          // Inter
         const int32_t* prev;   // Inter, InterGroup: the frame before the (first) frame
         size_t block_off, payload_off;
     };
     std::vector<Op> ops;
-    DeviceBuffer d_runs, d_rows, d_seeds, d_iargs, d_blocks, d_payload, d_gframes;
+    DeviceBuffer d_runs, d_rows, d_seeds, d_tileidx, d_left, d_iargs, d_blocks, d_payload, d_gframes;
 
     void decode(hipStream_t stream) override {
         for (const Op& op : ops) {
-            if (op.kind == Op::Intra)
+            if (op.kind == Op::Intra && op.tiles)
+                launch_iframe_tiles(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, op.band_rows, stream);
+            else if (op.kind == Op::Intra)
                 launch_iframes(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, op.band_rows, stream);
             else if (op.kind == Op::InterGroup)
                 launch_pframe_group(geo, static_cast<const PGroupFrame*>(d_gframes.p) + op.first, op.count, op.prev,
@@ -94,13 +97,14 @@ struct SpCodec : jsp_codec {
         st->info = jsp_staged_info{};
 
         std::vector<IRun> runs;
-        std::vector<uint32_t> rows, seeds;
+        std::vector<uint32_t> rows, seeds, tileidx, left;
         std::vector<IFrameArgs> iargs;
-        std::vector<size_t> iarg_run_off, iarg_row_off, iarg_seed_off;
+        std::vector<size_t> iarg_run_off, iarg_row_off, iarg_seed_off, iarg_tile_off, iarg_left_off;
         int nkey = 0;
         for (const auto& f : frames) nkey += f.key ? 1 : 0;
         const int band_rows = opt_band_rows >= 0 ? opt_band_rows : choose_band_rows(g, nkey);   // one cut for the whole batch
-        host.set_band_rows(band_rows);
+        const bool tiles = iframe_tiles_ok(st->geo);   // key frames as independent tiles (needs aligned buffers)
+        host.set_iframe_layout(band_rows, tiles ? iframe_tile_span(st->geo) : 0);
         std::vector<PBlock> blocks;
         std::vector<uint32_t> payload;
         std::vector<PGroupFrame> gframes;
@@ -133,14 +137,18 @@ struct SpCodec : jsp_codec {
                     iarg_run_off.push_back(runs.size());
                     iarg_row_off.push_back(rows.size());
                     iarg_seed_off.push_back(seeds.size());
+                    iarg_tile_off.push_back(tileidx.size());
+                    iarg_left_off.push_back(left.size());
                     runs.insert(runs.end(), fo.runs.begin(), fo.runs.end());
-                    rows.insert(rows.end(), fo.row_run.begin(), fo.row_run.end());
+                    if (!tiles) rows.insert(rows.end(), fo.row_run.begin(), fo.row_run.end());
                     seeds.insert(seeds.end(), fo.seeds.begin(), fo.seeds.end());
+                    tileidx.insert(tileidx.end(), fo.tile_idx.begin(), fo.tile_idx.end());
+                    left.insert(left.end(), fo.left.begin(), fo.left.end());
                     const bool join = !st->ops.empty() && st->ops.back().kind == SpStaged::Op::Intra &&
                                       !group_dsts.count(f.dst);
                     if (join) st->ops.back().count++;
                     else {
-                        st->ops.push_back({SpStaged::Op::Intra, (int)iargs.size(), 1, band_rows, nullptr, nullptr, 0, 0});
+                        st->ops.push_back({SpStaged::Op::Intra, (int)iargs.size(), 1, band_rows, tiles, nullptr, nullptr, 0, 0});
                         group_dsts.clear();
                     }
                     group_dsts.insert(f.dst);
@@ -156,11 +164,11 @@ struct SpCodec : jsp_codec {
                     if (fuse_inter && fo.motion_pixels * 4 <= npx && blocks.size() < (1u << 31) && payload.size() < (1u << 31)) {
                         host.literalise_motion(fo);
                         if (st->ops.empty() || st->ops.back().kind != SpStaged::Op::InterGroup)
-                            st->ops.push_back({SpStaged::Op::InterGroup, (int)gframes.size(), 0, 0, nullptr, prev_dev, 0, 0});
+                            st->ops.push_back({SpStaged::Op::InterGroup, (int)gframes.size(), 0, 0, false, nullptr, prev_dev, 0, 0});
                         st->ops.back().count++;
                         gframes.push_back({f.dst, (uint32_t)blocks.size(), (uint32_t)payload.size()});
                     } else {
-                        st->ops.push_back({SpStaged::Op::Inter, 0, 0, 0, f.dst, prev_dev, blocks.size(), payload.size()});
+                        st->ops.push_back({SpStaged::Op::Inter, 0, 0, 0, false, f.dst, prev_dev, blocks.size(), payload.size()});
                     }
                     blocks.insert(blocks.end(), fo.blocks.begin(), fo.blocks.end());
                     payload.insert(payload.end(), fo.payload.begin(), fo.payload.end());
@@ -178,7 +186,8 @@ struct SpCodec : jsp_codec {
         st->info.frames = nf;
         st->info.pixels = (uint64_t)g.X * g.Y * nf;
         st->info.kernel_launches = st->ops.size();
-        st->info.descriptor_bytes = runs.size() * sizeof(IRun) + rows.size() * 4 + seeds.size() * 4 + iargs.size() * sizeof(IFrameArgs) +
+        st->info.descriptor_bytes = runs.size() * sizeof(IRun) + (rows.size() + seeds.size() + tileidx.size() + left.size()) * 4 +
+                                    iargs.size() * sizeof(IFrameArgs) +
                                     blocks.size() * sizeof(PBlock) + payload.size() * 4 + gframes.size() * sizeof(PGroupFrame);
         st->info.host_stage_ms = now_ms() - t0;
 
@@ -186,6 +195,8 @@ struct SpCodec : jsp_codec {
         st->d_runs.reserve(std::max<size_t>(runs.size(), 1) * sizeof(IRun));
         st->d_rows.reserve(std::max<size_t>(rows.size(), 1) * 4);
         st->d_seeds.reserve(std::max<size_t>(seeds.size(), 1) * 4);
+        st->d_tileidx.reserve(std::max<size_t>(tileidx.size(), 1) * 4);
+        st->d_left.reserve(std::max<size_t>(left.size(), 1) * 4);
         st->d_iargs.reserve(std::max<size_t>(iargs.size(), 1) * sizeof(IFrameArgs));
         st->d_blocks.reserve(std::max<size_t>(blocks.size(), 1) * sizeof(PBlock));
         st->d_payload.reserve(std::max<size_t>(payload.size(), 1) * 4 + 16);
@@ -194,6 +205,8 @@ struct SpCodec : jsp_codec {
             iargs[k].runs = static_cast<const IRun*>(st->d_runs.p) + iarg_run_off[k];
             iargs[k].row_run = static_cast<const uint32_t*>(st->d_rows.p) + iarg_row_off[k];
             iargs[k].seeds = static_cast<const uint32_t*>(st->d_seeds.p) + iarg_seed_off[k];
+            iargs[k].tile_idx = static_cast<const uint32_t*>(st->d_tileidx.p) + iarg_tile_off[k];
+            iargs[k].left = static_cast<const uint32_t*>(st->d_left.p) + iarg_left_off[k];
         }
         auto up = [&](DeviceBuffer& d, const void* h, size_t bytes) {
             if (bytes) JSP_HIP(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream));
@@ -201,6 +214,8 @@ struct SpCodec : jsp_codec {
         up(st->d_runs, runs.data(), runs.size() * sizeof(IRun));
         up(st->d_rows, rows.data(), rows.size() * 4);
         up(st->d_seeds, seeds.data(), seeds.size() * 4);
+        up(st->d_tileidx, tileidx.data(), tileidx.size() * 4);
+        up(st->d_left, left.data(), left.size() * 4);
         up(st->d_iargs, iargs.data(), iargs.size() * sizeof(IFrameArgs));
         up(st->d_blocks, blocks.data(), blocks.size() * sizeof(PBlock));
         up(st->d_payload, payload.data(), payload.size() * 4);

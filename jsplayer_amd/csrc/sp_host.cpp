@@ -113,10 +113,11 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             ++out.stream_runs;
             const uint32_t word = (payload & 0xFFFFFFu) | (kind << 24);
             const long stop = start + cnt < end ? start + cnt : end;
+            const long split = span_px_ > 0 ? span_px_ : kRunSplit;
             long col = start % X;
             for (long i = start; i < stop;) {
                 runs.push_back({(uint32_t)i, word});
-                const long next_col = (col / kRunSplit + 1) * kRunSplit;
+                const long next_col = (col / split + 1) * split;
                 const long step = (next_col < X ? next_col : X) - col;
                 i += step;
                 col = next_col < X ? next_col : 0;
@@ -193,6 +194,36 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             const uint32_t first = (uint32_t)((long)y * X);
             while (r + 1 < runs.size() && runs[r + 1].start <= first) ++r;
             out.row_run[y] = (uint32_t)r;
+        }
+        if (span_px_ > 0) {  // tile layout: records regrouped tile by tile, plus what each tile needs from its left
+            const int rows_per = band_rows_ > 0 && band_rows_ < g_.Y ? band_rows_ : g_.Y;
+            const int nbands = (g_.Y + rows_per - 1) / rows_per, nspans = (g_.X + span_px_ - 1) / span_px_;
+            const size_t ntiles = (size_t)nbands * nspans, stride = (size_t)rows_per + 1;
+            runs.pop_back();                              // the sentinel has no place in a tile
+            std::vector<uint32_t>& idx = out.tile_idx;
+            idx.assign(ntiles * stride + 1, 0);           // counts first (shifted by one), then prefix sums
+            auto slot = [&](uint32_t start) -> size_t {
+                const long y = start / X, x = start - y * X;
+                return ((size_t)(y / rows_per) * nspans + (size_t)(x / span_px_)) * stride + (size_t)(y % rows_per);
+            };
+            for (const IRun& r : runs) ++idx[slot(r.start) + 1];
+            for (size_t i = 1; i < idx.size(); ++i) idx[i] += idx[i - 1];
+            std::vector<IRun> tiled(runs.size());
+            std::vector<uint32_t> cursor(idx.begin(), idx.end() - 1);
+            for (const IRun& r : runs) tiled[cursor[slot(r.start)]++] = r;   // stable: row-major order survives inside a tile
+            runs.swap(tiled);
+            idx.pop_back();                               // ntiles * stride entries: the slot after a tile's last row is its end
+            out.left.assign(ntiles * rows_per, 0);
+            for (int b = 0; b < nbands; ++b)
+                for (int sp = 0; sp < nspans; ++sp)
+                    for (int r = 0; r < rows_per && b * rows_per + r < g_.Y; ++r) {
+                        const long y = (long)b * rows_per + r;
+                        // what "above-left" of the span's first pixel reads: one row up, one column left;
+                        // for column 0 the linear index wraps to the last pixel two rows up
+                        const long i = y * X + (long)sp * span_px_ - X - 1;
+                        out.left[((size_t)b * nspans + sp) * rows_per + r] = i >= 0 ? (uint32_t)dst[i] : 0u;
+                    }
+            out.span_px = span_px_;
         }
         if (band_rows_ > 0 && band_rows_ < g_.Y) {  // the row above every band after the first, from the shadow
             out.band_rows = band_rows_;

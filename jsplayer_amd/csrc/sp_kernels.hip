@@ -508,6 +508,152 @@ __global__ __launch_bounds__(WG) void sp_iframe_rows_reg_kernel(const IFrameArgs
     }
 }
 
+// Tile path: one WAVE per tile = a band of rows x a span of 64*PPL columns.  The host stage hands every
+// tile what crosses its borders — the row above the band (seeds) and, per row, the pixel left of the span's
+// first pixel one row up (`left`) — orders the run records tile by tile and never lets one cross a span, so
+// a wave needs nothing another wave produces: no workgroup barrier, no LDS shared between waves, the row
+// loop is one wave's private instruction stream (resolve as in sp_iframe_rows_reg_kernel: row above in
+// registers, run words scattered through an LDS row of the span, branch-free predictor).  PPL = 4 pixels per
+// lane is the default (see iframe_tile_span).
+template <int PPL>
+__global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
+                                                            int band_rows, int nspans, int win_cap) {
+    static_assert(PPL == 4 || PPL == 8, "4 or 8 pixels per lane");
+    constexpr int SPAN = 64 * PPL;
+    constexpr int V = PPL / 4;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const IFrameArgs fa = args[blockIdx.x];
+    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
+    const int tile = blockIdx.y;
+    const int band = tile / nspans, span = tile - band * nspans;
+    const int yb = band * band_rows;
+    if (yb >= Y) return;
+    const int ye = yb + band_rows < Y ? yb + band_rows : Y;
+    const int lane = threadIdx.x;
+    const int xs = span * SPAN;                       // first column of the span
+    const int x0 = xs + lane * PPL;
+    const bool active = x0 < X;                       // X % PPL == 0: an active lane owns PPL pixels
+    if (fa.flat) {
+        if (active)
+            for (int y = yb; y < ye; ++y)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    store4_global(dst + (size_t)y * X + x0 + 4 * v, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
+        return;
+    }
+    uint32_t* head = lds;                             // SPAN words
+    uint32_t* idx = lds + SPAN;                       // band_rows + 1 offsets (relative to fa.runs)
+    uint32_t* left = idx + ((band_rows + 1 + 3) & ~3);   // band_rows words
+    uint2* win = reinterpret_cast<uint2*>(left + ((band_rows + 3) & ~3));   // win_cap records
+    const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
+    const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
+    for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
+    for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
+#pragma unroll
+    for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + lane * PPL + 4 * v) = make_uint4(0, 0, 0, 0);
+    uint32_t p[PPL];                                  // this lane's pixels of the row above
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) p[j] = 0;
+    if (yb > 0 && active) {
+        const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + j);
+    }
+    // everything fetched so far must have landed before the row loop: a vmcnt wait inside it would also wait for
+    // the frame stores (loads and stores share the counter)
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt/lgkmcnt untouched
+    __builtin_amdgcn_wave_barrier();
+
+    const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
+    int y = yb;
+    while (y < ye) {
+        // window: rows y .. y_end-1 whose records fit in win_cap.  A single row with more records than that
+        // (more than one run every other pixel) is scattered straight from global memory.
+        const uint32_t w0 = idx[y - yb];
+        int y_end = y + 1;
+        while (y_end < ye && (int)(idx[y_end + 1 - yb] - w0) <= win_cap) ++y_end;
+        int wn = (int)(idx[y_end - yb] - w0);
+        const bool direct = wn > win_cap;             // only possible with y_end == y + 1
+        if (direct) wn = 0;
+        for (int k = lane; k < wn; k += 64) win[k] = load2_global(gruns + w0 + k);
+        {
+            const uint32_t r0 = w0, r1 = idx[y + 1 - yb], origin = (uint32_t)((size_t)y * X + xs);
+            if (direct) {
+                for (int r = lane; r < (int)(r1 - r0); r += 64) {
+                    const uint2 q = load2_global(gruns + r0 + r);
+                    head[q.x - origin] = q.y | HEAD_PRESENT;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_wave_barrier();
+            if (!direct)
+                for (int r = lane; r < (int)(r1 - r0); r += 64) {
+                    const uint2 q = win[r];
+                    head[q.x - origin] = q.y | HEAD_PRESENT;
+                }
+        }
+        uint32_t r1 = idx[y + 1 - yb];
+        uint32_t r2 = y + 1 < y_end ? idx[y + 2 - yb] : r1;
+        for (; y < y_end; ++y) {
+            const bool more = y + 1 < y_end;
+            const uint32_t r3 = y + 2 < y_end ? idx[y + 3 - yb] : r2;     // a row ahead, off the critical path
+            const uint32_t eg = left[y - yb];
+            uint4 hv[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) hv[v] = make_uint4(0, 0, 0, 0);
+            if (active) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) hv[v] = *reinterpret_cast<const uint4*>(head + lane * PPL + 4 * v);
+            }
+            const int n_next = more ? (int)(r2 - r1) : 0;
+            uint2 nrec = make_uint2(0, 0);
+            if (lane < n_next) nrec = win[(int)(r1 - w0) + lane];
+            const uint32_t row0 = (uint32_t)((size_t)y * X);
+            uint32_t u0 = lane_to_the_left(p[PPL - 1]);
+            if (lane == 0) u0 = eg;
+            if (active) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + lane * PPL + 4 * v) = make_uint4(0, 0, 0, 0);
+                uint32_t h[PPL];
+#pragma unroll
+                for (int v = 0; v < V; ++v) { h[4 * v] = hv[v].x; h[4 * v + 1] = hv[v].y; h[4 * v + 2] = hv[v].z; h[4 * v + 3] = hv[v].w; }
+                uint32_t last = h[0];
+#pragma unroll
+                for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
+                const unsigned long long seen = __ballot(last != 0u);
+                const unsigned long long lower = seen & ((1ull << lane) - 1ull);
+                const int src = lower ? 63 - __clzll((long long)lower) : lane;
+                uint32_t w = (uint32_t)__shfl((int)last, src);   // lane 0 always has h[0] != 0: a record starts every span
+                auto predict = [](uint32_t word, uint32_t lft, uint32_t above) -> uint32_t {
+                    const uint32_t use_above = (uint32_t)((int32_t)(word << 7) >> 31), use_left = (uint32_t)((int32_t)(word << 6) >> 31);
+                    const uint32_t base = ((lft & use_left) | (above & ~use_left)) & use_above;
+                    return add_bytes(base, word);
+                };
+                uint32_t q[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    w = h[j] ? h[j] : w;
+                    q[j] = predict(w, j ? p[j - 1] : u0, p[j]);
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    store4_global(dst + row0 + x0 + 4 * v, make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]));
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) p[j] = q[j];
+            }
+            const uint32_t origin_next = row0 + (uint32_t)X + (uint32_t)xs;
+            if (lane < n_next) head[nrec.x - origin_next] = nrec.y | HEAD_PRESENT;
+            for (int r = lane + 64; r < n_next; r += 64) {   // rows with more records than lanes
+                const uint2 q2 = win[(int)(r1 - w0) + r];
+                head[q2.x - origin_next] = q2.y | HEAD_PRESENT;
+            }
+            __builtin_amdgcn_wave_barrier();
+            r1 = r2;
+            r2 = r3;
+        }
+    }
+}
+
 constexpr int PWG = 256;  // 16 rows x 16 chunks of 4 pixels = 4 blocks side by side
 
 __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ prev,
@@ -773,6 +919,44 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, in
     } else {
         hipLaunchKernelGGL(sp_iframe_rows_search_kernel, grid, dim3(IWG), lds, stream, d_args, g.X, g.Y, cap, band_rows);
     }
+}
+
+bool iframe_tiles_ok(const Geometry& g) {
+    static const bool off = [] { const char* k = getenv("JSP_SP_IFRAME_KERNEL"); return k && k[0] != 't'; }();   // reg|rows|search: the older paths
+    return !off && (g.X & 3) == 0 && g.aligned16;
+}
+int iframe_tile_span(const Geometry& g) {
+    static const int forced = [] { const char* e = getenv("JSP_SP_TILE_PPL"); return e ? atoi(e) : 0; }();
+    // 4 pixels per lane (256-column spans) is the default: at 64 x 1080p the 8-pixel variant took 189 us against
+    // 147 us (half as many waves, each with a longer serial row step).  JSP_SP_TILE_PPL=8 selects it for tuning.
+    return (forced == 8 && (g.X & 7) == 0) ? 512 : 256;
+}
+namespace {
+struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
+TilePlan tile_plan(const Geometry& g, int band_rows) {
+    TilePlan t;
+    t.rows = rows_in_band(g, band_rows);
+    t.span = iframe_tile_span(g);
+    t.nspans = (g.X + t.span - 1) / t.span;
+    // per wave: head row + row index + left column + record window; ~4.5 KB keeps 32 waves on a CU
+    const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + (((size_t)t.rows + 3) & ~size_t(3));
+    const size_t budget = 4608 / 4;
+    size_t cap = budget > fixed ? (budget - fixed) / 2 : 0;
+    if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
+    t.win_cap = (int)cap;
+    t.lds = 4 * (fixed + 2 * cap);
+    return t;
+}
+}  // namespace
+void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream) {
+    if (nframes <= 0) return;
+    const TilePlan t = tile_plan(g, band_rows);
+    const int bands = (g.Y + t.rows - 1) / t.rows;
+    const dim3 grid(nframes, bands * t.nspans);
+    if (t.span == 512)
+        hipLaunchKernelGGL(sp_iframe_tile_kernel<8>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
+    else
+        hipLaunchKernelGGL(sp_iframe_tile_kernel<4>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,

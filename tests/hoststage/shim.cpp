@@ -19,6 +19,13 @@ void* hs_create(int w, int h, int bpp) { return new Shim(w, h, bpp); }
 void hs_destroy(void* p) { delete (Shim*)p; }
 void hs_preinit(void* p, int lines) { ((Shim*)p)->host.preinit(lines); }
 void hs_set_band_rows(void* p, int rows) { ((Shim*)p)->host.set_band_rows(rows); }
+void hs_set_iframe_layout(void* p, int rows, int span) { ((Shim*)p)->host.set_iframe_layout(rows, span); }
+size_t hs_tile_words(void* p, int which) { const FrameOut& o = ((Shim*)p)->out; return which ? o.left.size() : o.tile_idx.size(); }
+void hs_fetch_tiles(void* p, uint32_t* idx, uint32_t* left) {
+    const FrameOut& o = ((Shim*)p)->out;
+    if (idx && !o.tile_idx.empty()) std::memcpy(idx, o.tile_idx.data(), o.tile_idx.size() * 4);
+    if (left && !o.left.empty()) std::memcpy(left, o.left.data(), o.left.size() * 4);
+}
 size_t hs_seed_words(void* p) { return ((Shim*)p)->out.seeds.size(); }
 void hs_fetch_seeds(void* p, uint32_t* seeds) {
     const FrameOut& o = ((Shim*)p)->out;

@@ -31,6 +31,10 @@ def lib():
         L.hs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_set_band_rows.argtypes = [C.c_void_p, C.c_int]
         L.hs_literalise_motion.argtypes = [C.c_void_p, C.c_void_p]
+        L.hs_set_iframe_layout.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.hs_tile_words.restype = C.c_size_t
+        L.hs_tile_words.argtypes = [C.c_void_p, C.c_int]
+        L.hs_fetch_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_seed_words.restype = C.c_size_t
         L.hs_seed_words.argtypes = [C.c_void_p]
         L.hs_fetch_seeds.argtypes = [C.c_void_p, C.c_void_p]
@@ -48,8 +52,12 @@ class HostStage:
         self.L.hs_preinit(self.h, lines)
 
     def set_band_rows(self, rows):
-        self.band_rows = rows
+        self.band_rows, self.span_px = rows, 0
         self.L.hs_set_band_rows(self.h, rows)
+
+    def set_iframe_layout(self, rows, span):
+        self.band_rows, self.span_px = rows, span
+        self.L.hs_set_iframe_layout(self.h, rows, span)
 
     def decode(self, key: bool, src: bytes):
         meta = np.zeros(12, dtype=np.uint64)
@@ -65,8 +73,12 @@ class HostStage:
         self.L.hs_fetch(self.h, runs.ctypes.data, rows.ctypes.data, blocks.ctypes.data, payload.ctypes.data)
         seeds = np.zeros(self.L.hs_seed_words(self.h), dtype=np.uint32)
         self.L.hs_fetch_seeds(self.h, seeds.ctypes.data)
+        tile_idx = np.zeros(self.L.hs_tile_words(self.h, 0), dtype=np.uint32)
+        left = np.zeros(self.L.hs_tile_words(self.h, 1), dtype=np.uint32)
+        self.L.hs_fetch_tiles(self.h, tile_idx.ctypes.data, left.ctypes.data)
         out.update(runs=runs, rows=rows, blocks=blocks, payload=payload, seeds=seeds,
-                   band_rows=getattr(self, "band_rows", 0))
+                   band_rows=getattr(self, "band_rows", 0), span_px=getattr(self, "span_px", 0),
+                   tile_idx=tile_idx, left=left)
         return out
 
     def literalise_motion(self, desc):
@@ -129,6 +141,43 @@ def expand_iframe(desc, X, Y):
         else:
             v = np.where(kind == RUN_CONST, v, 0)
         out[y] = v
+    return out.reshape(-1)
+
+
+def expand_iframe_tiles(desc, X, Y):
+    """What sp_iframe_tile_kernel computes: every tile (band x 256-column span) on its own, from its records,
+    the seed row above its band and its column of left pixels — nothing another tile produced."""
+    if desc["kind"] == KIND_FLAT:
+        return np.full(X * Y, desc["flat_colour"], dtype=np.uint32)
+    span, runs, idx, left, seeds = desc["span_px"], desc["runs"], desc["tile_idx"], desc["left"], desc["seeds"]
+    rows_per = desc["band_rows"] if 0 < desc["band_rows"] < Y else Y
+    nbands, nspans = (Y + rows_per - 1) // rows_per, (X + span - 1) // span
+    assert idx.size == nbands * nspans * (rows_per + 1) and left.size == nbands * nspans * rows_per
+    out = np.zeros((Y, X), dtype=np.uint32)
+    covered = np.zeros(len(runs), dtype=bool)
+    for b in range(nbands):
+        for s in range(nspans):
+            t = b * nspans + s
+            xs, xe = s * span, min(X, (s + 1) * span)
+            up = seeds[(b - 1) * (X + 1) + 1 + xs:(b - 1) * (X + 1) + 1 + xe].copy() if b > 0 else np.zeros(xe - xs, np.uint32)
+            for r in range(min(rows_per, Y - b * rows_per)):
+                y = b * rows_per + r
+                lo, hi = int(idx[t * (rows_per + 1) + r]), int(idx[t * (rows_per + 1) + r + 1])
+                rec = runs[lo:hi]
+                covered[lo:hi] = True
+                cols = rec[:, 0].astype(np.int64) - y * X - xs
+                assert len(rec) and cols[0] == 0 and np.all(np.diff(cols) > 0) and cols[-1] < xe - xs, (b, s, r)
+                k = np.searchsorted(cols, np.arange(xe - xs), side="right") - 1
+                w = rec[k, 1]
+                kind, val = w >> 24, w & 0xFFFFFF
+                lft = np.empty(xe - xs, np.uint32)
+                lft[1:] = up[:-1]
+                lft[0] = left[t * rows_per + r]
+                v = np.where(kind == RUN_ABOVE, _add_bytes(up, val), val)
+                v = np.where(kind == RUN_ABOVE_LEFT, lft, v).astype(np.uint32)
+                out[y, xs:xe] = v
+                up = v
+    assert covered.all()
     return out.reshape(-1)
 
 

@@ -115,6 +115,24 @@ def test_key_frame_bands_expand_from_their_seed_rows(band_rows):
         assert sd[0] == (pic[y0 - 2, w - 1] if y0 >= 2 else 0)
 
 
+@pytest.mark.parametrize("size", [(100, 48), (37, 23), (600, 40), (256, 17), (260, 9)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("span", [256, 512])
+@pytest.mark.parametrize("band_rows", [0, 1, 5, 24])
+def test_key_frame_tiles_stand_alone(size, band_rows, span):
+    """Tile layout of key frames (one wave per band x 256-column span on the GPU): every tile is rebuilt from its
+    own records, the seed row above its band and its column of left pixels only, and the mosaic is the oracle's
+    frame.  Widths below, at, just above and well above one span (256 or 512 columns)."""
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(660 + w, w, h, 3, version=4, key_every=1, rects=30, gradients=8)
+    host = hs.HostStage(w, h, 24)
+    host.preinit(4)
+    host.set_iframe_layout(band_rows, span)
+    for c, img in zip(chunks, frames):
+        d = host.decode(True, c)
+        assert d["status"] == 0 and d["kind"] == hs.KIND_INTRA
+        assert np.array_equal(hs.expand_iframe_tiles(d, w, h), img)
+
+
 @pytest.mark.parametrize("version", [2, 4])
 def test_motion_rectangles_as_literals(version):
     """literalise_motion (what lets inter frames share a launch): afterwards no block is motion-compensated,

@@ -83,6 +83,15 @@ def test_key_frame_bands(size, band_rows):
     drive_pair(w, h, 24, chunks, keys, frames, band_rows=band_rows)
 
 
+def test_noise_key_frame_rows_with_more_runs_than_the_tile_window():
+    """Almost every pixel its own run: a 512-column span row then has more records than a tile's LDS window
+    holds, and the kernel scatters that row straight from global memory."""
+    w, h = 1024, 40
+    chunks, keys, frames = sg.sp_clip(992, w, h, 2, version=4, key_every=1, noise=0.97)
+    drive_pair(w, h, 24, chunks, keys, frames)
+    drive_pair(w, h, 24, chunks, keys, frames, band_rows=7)
+
+
 def test_key_frame_bands_1080p_batch():
     """A batch of 1080p key frames in one launch, banded automatically and with an odd band height."""
     w, h = 1920, 1080
