@@ -940,7 +940,8 @@ TilePlan tile_plan(const Geometry& g, int band_rows) {
     t.nspans = (g.X + t.span - 1) / t.span;
     // per wave: head row + row index + left column + record window; ~4.5 KB keeps 32 waves on a CU
     const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + (((size_t)t.rows + 3) & ~size_t(3));
-    const size_t budget = 4608 / 4;
+    static const size_t budget_bytes = [] { const char* e = getenv("JSP_SP_TILE_LDS_BYTES"); const long v = e ? atol(e) : 0; return (size_t)(v >= 2048 && v <= 65536 ? v : 4608); }();
+    const size_t budget = budget_bytes / 4;
     size_t cap = budget > fixed ? (budget - fixed) / 2 : 0;
     if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
     t.win_cap = (int)cap;
