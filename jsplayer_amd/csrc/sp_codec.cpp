@@ -102,8 +102,9 @@ struct SpCodec : jsp_codec {
         std::vector<size_t> iarg_run_off, iarg_row_off, iarg_seed_off, iarg_tile_off, iarg_left_off;
         int nkey = 0;
         for (const auto& f : frames) nkey += f.key ? 1 : 0;
-        const int band_rows = opt_band_rows >= 0 ? opt_band_rows : choose_band_rows(g, nkey);   // one cut for the whole batch
+        int band_rows = opt_band_rows >= 0 ? opt_band_rows : choose_band_rows(g, nkey);   // one cut for the whole batch
         const bool tiles = iframe_tiles_ok(st->geo);   // key frames as independent tiles (needs aligned buffers)
+        if (tiles && g.Y > 4096 && (band_rows <= 0 || band_rows > 4096)) band_rows = 4096;   // a tile's row index lives in LDS
         host.set_iframe_layout(band_rows, tiles ? iframe_tile_span(st->geo) : 0);
         std::vector<PBlock> blocks;
         std::vector<uint32_t> payload;
