@@ -144,7 +144,9 @@ def main():
 
     from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
 
-    spec = WORKLOADS[args.workload]
+    spec = dict(WORKLOADS[args.workload])
+    if os.environ.get("JSP_BENCH_FRAMES"):          # experiment knob: another batch / clip length
+        spec["frames"] = int(os.environ["JSP_BENCH_FRAMES"])
     w, h, nfr = spec["w"], spec["h"], spec["frames"]
     frames, keys, pal = build_clip(spec, rank)
     all_frames, all_keys = frames, keys
@@ -168,7 +170,11 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     codec.set_stream(stream.cuda_stream)
-    dsts = [torch.empty(w * h, dtype=torch.int32, device="cuda") for _ in range(nfr)]
+    if os.environ.get("JSP_BENCH_ONE_ALLOC"):   # experiment: all frame buffers carved out of one allocation
+        pool = torch.empty(nfr * w * h, dtype=torch.int32, device="cuda")
+        dsts = [pool[i * w * h:(i + 1) * w * h] for i in range(nfr)]
+    else:
+        dsts = [torch.empty(w * h, dtype=torch.int32, device="cuda") for _ in range(nfr)]
     staged = codec.stage_batch(frames, dsts, is_key=keys)   # host parse + H2D: outside the timed region
     info = staged.info()
 

@@ -722,10 +722,13 @@ __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ d
 // motion-compensated (the host stage turned such rectangles into literal ones), so a lane never needs a
 // pixel another lane produced: no synchronisation between frames, the previous frame is read once, every
 // frame of the group costs its block records, its literal pixels and one 16-byte store per lane.
-// The records of GROUP_CHUNK frames (4 blocks + the frame's destination each) are staged in LDS first:
-// read from LDS they count on lgkmcnt, so the frame loop never waits on vmcnt — where a load would queue
-// behind the acknowledgement of every frame store issued before it — except for the rare literal pixels.
-constexpr int GROUP_CHUNK = 128;
+// Loads and stores share vmcnt, so a load waited for inside the frame loop would queue behind the
+// acknowledgement of every frame store issued before it.  The frame loop therefore touches LDS only: for a
+// chunk of frames the workgroup first stages (a) the records of its 4 blocks and each frame's destination
+// and (b) the literal pixels of its changed rectangles — as many frames as fit the literal buffer, at
+// least one — and only then walks those frames.  (Fetching literals from HBM inside the loop cost a store
+// round trip in 28 % of the wave-frames of the test clip: 2.1 us per frame instead of 1.6.)
+constexpr int GROUP_LITERALS_MIN = 1024;  // one frame needs at most 4 x 256 words of literal pixels
 struct GroupSlot {       // LDS image of one frame of the chunk, 80 bytes
     PBlock pb[4];
     uint32_t* dst;
@@ -738,8 +741,13 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
                                                               const uint32_t* __restrict__ prev,
                                                               const PBlock* __restrict__ blocks,
                                                               const uint32_t* __restrict__ payload, int X, int Y, int nbx,
-                                                              int vec) {
-    __shared__ __align__(16) GroupSlot slots[GROUP_CHUNK];
+                                                              int vec, int chunk_frames, int literal_words) {
+    // LDS: [slots: chunk_frames x 80 B][lit_at: chunk_frames x 4 words][lits: literal_words][s_fit]
+    extern __shared__ __align__(16) uint32_t group_lds[];
+    GroupSlot* slots = reinterpret_cast<GroupSlot*>(group_lds);
+    uint32_t* lit_at = group_lds + (size_t)chunk_frames * (sizeof(GroupSlot) / 4);   // where in `lits` the rectangle of (frame, block) starts
+    uint32_t* lits = lit_at + (size_t)chunk_frames * 4;
+    int& s_fit = *reinterpret_cast<int*>(lits + literal_words);   // frames of the chunk whose literals fit
     const int ly = threadIdx.x >> 4;
     const int chunk = threadIdx.x & 15;
     const int kb = chunk >> 2;                // which of the workgroup's 4 blocks
@@ -762,47 +770,79 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
                 if (x0 + j < X) px[j] = prev[i0 + j];
         }
     }
-    // Loads and stores share vmcnt, so every wait on a load inside the frame loop would also wait for the
-    // frame stores before it.  Settle the previous-frame pixels here, and the literal pixels right where
-    // they are fetched (rare), so that the stores of untouched lanes stream without any wait.
-    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt/lgkmcnt untouched
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the previous-frame pixels are settled before any store is issued
     const int nb_here = nbx - (int)blockIdx.x * 4 < 4 ? nbx - (int)blockIdx.x * 4 : 4;   // blocks this workgroup covers
-    for (int f0 = 0; f0 < nframes; f0 += GROUP_CHUNK) {
-        const int nf = nframes - f0 < GROUP_CHUNK ? nframes - f0 : GROUP_CHUNK;
-        __syncthreads();                      // the previous chunk's slots are no longer read
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int f0 = 0;
+    while (f0 < nframes) {
+        int nf = nframes - f0 < chunk_frames ? nframes - f0 : chunk_frames;
+        __syncthreads();                      // the previous chunk's slots and literals are no longer read
         for (int t = threadIdx.x; t < nf * 5; t += PWG) {
             const int f = t / 5, k = t - f * 5;
             const PGroupFrame gf = frames[f0 + f];
             if (k < 4) {
-                if (k < nb_here) slots[f].pb[k] = blocks[(size_t)gf.block_off + (size_t)by * nbx + blockIdx.x * 4 + k];
+                PBlock pb{};
+                if (k < nb_here) pb = blocks[(size_t)gf.block_off + (size_t)by * nbx + blockIdx.x * 4 + k];
+                slots[f].pb[k] = pb;
             } else {
                 slots[f].dst = reinterpret_cast<uint32_t*>(gf.dst);
                 slots[f].payload_off = gf.payload_off;
             }
         }
         __syncthreads();
-        if (!mine) continue;
-        for (int f = 0; f < nf; ++f) {
-            const PBlock pb = slots[f].pb[kb];
-            uint32_t* out = slots[f].dst + i0;
-            const bool touched = pb.flags != 0 && ly >= pb.y1 && ly < pb.y2 && cx0 < pb.x2 && cx0 + 4 > pb.x1;
-            if (touched) {
-                const int w = pb.x2 - pb.x1;
-                const uint32_t* lit = payload + slots[f].payload_off + pb.payload + (uint32_t)((ly - pb.y1) * w) - pb.x1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rx = cx0 + j;
-                    if (rx >= pb.x1 && rx < pb.x2 && x0 + j < X) px[j] = load1_global(lit + rx);
+        // where each changed rectangle's literals go in `lits`, and how many frames fit (serial: <= 4 * 96 steps)
+        if (threadIdx.x == 0) {
+            uint32_t used = 0;
+            int fit = 0;
+            for (; fit < nf; ++fit) {
+                uint32_t need = 0, at[4];
+                for (int k = 0; k < 4; ++k) {
+                    const PBlock& pb = slots[fit].pb[k];
+                    at[k] = used + need;
+                    if (pb.flags & PB_DATA) need += (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
                 }
-                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (used + need > (uint32_t)literal_words && fit > 0) break;   // (one frame always fits: <= 1024 words)
+                for (int k = 0; k < 4; ++k) lit_at[fit * 4 + k] = at[k];
+                used += need;
             }
-            if (full) store4_global(out, make_uint4(px[0], px[1], px[2], px[3]));   // (nontemporal: no gain, measured)
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x0 + j < X) store1_global(out + j, px[j]);
+            s_fit = fit;
+        }
+        __syncthreads();
+        nf = s_fit;
+        // fetch the literals: wave k takes block k's rectangles, lanes run along the rectangle's pixels
+        for (int f = 0; f < nf; ++f) {
+            const PBlock pb = slots[f].pb[wave];
+            if (pb.flags & PB_DATA) {
+                const uint32_t n = (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
+                const uint32_t* src = payload + slots[f].payload_off + pb.payload;
+                uint32_t* to = lits + lit_at[f * 4 + wave];
+                for (uint32_t i = lane; i < n; i += 64) to[i] = load1_global(src + i);
             }
         }
+        __syncthreads();                      // literals are in place (the barrier waits for vmcnt and LDS)
+        if (mine) {
+            for (int f = 0; f < nf; ++f) {
+                const PBlock pb = slots[f].pb[kb];
+                uint32_t* out = slots[f].dst + i0;
+                const bool touched = pb.flags != 0 && ly >= pb.y1 && ly < pb.y2 && cx0 < pb.x2 && cx0 + 4 > pb.x1;
+                if (touched) {
+                    const int w = pb.x2 - pb.x1;
+                    const uint32_t* lit = lits + lit_at[f * 4 + kb] + (uint32_t)((ly - pb.y1) * w) - pb.x1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rx = cx0 + j;
+                        if (rx >= pb.x1 && rx < pb.x2 && x0 + j < X) px[j] = lit[rx];
+                    }
+                }
+                if (full) store4_global(out, make_uint4(px[0], px[1], px[2], px[3]));   // (nontemporal: no gain, measured)
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (x0 + j < X) store1_global(out + j, px[j]);
+                }
+            }
+        }
+        f0 += nf;
     }
 }
 
@@ -974,8 +1014,14 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     if (nframes <= 0) return;
     const int vec = ((g.X & 3) == 0 && aligned16 && (reinterpret_cast<uintptr_t>(prev) & 15) == 0) ? 1 : 0;
     dim3 grid((g.nbx + 3) / 4, g.nby);
-    hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), 0, stream, d_frames, nframes,
-                       reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec);
+    // A chunk of 16 frames and 1024 literal words is 5.6 KB of LDS per workgroup.  Measured on one box, 299
+    // 1080p frames: chunk 8 / 16 / 32 / 64 / 160 frames -> 650 / 643 / 668 / 733 / 780 us (larger chunks cost
+    // occupancy and longer staging stalls).  JSP_SP_GROUP_CHUNK / JSP_SP_GROUP_LITERALS: tuning knobs.
+    static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 16; }();
+    static const int lit_words = [] { const char* e = getenv("JSP_SP_GROUP_LITERALS"); const int v = e ? atoi(e) : 0; return v >= GROUP_LITERALS_MIN && v <= 8192 ? v : GROUP_LITERALS_MIN; }();
+    const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 16;
+    hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
+                       reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec, chunk, lit_words);
 }
 
 }  // namespace jsp::sp

@@ -3,6 +3,7 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/hbm_ceiling.hip -o /tmp/hbm_ceiling && /tmp/hbm_ceiling
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -106,14 +107,61 @@ static double time_us(F&& launch, int reps) {
     return ms * 1e3 / reps;
 }
 
-int main() {
-    const int X = 1920, Y = 1080, F = 64;
+// Temporal shapes: a workgroup owns a tile of the picture and writes it once per frame, frame after frame
+// (what the inter-frame group kernels do).  TR rows x TC pixels per workgroup, 256 lanes, each lane TR*TC/1024
+// stores of 16 B per frame; lanes run along the row first.
+template <int TR, int TC>
+__global__ __launch_bounds__(256) void temporal_fill(uint32_t* __restrict__ base, int X, int Y, size_t frame_ints, int F) {
+    constexpr int LANES_PER_ROW = TC / 4, ROWS_PER_PASS = 256 / LANES_PER_ROW, PASSES = TR / ROWS_PER_PASS;
+    static_assert(PASSES >= 1 && TR % ROWS_PER_PASS == 0, "shape");
+    const int tiles_x = (X + TC - 1) / TC;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * TC + (threadIdx.x % LANES_PER_ROW) * 4, r0 = ty * TR + threadIdx.x / LANES_PER_ROW;
+    if (x >= X) return;
+    u32x4 v = u32x4{(uint32_t)x, (uint32_t)r0, 3u, 4u};
+    for (int f = 0; f < F; ++f) {
+        uint32_t* dst = base + (size_t)f * frame_ints;
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+            const int y = r0 + k * ROWS_PER_PASS;
+            if (y < Y) *reinterpret_cast<u32x4*>(dst + (size_t)y * X + x) = v;
+        }
+        v.x += 1;
+    }
+}
+// same as temporal_fill<16, 64>, but every frame's base pointer comes from a table staged in LDS (what the
+// ScreenPressor group kernel does with its per-frame destinations)
+__global__ __launch_bounds__(256) void temporal_fill_lds_table(uint32_t* const* __restrict__ table, int X, int Y, int F) {
+    __shared__ uint32_t* s_tab[128];
+    const int tiles_x = (X + 63) / 64;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 64 + (threadIdx.x % 16) * 4, y = ty * 16 + threadIdx.x / 16;
+    u32x4 v = u32x4{(uint32_t)x, (uint32_t)y, 3u, 4u};
+    for (int f0 = 0; f0 < F; f0 += 128) {
+        const int nf = F - f0 < 128 ? F - f0 : 128;
+        __syncthreads();
+        if ((int)threadIdx.x < nf) s_tab[threadIdx.x] = table[f0 + threadIdx.x];
+        __syncthreads();
+        if (x < X && y < Y)
+            for (int f = 0; f < nf; ++f) *reinterpret_cast<u32x4*>(s_tab[f] + (size_t)y * X + x) = v;
+    }
+}
+
+template <int TR, int TC>
+static double run_temporal(uint32_t* d, int X, int Y, size_t frame_ints, int F) {
+    const int tiles = ((X + TC - 1) / TC) * ((Y + TR - 1) / TR);
+    return time_us([&] { temporal_fill<TR, TC><<<tiles, 256>>>(d, X, Y, frame_ints, F); }, 30);
+}
+
+int main(int argc, char** argv) {
+    // optional argument: number of frames (default 64 = 531 MB; 299 = 2.5 GB, far beyond the 256 MB Infinity Cache)
+    const int X = 1920, Y = 1080, F = argc > 1 ? atoi(argv[1]) : 64;
     const size_t frame_ints = (size_t)X * Y, bytes = frame_ints * 4 * F, n16 = bytes / 16;
     u32x4 *d, *s;
     CK(hipMalloc(&d, bytes)); CK(hipMalloc(&s, bytes));
     CK(hipMemset(s, 1, bytes));
     const int nblocks = (X / 4) * (Y / 4);
-    printf("buffer %.1f MB (64 frames 1920x1080 RGB32)\n", bytes / 1e6);
+    printf("buffer %.1f MB (%d frames 1920x1080 RGB32)\n", bytes / 1e6, F);
     for (int grid : {2048, 8192, 32768, (int)((n16 + 255) / 256)}) {
         double t1 = time_us([&] { fill16<false><<<grid, 256>>>(d, n16, 7); }, 50);
         double t2 = time_us([&] { fill16<true><<<grid, 256>>>(d, n16, 7); }, 50);
@@ -139,6 +187,30 @@ int main() {
         double f = time_us([&] { fill_blocks_rowsplit<<<dim3((nblocks + 63) / 64, F), 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints); }, 50);
         double g2 = time_us([&] { fill_blocks_rowsplit2<<<dim3((nblocks + 127) / 128, F), 256>>>((uint32_t*)d, nblocks, X / 4, X, frame_ints); }, 50);
         printf("F block-shaped 1 store/lane (wave = row) %7.1f us %6.0f GB/s | G 2 stores/lane %7.1f us %6.0f GB/s\n", f, bytes / f / 1e3, g2, bytes / g2 / 1e3);
+    }
+    {
+        struct { const char* name; double us; int wgs; } r[] = {
+            {"16 rows x 64 px (1 store/lane)", run_temporal<16, 64>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"4 rows x 256 px (1 store/lane, wave = 1 KiB row)", run_temporal<4, 256>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"1 row x 1024 px (1 store/lane)", run_temporal<1, 1024>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"8 rows x 256 px (2 stores/lane)", run_temporal<8, 256>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"16 rows x 256 px (4 stores/lane)", run_temporal<16, 256>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"32 rows x 64 px (2 stores/lane)", run_temporal<32, 64>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"64 rows x 64 px (4 stores/lane)", run_temporal<64, 64>((uint32_t*)d, X, Y, frame_ints, F), 0},
+            {"4 rows x 1024 px (4 stores/lane)", run_temporal<4, 1024>((uint32_t*)d, X, Y, frame_ints, F), 0},
+        };
+        {
+            std::vector<uint32_t*> h(F);
+            for (int f = 0; f < F; ++f) h[f] = (uint32_t*)d + (size_t)f * frame_ints;
+            uint32_t** dt;
+            CK(hipMalloc(&dt, sizeof(uint32_t*) * F));
+            CK(hipMemcpy(dt, h.data(), sizeof(uint32_t*) * F, hipMemcpyHostToDevice));
+            const int tiles = ((X + 63) / 64) * ((Y + 15) / 16);
+            double us = time_us([&] { temporal_fill_lds_table<<<tiles, 256>>>(dt, X, Y, F); }, 30);
+            printf("temporal 16 rows x 64 px, frame pointers from an LDS table: %7.1f us %6.0f GB/s\n", us, bytes / us / 1e3);
+        }
+        printf("temporal tile fill, all frames written by long-lived workgroups (one tile each, frame after frame):\n");
+        for (auto& e : r) printf("  %-52s %7.1f us %6.0f GB/s\n", e.name, e.us, bytes / e.us / 1e3);
     }
     double t7 = time_us([&] { (void)hipMemsetAsync(d, 0, bytes, 0); }, 20);
     double t8 = time_us([&] { (void)hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0); }, 20);
