@@ -741,7 +741,7 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
                                                               const uint32_t* __restrict__ prev,
                                                               const PBlock* __restrict__ blocks,
                                                               const uint32_t* __restrict__ payload, int X, int Y, int nbx,
-                                                              int vec, int chunk_frames, int literal_words) {
+                                                              int vec, int chunk_frames, int literal_words, int stagger) {
     // LDS: [slots: chunk_frames x 80 B][lit_at: chunk_frames x 4 words][lits: literal_words][s_fit]
     extern __shared__ __align__(16) uint32_t group_lds[];
     GroupSlot* slots = reinterpret_cast<GroupSlot*>(group_lds);
@@ -776,6 +776,12 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
     int f0 = 0;
     while (f0 < nframes) {
         int nf = nframes - f0 < chunk_frames ? nframes - f0 : chunk_frames;
+        // the first chunk is shortened by a per-workgroup amount, so that workgroups do not all stop storing at
+        // the same time to stage their next chunk (the staging loads wait for the store queue to drain)
+        if (f0 == 0 && stagger) {
+            const int first = 1 + (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)chunk_frames);
+            nf = nf < first ? nf : first;
+        }
         __syncthreads();                      // the previous chunk's slots and literals are no longer read
         for (int t = threadIdx.x; t < nf * 5; t += PWG) {
             const int f = t / 5, k = t - f * 5;
@@ -1019,9 +1025,10 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     // occupancy and longer staging stalls).  JSP_SP_GROUP_CHUNK / JSP_SP_GROUP_LITERALS: tuning knobs.
     static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 16; }();
     static const int lit_words = [] { const char* e = getenv("JSP_SP_GROUP_LITERALS"); const int v = e ? atoi(e) : 0; return v >= GROUP_LITERALS_MIN && v <= 8192 ? v : GROUP_LITERALS_MIN; }();
+    static const int stagger = [] { const char* e = getenv("JSP_SP_GROUP_STAGGER"); return e ? atoi(e) : 1; }();
     const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 16;
     hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
-                       reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec, chunk, lit_words);
+                       reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec, chunk, lit_words, stagger);
 }
 
 }  // namespace jsp::sp
