@@ -164,7 +164,10 @@ struct SpCodec : jsp_codec {
                     group_dsts.clear();
                     if (fuse_inter && fo.motion_pixels * 4 <= npx && blocks.size() < (1u << 31) && payload.size() < (1u << 31)) {
                         host.literalise_motion(fo);
-                        if (st->ops.empty() || st->ops.back().kind != SpStaged::Op::InterGroup)
+                        // (the group kernel relies on the block tables of a group's frames following each other)
+                        const bool extend = !st->ops.empty() && st->ops.back().kind == SpStaged::Op::InterGroup &&
+                                            (size_t)gframes.back().block_off + fo.blocks.size() == blocks.size();
+                        if (!extend)
                             st->ops.push_back({SpStaged::Op::InterGroup, (int)gframes.size(), 0, 0, false, nullptr, prev_dev, 0, 0});
                         st->ops.back().count++;
                         gframes.push_back({f.dst, (uint32_t)blocks.size(), (uint32_t)payload.size()});

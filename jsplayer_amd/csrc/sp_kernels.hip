@@ -742,12 +742,13 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
                                                               const PBlock* __restrict__ blocks,
                                                               const uint32_t* __restrict__ payload, int X, int Y, int nbx,
                                                               int vec, int chunk_frames, int literal_words, int stagger) {
-    // LDS: [slots: chunk_frames x 80 B][lit_at: chunk_frames x 4 words][lits: literal_words][s_fit]
+    // LDS: [slots: chunk_frames x 80 B][lit_at: chunk_frames x 4 words][lits: literal_words][wave_tot 4][wave_over 4]
     extern __shared__ __align__(16) uint32_t group_lds[];
     GroupSlot* slots = reinterpret_cast<GroupSlot*>(group_lds);
     uint32_t* lit_at = group_lds + (size_t)chunk_frames * (sizeof(GroupSlot) / 4);   // where in `lits` the rectangle of (frame, block) starts
     uint32_t* lits = lit_at + (size_t)chunk_frames * 4;
-    int& s_fit = *reinterpret_cast<int*>(lits + literal_words);   // frames of the chunk whose literals fit
+    uint32_t* wave_tot = lits + literal_words;       // 4 words
+    int* wave_over = reinterpret_cast<int*>(wave_tot + 4);   // 4 words
     const int ly = threadIdx.x >> 4;
     const int chunk = threadIdx.x & 15;
     const int kb = chunk >> 2;                // which of the workgroup's 4 blocks
@@ -783,38 +784,53 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
             nf = nf < first ? nf : first;
         }
         __syncthreads();                      // the previous chunk's slots and literals are no longer read
+        // one round trip: the frames' destinations / literal bases and the records of this workgroup's blocks (the
+        // block tables of a group's frames follow each other in memory: PGroupFrame::block_off advances by nblocks)
+        const uint32_t block_off0 = frames[0].block_off, nblocks_frame = (uint32_t)nbx * (uint32_t)gridDim.y;
         for (int t = threadIdx.x; t < nf * 5; t += PWG) {
             const int f = t / 5, k = t - f * 5;
-            const PGroupFrame gf = frames[f0 + f];
             if (k < 4) {
                 PBlock pb{};
-                if (k < nb_here) pb = blocks[(size_t)gf.block_off + (size_t)by * nbx + blockIdx.x * 4 + k];
+                if (k < nb_here)
+                    pb = blocks[(size_t)block_off0 + (size_t)(f0 + f) * nblocks_frame + (size_t)by * nbx + blockIdx.x * 4 + k];
                 slots[f].pb[k] = pb;
             } else {
+                const PGroupFrame gf = frames[f0 + f];
                 slots[f].dst = reinterpret_cast<uint32_t*>(gf.dst);
                 slots[f].payload_off = gf.payload_off;
             }
         }
         __syncthreads();
-        // where each changed rectangle's literals go in `lits`, and how many frames fit (serial: <= 4 * 96 steps)
-        if (threadIdx.x == 0) {
-            uint32_t used = 0;
-            int fit = 0;
-            for (; fit < nf; ++fit) {
-                uint32_t need = 0, at[4];
-                for (int k = 0; k < 4; ++k) {
-                    const PBlock& pb = slots[fit].pb[k];
-                    at[k] = used + need;
-                    if (pb.flags & PB_DATA) need += (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
-                }
-                if (used + need > (uint32_t)literal_words && fit > 0) break;   // (one frame always fits: <= 1024 words)
-                for (int k = 0; k < 4; ++k) lit_at[fit * 4 + k] = at[k];
-                used += need;
+        // where each changed rectangle's literals go in `lits`, and how many frames fit: exclusive prefix sum over the
+        // (frame, block) items — one item per lane (chunk_frames <= 64), wave scans joined through LDS
+        {
+            const int item = threadIdx.x;             // = frame * 4 + block
+            uint32_t need = 0;
+            if (item < nf * 4) {
+                const PBlock pb = slots[item >> 2].pb[item & 3];
+                if (pb.flags & PB_DATA) need = (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
             }
-            s_fit = fit;
+            uint32_t incl = need;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int w2 = 0; w2 < wave; ++w2) base += wave_tot[w2];
+            const uint32_t excl = base + incl - need;
+            if (item < nf * 4) lit_at[item] = excl;
+            // a frame fits if the literals up to and including its last block do; frame 0 always does (<= 1024 words)
+            const bool over = item < nf * 4 && (item & 3) == 3 && base + incl > (uint32_t)literal_words && item >= 4;
+            const unsigned long long m = __ballot(over);
+            if (lane == 0) wave_over[wave] = m ? (wave * 64 + __ffsll((long long)m) - 1) >> 2 : 0x7FFFFFFF;
+            __syncthreads();
+            int fit = nf;
+            for (int w2 = 0; w2 < 4; ++w2) fit = wave_over[w2] < fit ? wave_over[w2] : fit;
+            nf = fit;
         }
-        __syncthreads();
-        nf = s_fit;
         // fetch the literals: wave k takes block k's rectangles, lanes run along the rectangle's pixels
         for (int f = 0; f < nf; ++f) {
             const PBlock pb = slots[f].pb[wave];
@@ -1021,12 +1037,15 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     const int vec = ((g.X & 3) == 0 && aligned16 && (reinterpret_cast<uintptr_t>(prev) & 15) == 0) ? 1 : 0;
     dim3 grid((g.nbx + 3) / 4, g.nby);
     // A chunk of 16 frames and 1024 literal words is 5.6 KB of LDS per workgroup.  Measured on one box, 299
-    // 1080p frames: chunk 8 / 16 / 32 / 64 / 160 frames -> 650 / 643 / 668 / 733 / 780 us (larger chunks cost
-    // occupancy and longer staging stalls).  JSP_SP_GROUP_CHUNK / JSP_SP_GROUP_LITERALS: tuning knobs.
-    static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 16; }();
+    // 1080p frames: chunk 16 / 32 / 64 frames -> 625 / 647 / 712 us (627 us with 64 frames and 2048 literal
+    // words).  With the block records withheld (every block "unchanged", nothing staged but the destinations)
+    // the same loop takes 483 us — the temporal fill ceiling — so the ~8 % of read traffic (records and literal
+    // pixels, many small requests issued by few lanes between store bursts) costs ~25 % of the time.
+    // JSP_SP_GROUP_CHUNK (<= 64) / JSP_SP_GROUP_LITERALS: tuning knobs.
+    static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();
     static const int lit_words = [] { const char* e = getenv("JSP_SP_GROUP_LITERALS"); const int v = e ? atoi(e) : 0; return v >= GROUP_LITERALS_MIN && v <= 8192 ? v : GROUP_LITERALS_MIN; }();
     static const int stagger = [] { const char* e = getenv("JSP_SP_GROUP_STAGGER"); return e ? atoi(e) : 1; }();
-    const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 16;
+    const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 32;
     hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
                        reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec, chunk, lit_words, stagger);
 }
