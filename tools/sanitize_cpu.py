@@ -24,6 +24,7 @@ for version in (2, 3, 4):
     for (w, h) in [(64, 48), (100, 52), (37, 23), (320, 240)]:
         chunks, keys, frames = sg.sp_clip(8000 + version, w, h, 6, version=version, flat_at=(3,), unchanged_at=(2,))
         host = hs.HostStage(w, h, 24); host.preinit(36)
+        host.set_iframe_layout([0, 5, 24][version - 2], [0, 256, 512][version - 2])   # row-major / tile layouts
         o = OracleScreenPressor(w, h, 24); o.Preinit(36)
         bufs = [np.zeros(w * h, np.int32) for _ in range(3)]
         seq = list(zip(chunks, keys))
@@ -42,7 +43,9 @@ for version in (2, 3, 4):
                 (o.DecompressI if key else o.DecompressP)(c, dst)
             except OracleAbort:
                 pass
-            host.decode(key, c)
+            d = host.decode(key, c)
+            if d["kind"] == hs.KIND_INTER:
+                host.literalise_motion(d)
             n += 1
 for bits in (16, 8):
     for (w, h) in [(16, 8), (37, 23), (64, 48)]:
