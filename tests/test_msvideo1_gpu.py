@@ -39,8 +39,11 @@ def make_gpu(bits, w, h, pal=None):
     return c
 
 
-def dev_buf(n, fill=0):
+def dev_buf(n, fill=0, misalign=False):
+    """A device frame buffer; `misalign`: a view that starts 4 bytes into its allocation (not 16-byte aligned)."""
     torch = torch_mod()
+    if misalign:
+        return torch.full((n + 4,), fill, dtype=torch.int32, device="cuda")[1:1 + n]
     return torch.full((n,), fill, dtype=torch.int32, device="cuda")
 
 
@@ -64,7 +67,7 @@ def test_known_answers_host_buffers(kat):
     run_kat(make_gpu, lambda n, fill: np.full(n, fill, dtype=np.int32), to_np, kat)
 
 
-def drive_pair(bits, w, h, frames, keys, pal, lines=36, nbuf=3, host=False, prefill=0x00A5A5A5):
+def drive_pair(bits, w, h, frames, keys, pal, lines=36, nbuf=3, host=False, prefill=0x00A5A5A5, misalign=False):
     """Feed the same clip to the oracle and to the HIP path with Manager's buffer protocol and
     compare everything observable after every frame."""
     orc = OracleMSVideo1(bits, w, h, pal)
@@ -72,7 +75,7 @@ def drive_pair(bits, w, h, frames, keys, pal, lines=36, nbuf=3, host=False, pref
     orc.Preinit(lines)
     gpu.Preinit(lines)
     obufs = [np.full(w * h, prefill, dtype=np.int32) for _ in range(nbuf)]
-    gbufs = [np.full(w * h, prefill, dtype=np.int32) if host else dev_buf(w * h, prefill) for _ in range(nbuf)]
+    gbufs = [np.full(w * h, prefill, dtype=np.int32) if host else dev_buf(w * h, prefill, misalign) for _ in range(nbuf)]
     for i, (src, key) in enumerate(zip(frames, keys)):
         oprev, gprev = orc.PreviousFrame(), gpu.PreviousFrame()
         oi = next(k for k in range(nbuf) if obufs[k] is not oprev)
@@ -271,3 +274,33 @@ def test_degenerate_and_4k_sizes(size):
     w, h = size
     frames, keys, pal = sg.msv1_clip(90, w, h, 3, p_mix=sg.msv1_p_mix(0.5, 30.0))
     drive_pair(16, w, h, frames, keys, pal)
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_frame_buffers_that_are_not_16_byte_aligned(bits):
+    """Caller buffers only have to be int32 arrays: a view 4 bytes into an allocation takes the scalar-store
+    instantiations of the block kernel (and one launch per frame for inter frames)."""
+    for (w, h) in [(64, 48), (320, 240)]:
+        frames, keys, pal = sg.msv1_clip(7300 + bits, w, h, 8, bits=bits, p_mix=sg.msv1_p_mix(0.6, 8.0))
+        drive_pair(bits, w, h, frames, keys, pal, misalign=True)
+        # and as one staged batch
+        gpu = make_gpu(bits, w, h, pal)
+        gpu.Preinit(36)
+        dsts = [dev_buf(w * h, -1, misalign=True) for _ in frames]
+        st = gpu.stage_batch(frames, dsts, is_key=keys)
+        st.decode()
+        gpu.sync()
+        orc = OracleMSVideo1(bits, w, h, pal)
+        orc.Preinit(36)
+        obufs = [np.full(w * h, -1, dtype=np.int32) for _ in frames]
+        for i, (f, k) in enumerate(zip(frames, keys)):
+            if k:
+                orc.DecompressI(f, obufs[i])
+            else:
+                orc.DecompressP(f, obufs[i])
+        _, adopted, _ = st.results()
+        for i in range(len(frames)):
+            if adopted[i]:
+                assert np.array_equal(to_np(dsts[i]), obufs[i]), (bits, w, h, i)
+        st.close()
+

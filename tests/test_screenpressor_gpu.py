@@ -11,8 +11,11 @@ from oracle_binding import OracleAbort, OracleScreenPressor
 pytestmark = pytest.mark.gpu
 
 
-def dev_buf(n, fill=0):
+def dev_buf(n, fill=0, misalign=False):
+    """A device frame buffer; `misalign`: a view that starts 4 bytes into its allocation (not 16-byte aligned)."""
     import torch
+    if misalign:
+        return torch.full((n + 4,), fill, dtype=torch.int32, device="cuda")[1:1 + n]
     return torch.full((n,), fill, dtype=torch.int32, device="cuda")
 
 
@@ -20,14 +23,14 @@ def to_np(t):
     return t.cpu().numpy() if hasattr(t, "cpu") else t
 
 
-def drive_pair(w, h, bpp, chunks, keys, frames=None, lines=36, nbuf=3, host=False, band_rows=None):
+def drive_pair(w, h, bpp, chunks, keys, frames=None, lines=36, nbuf=3, host=False, band_rows=None, misalign=False):
     orc, gpu = OracleScreenPressor(w, h, bpp), ScreenPressor(w, h, bpp)
     orc.Preinit(lines)
     gpu.Preinit(lines)
     if band_rows is not None:
         gpu.set_option("sp_band_rows", str(band_rows))
     obufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) for _ in range(nbuf)]
-    gbufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) if host else dev_buf(w * h, 0x00A5A5A5) for _ in range(nbuf)]
+    gbufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) if host else dev_buf(w * h, 0x00A5A5A5, misalign) for _ in range(nbuf)]
     for i, (src, key) in enumerate(zip(chunks, keys)):
         oprev, gprev = orc.PreviousFrame(), gpu.PreviousFrame()
         oi = next(k for k in range(nbuf) if obufs[k] is not oprev)
@@ -81,6 +84,28 @@ def test_key_frame_bands(size, band_rows):
     w, h = size
     chunks, keys, frames = sg.sp_clip(990, w, h, 7, version=4, key_every=3, flat_at=(4,), rects=40, gradients=10)
     drive_pair(w, h, 24, chunks, keys, frames, band_rows=band_rows)
+
+
+@pytest.mark.parametrize("size", [(64, 48), (320, 240), (100, 52)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_frame_buffers_that_are_not_16_byte_aligned(size):
+    """Caller buffers only have to be int32 arrays: a view 4 bytes into an allocation routes key frames to the
+    row-major layout and the per-lane-search kernel, inter frames to the scalar-store paths — per call and as a
+    staged batch with fused inter frames."""
+    w, h = size
+    chunks, keys, frames = sg.sp_clip(993, w, h, 9, version=4, key_every=5, unchanged_at=(2,))
+    drive_pair(w, h, 24, chunks, keys, frames, misalign=True)
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    dsts = [dev_buf(w * h, -1, misalign=True) for _ in range(9)]
+    assert all(d.data_ptr() % 16 == 4 for d in dsts)
+    st = gpu.stage_batch(chunks, dsts, is_key=keys)
+    st.decode()
+    gpu.sync()
+    _, adopted, _ = st.results()
+    for i, (d, img) in enumerate(zip(dsts, frames)):
+        if adopted[i]:
+            assert np.array_equal(to_np(d).view(np.uint32), img), f"frame {i}"
+    st.close()
 
 
 def test_noise_key_frame_rows_with_more_runs_than_the_tile_window():
