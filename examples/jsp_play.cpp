@@ -1,0 +1,168 @@
+// Manager.worker-equivalent decode loop in plain C++ over the C ABI: no Python, no torch —
+// what a native host (or an hxcpp build of the player) would do with libjsplayer_amd.so.
+//
+//   jsp_play clip.avi            prints one line per frame:  index key|inter slot significant crc32
+//
+// It restates, in this project's own words, only what touches the codec:
+//   * the container facts that select and feed it (AVIParser.hx:42-88,142-171; ParserUtils.hx:24-27):
+//     avih size / rate, strh fourcc, strf depth + palette, `00dc`/`00db` chunks of LIST movi padded to even size;
+//   * the frame-buffer pool of NUM_BUFFERS + 1 device frames that never hands out the buffer holding the
+//     previous frame (Manager.hx:114-118,424-443,470-477);
+//   * the DecompressI / DecompressP protocol with its identity test (Manager.hx:499-524) and
+//     frames_differ_significantly for key frames (Manager.hx:392-421) on the GPU (jsp_frames_differ).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jsplayer_amd.h"
+
+namespace {
+constexpr int kInsignificantLines = 36;   // Manager.hx:61
+constexpr int kNumBuffers = 8;            // Main.hx:148
+
+uint32_t le32(const uint8_t* p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+uint32_t crc32(const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    if (!table[1])
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = c & 1 ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+struct Clip {
+    int X = 0, Y = 0, bpp = 32, kind = JSP_CODEC_SCREENPRESSOR;
+    std::vector<uint8_t> palette;
+    std::vector<std::pair<size_t, size_t>> frames;   // offset, padded size inside `bytes`
+    std::vector<uint8_t> bytes;
+};
+
+bool is_msvc(const uint8_t* f) {
+    return !std::memcmp(f, "MSVC", 4) || !std::memcmp(f, "msvc", 4) || !std::memcmp(f, "CRAM", 4) || !std::memcmp(f, "\0\0\0\0", 4);
+}
+
+void walk(Clip& c, size_t lo, size_t hi, bool in_movi, uint8_t (&fourcc)[4], bool& video_stream, bool& have_video) {
+    const uint8_t* d = c.bytes.data();
+    for (size_t pos = lo; pos + 8 <= hi;) {
+        const uint8_t* tag = d + pos;
+        const size_t size = le32(d + pos + 4), body = pos + 8, padded = (size + 1) & ~size_t(1);
+        if (!std::memcmp(tag, "LIST", 4)) {
+            const bool movi = !std::memcmp(d + body, "movi", 4);
+            walk(c, body + 4, std::min(body + size, hi), in_movi || movi, fourcc, video_stream, have_video);
+        } else if (!std::memcmp(tag, "avih", 4)) {
+            c.X = (int)le32(d + body + 32);
+            c.Y = (int)le32(d + body + 36);
+        } else if (!std::memcmp(tag, "strh", 4)) {
+            video_stream = !std::memcmp(d + body, "vids", 4) && !have_video;
+            if (video_stream) std::memcpy(fourcc, d + body + 4, 4);
+        } else if (!std::memcmp(tag, "strf", 4) && video_stream) {
+            c.bpp = d[body + 14] | d[body + 15] << 8;
+            const uint8_t* f = std::memcmp(fourcc, "\0\0\0\0", 4) ? fourcc : d + body + 16;
+            if (is_msvc(f)) c.kind = c.bpp == 8 ? JSP_CODEC_MSVIDEO1_8 : JSP_CODEC_MSVIDEO1_16;
+            if (c.bpp == 8 && padded > 40) c.palette.assign(d + body + 40, d + body + padded);
+            video_stream = false;
+            have_video = true;
+        } else if (in_movi && (!std::memcmp(tag, "00dc", 4) || !std::memcmp(tag, "00db", 4))) {
+            c.frames.emplace_back(body, std::min(padded, c.bytes.size() - body));
+        }
+        pos = body + padded;
+    }
+}
+
+bool load(const char* path, Clip& c) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    c.bytes.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n > 12 && std::fread(c.bytes.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    if (!ok || std::memcmp(c.bytes.data(), "RIFF", 4) || std::memcmp(c.bytes.data() + 8, "AVI ", 4)) return false;
+    uint8_t fourcc[4] = {0, 0, 0, 0};
+    bool video_stream = false, have_video = false;
+    walk(c, 12, std::min(c.bytes.size(), (size_t)8 + le32(c.bytes.data() + 4)), false, fourcc, video_stream, have_video);
+    return c.X > 0 && c.Y > 0;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi\n", argv[0]); return 2; }
+    Clip clip;
+    if (!load(argv[1], clip)) { std::fprintf(stderr, "%s: not a RIFF/AVI file this player understands\n", argv[1]); return 2; }
+    jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
+                                      (int)clip.palette.size(), 0);
+    if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return 1; }
+    jsp_preinit(dec, kInsignificantLines);
+    jsp_pool* pool = jsp_pool_create(0, clip.X, clip.Y, kNumBuffers + 1);
+    if (!pool) { std::fprintf(stderr, "jsp_pool_create: %s\n", jsp_last_error()); return 1; }
+    const int nbuf = jsp_pool_count(pool);
+    const size_t npx = (size_t)clip.X * clip.Y;
+    std::vector<long> first(nbuf, -1), last(nbuf, -1);   // frames each slot currently shows (-1: free)
+    std::vector<int32_t> host(npx);
+    const uint8_t* prev_key = nullptr;
+    size_t prev_key_len = 0;
+    bool last_was_key = false;
+    int rc = 0;
+    for (size_t i = 0; i < clip.frames.size(); ++i) {
+        const uint8_t* src = clip.bytes.data() + clip.frames[i].first;
+        const size_t len = clip.frames[i].second;
+        const bool key = i == 0 || jsp_is_key_frame(dec, src, len);          // DataLoaderAVISeq.hx:45
+        int32_t* prev = jsp_previous_frame(dec);
+        int prev_slot = -1, slot = -1;
+        for (int k = 0; k < nbuf; ++k) if (prev && jsp_pool_buffer(pool, k) == prev) prev_slot = k;
+        {   // a free slot, else the one showing the oldest frames already behind the frame of interest
+            long oldest = 1L << 60;
+            int victim = -1;
+            for (int k = 0; k < nbuf && slot < 0; ++k) {
+                if (k == prev_slot) continue;
+                if (first[k] < 0) slot = k;
+                else if (last[k] < (long)i && first[k] < oldest) { oldest = first[k]; victim = k; }
+            }
+            if (slot < 0) { slot = victim; if (slot >= 0) first[slot] = last[slot] = -1; }
+        }
+        if (slot < 0) { std::fprintf(stderr, "no free frame buffer\n"); rc = 1; break; }
+        int32_t* dst = jsp_pool_buffer(pool, slot);
+        int shown = slot, signif = -1;
+        if (key) {
+            const int state = jsp_decompress_i(dec, src, len, dst);
+            if (state != JSP_ZERO_STATE) { std::printf("%zu key error %d %s\n", i, state, jsp_last_error()); last_was_key = true; continue; }
+            first[slot] = last[slot] = (long)i;
+            if (i == 0) signif = 1;
+            else if (last_was_key && prev_key) signif = !(prev_key_len == len && !std::memcmp(prev_key, src, len));
+            else if (!prev) signif = 1;
+            else jsp_frames_differ(dst, prev, (size_t)kInsignificantLines * clip.X, npx, &signif, nullptr);
+            prev_key = src;
+            prev_key_len = len;
+        } else {
+            int32_t* shown_ptr = nullptr;
+            if (jsp_decompress_p(dec, src, len, dst, &shown_ptr, &signif) != 0) {
+                std::printf("%zu inter raised %s\n", i, jsp_last_error());
+                last_was_key = false;
+                continue;
+            }
+            if (shown_ptr && shown_ptr == prev && prev_slot >= 0) {          // "no changes": the old slot keeps showing
+                last[prev_slot] = (long)i;
+                shown = prev_slot;
+            } else if (shown_ptr) {
+                first[slot] = last[slot] = (long)i;
+            } else
+                shown = -1;
+        }
+        last_was_key = key;
+        uint32_t crc = 0;
+        if (shown >= 0 && jsp_download(jsp_pool_buffer(pool, shown), host.data(), npx) == 0)
+            crc = crc32(reinterpret_cast<const uint8_t*>(host.data()), npx * 4);
+        std::printf("%zu %s %d %d %08x\n", i, key ? "key" : "inter", shown, signif, crc);
+    }
+    jsp_pool_destroy(pool);
+    jsp_codec_destroy(dec);
+    return rc;
+}

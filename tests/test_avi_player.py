@@ -176,3 +176,40 @@ def test_indexed_playback_matches_sequential_playback():
     assert len(shown[0]) == 9
     for a, b, f in zip(shown[0], shown[1], frames):
         assert np.array_equal(a, b) and np.array_equal(a.view(np.uint32), f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["msvc16", "msvc8", "screenpressor"])
+def test_cpp_player_over_the_c_abi(what, tmp_path):
+    """examples/jsp_play: a C++ host that links nothing but libjsplayer_amd.so (no Python, no torch) plays an AVI file
+    through the C ABI with the Manager's buffer discipline; per frame it must show what the Manager-equivalent loop
+    shows on the oracle codecs — same key flags, same pool slots, same significant_changes, same picture (CRC-32)."""
+    import os
+    import subprocess
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "jsp_play")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    if what == "screenpressor":
+        chunks, keys, _ = sg.sp_clip(31, 320, 240, 12, version=4, key_every=5, unchanged_at=(2, 7))
+        blob = avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24)
+    else:
+        bits = 16 if what == "msvc16" else 8
+        frames, pal = config0_clip(bits, 30)
+        blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=bits, palette=pal)
+    path = tmp_path / "clip.avi"
+    path.write_bytes(blob)
+    res = subprocess.run([exe, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode == 0, res.stderr.decode()
+    lines = [l.split() for l in res.stdout.decode().splitlines()]
+    vi, got = avi.read_avi(blob)
+    mgr = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
+    shown = []
+    mgr.play(got, on_frame=lambda d, buf: shown.append((d, zlib.crc32(buf.tobytes()))))
+    assert len(lines) == len(shown) == len(got)
+    for ln, (d, crc) in zip(lines, shown):
+        assert int(ln[0]) == d.index and ln[1] == ("key" if d.key else "inter"), ln
+        assert int(ln[2]) == d.buffer_index, ln
+        assert int(ln[3]) == int(bool(d.significant_changes)), ln
+        assert int(ln[4], 16) == crc, ln
