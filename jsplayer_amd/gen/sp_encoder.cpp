@@ -192,6 +192,13 @@ public:
 private:
     void push(const Interval& iv) {
         if (iv.freq == 0 || iv.freq > 4096) throw std::logic_error("bad interval");
+        // The reference's 40-entry table built from a 64-symbol list (Cx6.createFrom2, ANS.hx:494-506) assigns
+        // 256 - d + (d + 1) * f0 slots: with f0 = 64 (version 3) and d >= 60 distinct symbols before the first
+        // repeat that is more than the 4096 there are, and the symbols pushed past the end cannot be coded by
+        // any encoder (the decoder only ever sees slots 0..4095).  Version 4 halved f0.  Refuse such input.
+        if (iv.cum + iv.freq > 4096)
+            throw std::logic_error("symbol interval outside the 12-bit code space (version-3 model overflow: a colour context "
+                                   "saw 60 or more distinct values before its first repeat); this content cannot be coded as v3");
         ev_.push_back({(uint16_t)iv.cum, (uint16_t)(iv.freq == 4096 ? 0xFFFF : iv.freq), 0});
     }
     void fixed(FixedModel& m, int c) {

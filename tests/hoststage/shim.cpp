@@ -18,6 +18,7 @@ extern "C" {
 void* hs_create(int w, int h, int bpp) { return new Shim(w, h, bpp); }
 void hs_destroy(void* p) { delete (Shim*)p; }
 void hs_preinit(void* p, int lines) { ((Shim*)p)->host.preinit(lines); }
+const char* hs_error(void* p) { const char* e = ((Shim*)p)->out.error; return e ? e : ""; }
 void hs_set_band_rows(void* p, int rows) { ((Shim*)p)->host.set_band_rows(rows); }
 void hs_set_iframe_layout(void* p, int rows, int span) { ((Shim*)p)->host.set_iframe_layout(rows, span); }
 size_t hs_tile_words(void* p, int which) { const FrameOut& o = ((Shim*)p)->out; return which ? o.left.size() : o.tile_idx.size(); }

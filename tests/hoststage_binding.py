@@ -30,6 +30,8 @@ def lib():
         L.hs_decode.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]
         L.hs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hs_set_band_rows.argtypes = [C.c_void_p, C.c_int]
+        L.hs_error.restype = C.c_char_p
+        L.hs_error.argtypes = [C.c_void_p]
         L.hs_literalise_motion.argtypes = [C.c_void_p, C.c_void_p]
         L.hs_set_iframe_layout.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.hs_tile_words.restype = C.c_size_t
@@ -64,7 +66,7 @@ class HostStage:
         src = bytes(src)
         status = self.L.hs_decode(self.h, 1 if key else 0, src, len(src), meta.ctypes.data)
         m = [int(v) for v in meta]
-        out = dict(status=status, kind=m[0], adopted=bool(m[1]), significant=bool(m[2]), prev_cleared=bool(m[3]),
+        out = dict(status=status, error=self.L.hs_error(self.h).decode(), kind=m[0], adopted=bool(m[1]), significant=bool(m[2]), prev_cleared=bool(m[3]),
                    flat_colour=m[8], prev_pixels=m[9], data_pixels=m[10], stream_bytes=m[11])
         runs = np.zeros((m[4], 2), dtype=np.uint32)
         rows = np.zeros(m[5], dtype=np.uint32)

@@ -162,6 +162,19 @@ def test_motion_rectangles_as_literals(version):
     assert moved_any > 1000
 
 
+def test_generator_refuses_what_the_version_3_model_cannot_code():
+    """Found by tools/fuzz_gpu.py: with f0 = 64 (version 3) the reference's table built from a 64-symbol list
+    (Cx6.createFrom2) hands out more than 4096 slots once a colour context saw 60+ distinct values before its first
+    repeat; symbols pushed past slot 4095 cannot be coded by any encoder, so the generator must refuse such (noise)
+    content instead of emitting a stream no decoder can follow.  Version 4 (f0 = 32) codes the same images."""
+    kw = dict(p_mix_at={1: dict(unchanged=0.01, motion=0.9), 2: dict(unchanged=0.02, motion=0.3)}, noise=0.9)
+    with pytest.raises(RuntimeError, match="12-bit code space"):
+        sg.sp_clip(916177101, 2288, 192, 3, version=3, **kw)
+    chunks, keys, frames = sg.sp_clip(916177101, 2288, 192, 3, version=4, **kw)
+    got, _ = oracle_decode_clip(2288, 192, 24, chunks, keys, 36)
+    assert all(np.array_equal(g, f) for g, f in zip(got, frames))
+
+
 def test_host_stage_rejects_what_the_reference_cannot_survive():
     host = hs.HostStage(16, 16, 24)
     assert host.decode(True, bytes([0x13, 0, 0, 0]))["status"] == 2

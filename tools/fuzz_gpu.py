@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised GPU campaign for the ScreenPressor kernels: random geometry, stream version, band height, clip
+structure (key frames, flat frames, unchanged frames, light / heavy motion, noise), buffer reuse and alignment;
+every adopted frame of a staged batch must equal the image the encoder was given.
+
+    python tools/fuzz_gpu.py [seconds] [seed]        (prints one line per clip and a summary; exit 1 on mismatch)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import torch
+    from jsplayer_amd import ScreenPressor
+    from jsplayer_amd import streamgen as sg
+    rng = np.random.default_rng(seed)
+    t0, clips, frames_checked, skipped = time.time(), 0, 0, 0
+    while time.time() - t0 < budget:
+        w = int(rng.choice([int(rng.integers(4, 160)) * 4, int(rng.integers(17, 700)), int(rng.integers(64, 600)) * 4]))
+        h = int(rng.integers(9, 200))
+        version = int(rng.choice([2, 3, 4]))
+        bpp = int(rng.choice([24, 24, 16]))
+        n = int(rng.integers(3, 11))
+        key_every = int(rng.choice([0, 1, 2, 4]))
+        unchanged = tuple(int(x) for x in rng.choice(np.arange(1, n), size=min(2, n - 1), replace=False)) if rng.random() < 0.5 else ()
+        flat = (int(rng.integers(1, n)),) if rng.random() < 0.3 else ()
+        mix = {}
+        for i in range(1, n):
+            if rng.random() < 0.3:
+                m = float(rng.choice([0.1, 0.3, 0.6, 0.9]))
+                mix[i] = dict(unchanged=float(rng.uniform(0, 1 - m)), motion=m)
+        noise = float(rng.choice([0.0, 0.05, 0.3, 0.9]))
+        band = str(rng.choice(["auto", "0", str(int(rng.integers(1, 60)))]))
+        cfg = int(rng.integers(0, 1 << 30))
+        try:
+            chunks, keys, frames = sg.sp_clip(cfg, w, h, n, bpp=bpp, version=version, key_every=key_every, unchanged_at=unchanged,
+                                              flat_at=flat, p_mix_at=mix, noise=noise)
+        except RuntimeError as e:      # content the version-3 model cannot code (see sp_encoder.cpp): not a decoder matter
+            print(f"skip {w}x{h} v{version} noise={noise} cfg={cfg}: {str(e)[:60]}", flush=True)
+            skipped += 1
+            continue
+        gpu = ScreenPressor(w, h, bpp)
+        gpu.Preinit(int(rng.integers(0, 60)))
+        gpu.set_option("sp_band_rows", band)
+        if rng.random() < 0.2:
+            gpu.set_option("sp_inter_fusion", "off")
+        misalign = rng.random() < 0.2
+        def buf():
+            if misalign:
+                return torch.full((w * h + 4,), -1, dtype=torch.int32, device="cuda")[1:1 + w * h]
+            return torch.full((w * h,), -1, dtype=torch.int32, device="cuda")
+        dsts = [buf() for _ in range(n)]
+        st = gpu.stage_batch(chunks, dsts, is_key=keys)
+        st.decode()
+        gpu.sync()
+        status, adopted, _ = st.results()
+        ok = status == [0] * n
+        for i in range(n):
+            if adopted[i] and not np.array_equal(dsts[i].cpu().numpy().view(np.uint32), frames[i]):
+                ok = False
+                print(f"MISMATCH frame {i}", flush=True)
+        print(f"{'ok ' if ok else 'BAD'} {w}x{h} v{version} bpp{bpp} n={n} key_every={key_every} unchanged={unchanged} flat={flat} "
+              f"mix={sorted(mix)} noise={noise} band={band} misalign={misalign} cfg={cfg}", flush=True)
+        st.close()
+        gpu.StopAndClean()
+        if not ok:
+            return 1
+        clips += 1
+        frames_checked += sum(adopted)
+    print(f"fuzz finished: {clips} clips, {frames_checked} frames, {skipped} skipped as unencodable, {time.time() - t0:.0f} s, seed {seed}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
