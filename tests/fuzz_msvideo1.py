@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised GPU campaign for MSVideo1 against the oracle (it lives under tests/ because it uses the oracle):
+random geometry (multiples of 4 or not), depth, clip structure, skip mixes, mutated / truncated / random frames, host and
+on-GPU parse, device / host / misaligned buffers, per-call API and staged batches.  Not collected by pytest.
+
+    python tests/fuzz_msvideo1.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import test_msvideo1_gpu as T
+    from jsplayer_amd import streamgen as sg
+    from oracle_binding import OracleMSVideo1
+    rng = np.random.default_rng(seed)
+    t0, clips, nframes = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        w = int(rng.choice([int(rng.integers(1, 120)) * 4, int(rng.integers(4, 500))]))
+        h = int(rng.choice([int(rng.integers(1, 70)) * 4, int(rng.integers(4, 300))]))
+        bits = int(rng.choice([16, 8]))
+        n = int(rng.integers(2, 12))
+        p_mix = sg.msv1_p_mix(float(rng.choice([0.0, 0.3, 0.7, 0.95, 1.0])), float(rng.choice([1.5, 8.0, 40.0, 300.0])))
+        key_every = int(rng.choice([0, 1, 3, 5]))
+        cfg = int(rng.integers(0, 1 << 30))
+        frames, keys, pal = sg.msv1_clip(cfg, w, h, n, bits=bits, p_mix=None if key_every == 1 else p_mix, key_every=key_every)
+        frames = list(frames)
+        for i in range(1, n):                       # mutate some frames (never frame 0: later frames need a previous one)
+            r = rng.random()
+            b = bytearray(frames[i])
+            if r < 0.10 and b:
+                b = b[: int(rng.integers(0, len(b)))]
+            elif r < 0.20 and b:
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif r < 0.25:
+                b = bytearray(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8).tobytes())
+            elif r < 0.30:
+                b = b + b"\x07"
+            frames[i] = bytes(b)
+        mode = str(rng.choice(["host", "gpu"]))
+        host_buffers, misalign = rng.random() < 0.15, rng.random() < 0.15
+        lines = int(rng.integers(0, 60))
+        tag = f"{w}x{h} {bits}bit n={n} key_every={key_every} parse={mode} host={host_buffers} misalign={misalign} lines={lines} cfg={cfg}"
+        try:
+            drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
+        except AssertionError as e:
+            print("BAD", tag, e, flush=True)
+            return 1
+        print("ok ", tag, flush=True)
+        clips += 1
+        nframes += n
+    print(f"fuzz finished: {clips} clips, {nframes} frames, {time.time() - t0:.0f} s, seed {seed}")
+    return 0
+
+
+def drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign):
+    """test_msvideo1_gpu.drive_pair with the parse mode its make_gpu() applies."""
+    T.PARSE_MODE = mode
+    T.drive_pair(bits, w, h, frames, keys, pal, lines=lines, host=host_buffers, misalign=misalign and not host_buffers)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
