@@ -22,7 +22,7 @@ def main():
     from jsplayer_amd import ScreenPressor
     from jsplayer_amd import streamgen as sg
     rng = np.random.default_rng(seed)
-    t0, clips, frames_checked, skipped = time.time(), 0, 0, 0
+    t0, clips, frames_checked, skipped, damaged = time.time(), 0, 0, 0, 0
     while time.time() - t0 < budget:
         w = int(rng.choice([int(rng.integers(4, 160)) * 4, int(rng.integers(17, 700)), int(rng.integers(64, 600)) * 4]))
         h = int(rng.integers(9, 200))
@@ -75,7 +75,37 @@ def main():
             return 1
         clips += 1
         frames_checked += sum(adopted)
-    print(f"fuzz finished: {clips} clips, {frames_checked} frames, {skipped} skipped as unencodable, {time.time() - t0:.0f} s, seed {seed}")
+        # ---- the same clip with damaged frames through the per-call API: no parity claim on garbage (the reference
+        # raises, spins or paints noise), but nothing may fault and a fresh key frame must decode exactly again
+        if rng.random() < 0.3 and keys[0]:
+            from jsplayer_amd import CodecError
+            gpu = ScreenPressor(w, h, bpp)
+            gpu.Preinit(36)
+            bufs = [buf() for _ in range(3)]
+            pick = lambda: next(b for b in bufs if b is not gpu.PreviousFrame())
+            gpu.DecompressI(chunks[0], pick())
+            for k in range(12):
+                i = int(rng.integers(0, n))
+                b = bytearray(chunks[i])
+                r = rng.random()
+                if r < 0.35 and len(b) > 1:
+                    b = b[: int(rng.integers(1, len(b)))]
+                elif r < 0.7 and len(b) > 1:
+                    for _ in range(int(rng.integers(1, 4))):
+                        b[int(rng.integers(1, len(b)))] ^= int(rng.integers(1, 256))
+                else:
+                    b = bytearray([b[0] if b else 0x32]) + bytearray(rng.integers(0, 256, size=int(rng.integers(0, 500)), dtype=np.uint8).tobytes())
+                try:
+                    (gpu.DecompressI if keys[i] else gpu.DecompressP)(bytes(b), pick())
+                except CodecError:
+                    pass
+                damaged += 1
+            dst = pick()
+            if int(gpu.DecompressI(chunks[0], dst)) != 0 or not np.array_equal(dst.cpu().numpy().view(np.uint32), frames[0]):
+                print("BAD: no exact recovery after damaged frames", w, h, version, cfg, flush=True)
+                return 1
+            gpu.StopAndClean()
+    print(f"fuzz finished: {clips} clips, {frames_checked} frames, {skipped} skipped as unencodable, {damaged} damaged frames survived, {time.time() - t0:.0f} s, seed {seed}")
     return 0
 
 
