@@ -710,9 +710,33 @@ struct EntroANS final : EntroCoder {  // EntroCoders.hx:182-313
     int decodeMY() override { return decodeF(mvtab[1]); }
 };
 
+// Test hook (tests/test_js_semantics.py): drive the rANS state machine alone with an arbitrary list of operations, so
+// that its int32 / out-of-range-read emulation can be held against a real JS engine.
+//   op (start, freq): freq >= 0 decAdvance(start, freq); freq == -1 raw(); freq == -2 reinit()
+// out[2k] = state r after op k (raw(): the byte or -1), out[2k+1] = pos; returns the number of ops done (stops at a hang)
+int rans_trace(const uint8_t* src, size_t n, long pos0, const int32_t* ops, int nops, int64_t* out) {
+    Rans rs;
+    rs.init(ByteView{src, (long)n}, pos0);
+    int k = 0;
+    for (; k < nops; ++k) {
+        const int32_t start = ops[2 * k], freq = ops[2 * k + 1];
+        int64_t v;
+        if (freq == -1) v = rs.raw();
+        else if (freq == -2) { rs.reinit(); v = rs.r; }
+        else { rs.decAdvance(start, freq); if (rs.hung) break; v = rs.r; }
+        out[2 * k] = v;
+        out[2 * k + 1] = rs.pos;
+    }
+    return k;
+}
+
 }  // namespace
 
 std::unique_ptr<EntroCoder> make_entro_rc() { return std::make_unique<EntroRC>(); }
 std::unique_ptr<EntroCoder> make_entro_ans(int f0) { return std::make_unique<EntroANS>(f0); }
 
 }  // namespace orc
+
+extern "C" int orc_rans_trace(const uint8_t* src, size_t n, long pos0, const int32_t* ops, int nops, int64_t* out) {
+    return orc::rans_trace(src, n, pos0, ops, nops, out);
+}

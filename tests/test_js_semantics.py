@@ -140,3 +140,49 @@ def test_screenpressor_oracle_agrees_with_a_real_js_engine():
             assert which == jr["which"], where
             checked += 1
     assert checked > 1500 and aborted > 0 and hung > 0
+
+
+# ---- ScreenPressor versions 3 / 4: the rANS state machine alone ------------------------------------------------
+def test_rans_state_machine_agrees_with_a_real_js_engine():
+    """oracle/sp_entropy_oracle.cpp's Rans (int32 wrap of the seed and of `(x << 8) | byte`, reads past the end,
+    unguarded probabilities, the renormalisation that never ends) against the same machine on plain JS numbers under
+    node: states and stream positions after every operation, and where a sequence hangs."""
+    import ctypes as C
+    import oracle_binding
+    L = oracle_binding.lib()
+    L.orc_rans_trace.restype = C.c_int
+    L.orc_rans_trace.argtypes = [C.c_char_p, C.c_size_t, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(79)
+    cases = []
+    for k in range(400):
+        nbytes = int(rng.integers(0, 60))
+        data = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+        if k % 3 == 0 and nbytes >= 4:
+            data[3] |= 0x80                                   # a negative seed
+        ops = []
+        for _ in range(int(rng.integers(1, 40))):
+            r = rng.random()
+            if r < 0.1:
+                ops.append([0, -1])
+            elif r < 0.15:
+                ops.append([0, -2])
+            elif r < 0.6:                                      # what a model would hand over
+                freq = int(rng.integers(1, 4097))
+                ops.append([int(rng.integers(0, 4097 - freq)), freq])
+            else:                                              # anything
+                ops.append([int(rng.integers(-5000, 9000)), int(rng.integers(0, 5000))])
+        cases.append(dict(bytes=data.tolist(), pos=int(rng.integers(0, max(1, nbytes + 3))), ops=ops))
+    res = subprocess.run([NODE, os.path.join(HERE, "js", "rans_js_semantics.js")], input=json.dumps(cases).encode(),
+                         stdout=subprocess.PIPE, check=True, timeout=120)
+    js = json.loads(res.stdout)
+    hangs = steps = 0
+    for cs, jr in zip(cases, js):
+        ops = np.array(cs["ops"], dtype=np.int32).reshape(-1)
+        out = np.zeros(2 * len(cs["ops"]), dtype=np.int64)
+        src = bytes(cs["bytes"])
+        done = L.orc_rans_trace(src, len(src), cs["pos"], ops.ctypes.data, len(cs["ops"]), out.ctypes.data)
+        assert done == len(jr), (cs["pos"], len(cs["bytes"]), done, len(jr))
+        assert out[:2 * done].reshape(-1, 2).tolist() == jr
+        hangs += done < len(cs["ops"])
+        steps += done
+    assert steps > 4000 and hangs > 0
