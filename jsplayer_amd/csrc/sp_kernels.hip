@@ -1036,14 +1036,16 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     if (nframes <= 0) return;
     const int vec = ((g.X & 3) == 0 && aligned16 && (reinterpret_cast<uintptr_t>(prev) & 15) == 0) ? 1 : 0;
     dim3 grid((g.nbx + 3) / 4, g.nby);
-    // A chunk of 16 frames and 1024 literal words is 5.6 KB of LDS per workgroup.  Measured on one box, 299
-    // 1080p frames: chunk 16 / 32 / 64 frames -> 625 / 647 / 712 us (627 us with 64 frames and 2048 literal
-    // words).  With the block records withheld (every block "unchanged", nothing staged but the destinations)
-    // the same loop takes 483 us — the temporal fill ceiling — so the ~8 % of read traffic (records and literal
-    // pixels, many small requests issued by few lanes between store bursts) costs ~25 % of the time.
+    // A chunk of 32 frames and 2048 literal words is 11 KB of LDS per workgroup (8 workgroups per CU still fit).
+    // Same-run A/B on one box, 299 1080p frames: 16 frames / 1024 words 682 us, 32 / 2048 640 us; on another box
+    // 16 / 1024 gave 625 us, 32 / 1024 647 us (the literals no longer fit: chunks get cut short), 64 / 2048 627 us.
+    // Also measured, no gain: block records regrouped per tile so that a chunk is one contiguous read; all literal
+    // pixels of a chunk fetched by a flat index space in one round trip (3 % slower than rectangle by rectangle).
+    // With the block records withheld (every block "unchanged", nothing staged but the destinations) the same loop
+    // takes 483 us — the temporal fill ceiling; without the literal fetches 539 us.
     // JSP_SP_GROUP_CHUNK (<= 64) / JSP_SP_GROUP_LITERALS: tuning knobs.
-    static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();
-    static const int lit_words = [] { const char* e = getenv("JSP_SP_GROUP_LITERALS"); const int v = e ? atoi(e) : 0; return v >= GROUP_LITERALS_MIN && v <= 8192 ? v : GROUP_LITERALS_MIN; }();
+    static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 32; }();
+    static const int lit_words = [] { const char* e = getenv("JSP_SP_GROUP_LITERALS"); const int v = e ? atoi(e) : 0; return v >= GROUP_LITERALS_MIN && v <= 8192 ? v : 2048; }();
     static const int stagger = [] { const char* e = getenv("JSP_SP_GROUP_STAGGER"); return e ? atoi(e) : 1; }();
     const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 32;
     hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
