@@ -250,6 +250,10 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                # measured HBM bytes / launch time: what the memory system really moved (temporal kernels keep pixels in
+                # registers from frame to frame, so their algorithmic rate can exceed it)
+                "traffic_rate": round(traffic / (kernel_us * 1e-6) / 1e9, 1) if traffic else None,
+                "traffic_frac": round(traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_per_launch,
                 "avg_launch_us": round(kernel_us, 2),
                 "launches_per_step": info["kernel_launches"],
