@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
                 }
 #pragma unroll
                 for (int v = 0; v < V; ++v)
-                    store4_global(dst + row0 + x0 + 4 * v, make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]));
+                    store4_global(dst + row0 + x0 + 4 * v, make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]));   // (nontemporal: same time, measured)
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) p[j] = q[j];
             }
