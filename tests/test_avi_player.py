@@ -213,3 +213,33 @@ def test_cpp_player_over_the_c_abi(what, tmp_path):
         assert int(ln[2]) == d.buffer_index, ln
         assert int(ln[3]) == int(bool(d.significant_changes)), ln
         assert int(ln[4], 16) == crc, ln
+
+
+@pytest.mark.parametrize("per_ix", [0, 4])
+def test_incremental_reader_yields_the_same_frames_however_the_bytes_arrive(per_ix):
+    """AviStream: the file fed in pieces of random size (down to one byte) gives the blobs and the VideoInfo of the
+    one-shot reader; a frame is available as soon as its chunk is complete, before the movi list ends."""
+    rng = np.random.default_rng(4)
+    frames = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in (10, 33, 0, 64, 7, 7, 128, 1, 90000, 2, 31)]
+    pal = bytes(rng.integers(0, 256, size=1024, dtype=np.uint8))
+    blob = avi.write_avi(64, 48, frames, fourcc=b"CRAM", bpp=8, palette=pal, opendml_frames_per_ix=per_ix)
+    vi, ref = avi.read_avi(blob)
+    for trial in range(25):
+        rd, got, pos, first_at = avi.AviStream(), [], 0, None
+        top = 1 if trial == 0 else int(rng.choice([3, 50, 700, 5000, 200000]))
+        while pos < len(blob):
+            n = int(rng.integers(1, top + 1))
+            got += rd.feed(blob[pos:pos + n])
+            pos += n
+            if got and first_at is None:
+                first_at = pos
+        assert got == ref and rd.info == vi and rd.frames_seen == len(ref)
+        if top <= 700:
+            assert first_at < len(blob) // 2           # frames did not wait for the end of the file
+    with pytest.raises(ValueError):
+        avi.AviStream().feed(b"RIFX" + blob[4:16])
+    # a file cut off before the pad byte of its last chunk: still every complete chunk
+    blob2 = avi.write_avi(16, 8, [b"\x01\x02\x03"])
+    cut = blob2[:blob2.index(b"idx1")]
+    cut = cut[:4] + (len(cut) - 9).to_bytes(4, "little") + cut[8:-1]
+    assert avi.AviStream().feed(cut) == avi.read_avi(cut)[1]
