@@ -243,3 +243,21 @@ def test_incremental_reader_yields_the_same_frames_however_the_bytes_arrive(per_
     cut = blob2[:blob2.index(b"idx1")]
     cut = cut[:4] + (len(cut) - 9).to_bytes(4, "little") + cut[8:-1]
     assert avi.AviStream().feed(cut) == avi.read_avi(cut)[1]
+
+
+def test_decode_while_the_file_is_still_arriving():
+    """play_incremental: pieces of the file in, pictures out — the same pictures, slots and flags as playing the
+    complete file."""
+    chunks, keys, frames = sg.sp_clip(7, 64, 48, 8, version=2, key_every=4, unchanged_at=(2,))
+    blob = avi.write_avi(64, 48, chunks, fourcc=b"SCPR", bpp=24)
+    vi, got = avi.read_avi(blob)
+    ref = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
+    ref_pics = []
+    ref.play(got, on_frame=lambda d, buf: ref_pics.append((d.index, d.key, d.buffer_index, d.significant_changes, buf.copy())))
+    pieces = [blob[i:i + 997] for i in range(0, len(blob), 997)]
+    pics = []
+    mgr = player.play_incremental(pieces, ORACLE_CLASSES, lambda n: np.zeros(n, dtype=np.int32),
+                                  on_frame=lambda d, buf: pics.append((d.index, d.key, d.buffer_index, d.significant_changes, buf.copy())))
+    assert mgr is not None and len(pics) == len(ref_pics) == 8
+    for a, b in zip(pics, ref_pics):
+        assert a[:4] == b[:4] and np.array_equal(a[4], b[4])
