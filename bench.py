@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: decoded Mpixels/s at 1920x1080 (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-Workload at every N (weak scaling): each rank owns ONE independent AVI stream — BASELINE.json
-configs[1], "MSVideo1 1920x1080 keyframe-only", 64 distinct frames of block mix M1 (25 % solid /
-50 % 2-colour / 25 % 8-colour) — already staged in HBM (stream bytes + host-built
-descriptor tables).  A "step" = one pass of the hot path over that batch: 64 frames reconstructed
-into 64 distinct RGB32 frame buffers by the HIP block kernel, through the C ABI
-(jsp_staged_decode).  Streams shard one per GPU; the only collective is the counter reduce.
+Workload at every N (weak scaling): each rank owns its own independent stream(s) — by default
+BASELINE.json configs[1], "MSVideo1 1920x1080 keyframe-only": 512 distinct frames of block mix M1 (25 % solid /
+50 % 2-colour / 25 % 8-colour) whose RAW STREAM BYTES are resident in HBM.  A "step" = one pass of
+the hot path over them: on-GPU parse + 4x4 block reconstruction into 512 distinct RGB32 frame buffers, through the
+C ABI (jsp_staged_decode).  A step reads 531 MB of stream and writes 4.2 GB of frames, so nothing a step touches
+is left in the 256 MiB Infinity Cache by the step before it.  Streams shard one per GPU; the only collective is
+the counter reduce.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
-The oracle (oracle/) is used ONLY in the cpu_baseline leg.
+After the timed region every frame the timed kernels left in HBM is compared with the CPU oracle's digest of
+the same frame (tests/golden/bench_digests.json, written by tests/golden/make_bench_digests.py): no value is
+printed on a mismatch.  A second leg times the SAME frames end to end — compressed bytes in host memory -> host
+stage -> H2D -> kernels — and reports it beside the resident-input number ("e2e").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline`, `e2e`,
+`verified`.  The oracle (oracle/) is used ONLY in the cpu_baseline leg.
 """
 from __future__ import annotations
 
@@ -26,105 +32,76 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-WORKLOADS = {
-    # name: (codec, width, height, frames per step, generator kwargs)
-    "msvideo1_16_1080p_keyframes_m1": dict(bits=16, w=1920, h=1080, frames=64, mix="m1", config_index=2),
-    "msvideo1_16_1080p_keyframes_solid": dict(bits=16, w=1920, h=1080, frames=64, mix="solid", config_index=2),
-    "msvideo1_16_1080p_keyframes_eight": dict(bits=16, w=1920, h=1080, frames=64, mix="eight", config_index=2),
-    "msvideo1_8_1080p_keyframes_m1": dict(bits=8, w=1920, h=1080, frames=64, mix="m1", config_index=2),
-    # the whole device pipeline from raw stream bytes: on-GPU parse (3 launches) + block kernel, every step
-    "msvideo1_16_1080p_keyframes_m1_gpuparse": dict(bits=16, w=1920, h=1080, frames=64, mix="m1", config_index=2, gpu_parse=True),
-    "msvideo1_16_1080p_inter70": dict(bits=16, w=1920, h=1080, frames=64, mix="m1", config_index=2, inter=0.70),
-    # BASELINE.json configs[2]: ScreenPressor 1080p I-frames (host rANS -> GPU run expansion), 64 key frames
-    "screenpressor_v4_1080p_iframes": dict(sp=True, version=4, w=1920, h=1080, frames=64, config_index=3, mode="intra"),
-    # throughput regime: 8 replicas of the 64 distinct key frames, 512 workgroups in one launch
-    "screenpressor_v4_1080p_iframes_x8": dict(sp=True, version=4, w=1920, h=1080, frames=64, config_index=3, mode="intra", replicas=8),
-    "screenpressor_v2_1080p_iframes": dict(sp=True, version=2, w=1920, h=1080, frames=64, config_index=3, mode="intra"),
-    # BASELINE.json configs[3]: ScreenPressor 1080p 300-frame clip, inter-frame kernel (frame 0 = key frame, untimed)
-    "screenpressor_v4_1080p_pclip300": dict(sp=True, version=4, w=1920, h=1080, frames=300, config_index=4, mode="inter"),
-}
 
-
-def build_clip(spec, rank):
-    from jsplayer_amd import streamgen as sg
-    if spec.get("sp"):
-        if spec["mode"] == "intra":   # every frame a key frame of its own synthetic desktop
-            chunks, keys, _ = sg.sp_clip(spec["config_index"] + 1000 * rank, spec["w"], spec["h"], spec["frames"],
-                                         version=spec["version"], key_every=1)
-        else:
-            chunks, keys, _ = sg.sp_clip(spec["config_index"] + 1000 * rank, spec["w"], spec["h"], spec["frames"],
-                                         version=spec["version"])
-        return chunks, keys, None
-    mix = {"m1": sg.MIX_M1, "solid": sg.MIX_ALL_SOLID, "eight": sg.MIX_ALL_EIGHT}[spec["mix"]]
-    p_mix = sg.msv1_p_mix(spec["inter"], 40.0) if "inter" in spec else None
-    # seeds +0..+7 for the 8-stream configuration
-    return sg.msv1_clip(spec["config_index"] + 1000 * rank, spec["w"], spec["h"], spec["frames"],
-                        bits=spec["bits"], key_mix=mix, p_mix=p_mix)
-
-
-def _oracle_stream(spec, frames, keys, pal, budget_s, max_frames, gate=None):
+def _oracle_stream(spec, clip, budget_s, max_frames, gate=None):
     """One oracle instance decoding the clip over and over for ~budget_s: (frames done, seconds).
     With `gate` (a threading.Barrier) the frame buffers are touched first and all streams start together
     (first-touch page faults of 8 threads at once would otherwise dominate a short sample)."""
     import numpy as np
     from oracle_binding import OracleMSVideo1, OracleScreenPressor
-    w, h = spec["w"], spec["h"]
-    orc = OracleScreenPressor(w, h, 24) if spec.get("sp") else OracleMSVideo1(spec["bits"], w, h, pal)
+    from jsplayer_amd.workloads import W, H
+    orc = OracleScreenPressor(W, H, 24) if spec["codec"] == "sp" else OracleMSVideo1(spec["bits"], W, H, clip.palette)
     orc.Preinit(36)
-    bufs = [np.ones(w * h, dtype=np.int32) for _ in range(2)]
+    bufs = [np.ones(W * H, dtype=np.int32) for _ in range(2)]
     if gate is not None:
         gate.wait()
     done, t0 = 0, time.perf_counter()
     while True:
-        for i, (src, key) in enumerate(zip(frames, keys)):
+        for src, key in zip(clip.frames, clip.keys):
             dst = bufs[0] if orc.PreviousFrame() is bufs[1] else bufs[1]
             if key:
                 orc.DecompressI(src, dst)
             else:
                 orc.DecompressP(src, dst)
             done += 1
+            if (done & 15) == 0 and time.perf_counter() - t0 >= budget_s:
+                return done, time.perf_counter() - t0
         el = time.perf_counter() - t0
         if el >= budget_s or done >= max_frames:
             return done, el
 
 
-def cpu_baseline(spec, frames, keys, pal, budget_s=12.0):
+def cpu_baseline(spec, clip, budget_s=12.0):
     """Oracle (C++ restatement of the Haxe reference, -O2) on the same frames: one thread, then one
     independent stream per host core (the reference's only way to use more cores)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from concurrent.futures import ThreadPoolExecutor
-    w, h = spec["w"], spec["h"]
-    done, el = _oracle_stream(spec, frames, keys, pal, budget_s, 4096)
-    ncores = max(1, min(os.cpu_count() or 1, 16))
     import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from jsplayer_amd.workloads import W, H
+    done, el = _oracle_stream(spec, clip, budget_s, 1 << 20)
+    ncores = max(1, min(os.cpu_count() or 1, 16))
     gate = threading.Barrier(ncores + 1)
     with ThreadPoolExecutor(ncores) as ex:      # the ctypes calls release the GIL
-        futs = [ex.submit(_oracle_stream, spec, frames, keys, pal, budget_s / 2, 4096, gate) for _ in range(ncores)]
+        futs = [ex.submit(_oracle_stream, spec, clip, budget_s / 2, 1 << 20, gate) for _ in range(ncores)]
         gate.wait()
         t0 = time.perf_counter()
         parts = [f.result() for f in futs]
     wall = time.perf_counter() - t0
     return {
-        "all_cores": {"value": round(sum(d for d, _ in parts) * w * h / wall / 1e6, 2), "unit": "Mpixels/s",
+        "all_cores": {"value": round(sum(d for d, _ in parts) * W * H / wall / 1e6, 2), "unit": "Mpixels/s",
                       "cores": ncores, "sample": f"{ncores} independent streams, one thread each, {wall:.1f} s"},
-        "value": round(done * w * h / el / 1e6, 2),
+        "value": round(done * W * H / el / 1e6, 2),
         "unit": "Mpixels/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{done} frames ({done // len(frames)} passes over the same {len(frames)}-frame 1920x1080 batch), "
-                  f"{el:.1f} s, oracle/ C++ restatement -O2 single thread, DecompressI/P only (entropy decode included)",
+        "sample": f"{done} frames of the workload's first clip ({len(clip.frames)} distinct 1920x1080 frames, in order), "
+                  f"{el:.1f} s, oracle/ C++ restatement -O2 single thread, DecompressI/P only (parse / entropy decode included)",
     }
 
 
 def main():
+    from jsplayer_amd import workloads as wl
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="msvideo1_16_1080p_keyframes_m1", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=wl.DEFAULT, choices=sorted(wl.WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="experiments only: the JSON line then says verified: false")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -142,41 +119,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
+    from jsplayer_amd.sharding import gather_per_rank, reduce_counters
 
-    spec = dict(WORKLOADS[args.workload])
-    if os.environ.get("JSP_BENCH_FRAMES"):          # experiment knob: another batch / clip length
-        spec["frames"] = int(os.environ["JSP_BENCH_FRAMES"])
-    w, h, nfr = spec["w"], spec["h"], spec["frames"]
-    frames, keys, pal = build_clip(spec, rank)
-    all_frames, all_keys = frames, keys
-    if spec.get("sp"):
-        codec = ScreenPressor(w, h, 24, device=local_rank)
-    else:
-        codec = (MSVideo1_16bit(w, h, device=local_rank) if spec["bits"] == 16
-                 else MSVideo1_8bit(w, h, pal, device=local_rank))
-    codec.Preinit(36)
-    if spec.get("gpu_parse"):
-        codec.set_option("msv1_parse", "gpu")
-    if spec.get("replicas"):
-        frames, keys = frames * spec["replicas"], keys * spec["replicas"]
-        nfr = len(frames)
-    if spec.get("mode") == "inter":
-        # the clip's key frame is decoded up front; the timed batch is the inter frames only
-        first = torch.empty(w * h, dtype=torch.int32, device="cuda")
-        assert codec.DecompressI(frames[0], first) == 0
-        frames, keys, nfr = frames[1:], keys[1:], nfr - 1
+    name = args.workload
+    spec = dict(wl.WORKLOADS[name])
+    W, H = wl.W, wl.H
+    nfr_override = int(os.environ["JSP_BENCH_FRAMES"]) if os.environ.get("JSP_BENCH_FRAMES") else None   # experiment knob
+    t_gen = time.perf_counter()
+    clips = wl.build_clips(name, rank, nfr_override)
+    t_gen = time.perf_counter() - t_gen
+    inter = spec.get("mode") == "inter"
+
     # a dedicated (non-null) stream: kernels and the timing events are queued on the same one
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    codec.set_stream(stream.cuda_stream)
-    if os.environ.get("JSP_BENCH_ONE_ALLOC"):   # experiment: all frame buffers carved out of one allocation
-        pool = torch.empty(nfr * w * h, dtype=torch.int32, device="cuda")
-        dsts = [pool[i * w * h:(i + 1) * w * h] for i in range(nfr)]
-    else:
-        dsts = [torch.empty(w * h, dtype=torch.int32, device="cuda") for _ in range(nfr)]
-    staged = codec.stage_batch(frames, dsts, is_key=keys)   # host parse + H2D: outside the timed region
-    info = staged.info()
+    work = wl.StagedWorkload(name, clips, device=local_rank, hip_stream=stream.cuda_stream)   # host stage + H2D: outside the timed region
+    infos, nfr, step = work.infos, work.frames_per_step, work.step
 
     def barrier():
         if distributed:
@@ -184,39 +142,84 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        staged.decode()
+        step()
     barrier()                                 # all ranks ready, device idle
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        staged.decode()
+        step()
     ev1.record(stream)
     torch.cuda.synchronize()                  # this rank's K steps are done
     elapsed = time.perf_counter() - t0
     barrier()                                 # closing bracket; the job's time is the max over ranks (below)
-    gpu_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
-    status, adopted, _ = staged.results()
-    assert all(s == 0 for s in status)
+    gpu_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream, whole timed region
+    # ---- what the timed kernels left in HBM against the oracle's digests ------------------------------------
+    verified, bad = False, []
+    if not args.no_verify and nfr_override is None:
+        gold = wl.golden_digests(name, rank)
+        if gold is None:
+            verified = "no golden digests recorded for this workload / rank"
+        else:
+            bad = work.mismatches(gold)
+            verified = not bad
+    # 2 = every frame matches, 1 = not checked, 0 = mismatch; the job's verdict is the minimum over ranks
+    ok = torch.tensor([0 if bad else (2 if verified is True else 1)], dtype=torch.int64, device="cuda")
+    if distributed:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 0:
+        if bad:
+            print(f"bench.py rank {rank}: {len(bad)} frames differ from the oracle's digests (first: clip/frame {bad[0]})", file=sys.stderr)
+        if distributed:
+            dist.destroy_process_group()
+        raise SystemExit("bench.py: decoded frames differ from the oracle: no value printed")
+
+    # ---- end to end: compressed frames in host memory -> host stage -> H2D -> kernels, same frames ------------
+    e2e = None
+    if not args.no_e2e:
+        chunk = 64
+        ncap = min(len(clips[0].frames), 256 if spec["codec"] == "msv1" else 64)   # a bounded sample of the first clip
+        codec = wl.make_codec(name, clips[0].palette, device=local_rank)
+        codec.set_stream(stream.cuda_stream)
+        fr, ky, ds = clips[0].frames[:ncap], clips[0].keys[:ncap], work.dsts[0]
+        if inter:
+            assert codec.DecompressI(fr[0], work.firsts[0]) == 0
+            fr, ky = fr[1:], ky[1:]
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for lo in range(0, len(fr), chunk):
+            st = codec.stage_batch(fr[lo:lo + chunk], ds[lo:lo + chunk], is_key=ky[lo:lo + chunk])
+            st.decode()
+            codec.sync()
+            st.close()
+        te = time.perf_counter() - te
+        e2e = {"value": round(len(fr) * W * H / te / 1e6, 1), "unit": "Mpixels/s", "frames": len(fr),
+               "ms_per_frame": round(te * 1e3 / len(fr), 4),
+               "includes": f"host stage + H2D + kernels, compressed frames in host memory, batches of {chunk} frames, one host thread"}
+        codec.StopAndClean()
 
     # trivial counter reduce over RCCL (north_star): frames and pixels decoded by the whole job,
     # time = max over ranks
-    from jsplayer_amd.sharding import reduce_counters
-    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * w * h, elapsed,
-                                                          device="cuda")
+    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * W * H, elapsed, device="cuda")
+    per_rank = gather_per_rank(nfr * args.steps, device="cuda")
 
     if rank == 0:
-        launches = info["kernel_launches"] * args.steps
-        kernel_us = gpu_ms * 1e3 / launches                   # average per launch, HIP events
-        alg_per_launch = info["algorithmic_bytes"] / info["kernel_launches"]
-        achieved = alg_per_launch / (kernel_us * 1e-6) / 1e9  # GB/s
-        traffic = None       # measured HBM bytes per launch (PMC passes kept under profiles/), if this workload has them
+        launches = sum(i["kernel_launches"] for i in infos)
+        step_us = gpu_ms * 1e3 / args.steps                      # GPU time of one step, HIP events
+        alg = sum(i["algorithmic_bytes"] for i in infos)          # SURVEY.md 8(d) formula, per step
+        moved = sum(i["moved_bytes"] for i in infos)              # what the launch plan has to move at the least
+        counted = min(alg, moved)     # reads the plan provably avoids (previous frame kept in registers) are not credited
+        achieved = counted / (step_us * 1e-6) / 1e9               # GB/s
+        kernels = work.kernels()
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_by_workload.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath):    # PMC passes kept under profiles/ (tools/pmc_traffic.sh): used only when they describe these kernels
             try:
-                traffic = json.load(open(tpath))["hbm_bytes_per_launch"].get(args.workload)
+                ent = json.load(open(tpath))["per_step"].get(name)
+                if ent and ent["kernels"] == kernels and ent["frames_per_step"] == nfr:
+                    traffic, traffic_source = ent["hbm_bytes"], ent["source"]
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs",
             "value": round(total_pixels / elapsed / 1e6, 1),
@@ -230,53 +233,58 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "verified": True if int(ok[0]) == 2 else (verified if isinstance(verified, str) else False),
             "config": {
-                "workload": args.workload,
-                "codec": f"ScreenPressor v{spec['version']}" if spec.get("sp") else f"MSVideo1_{spec['bits']}bit",
-                "frame": f"{w}x{h}",
+                "workload": name,
+                "codec": f"ScreenPressor v{spec['version']}" if spec["codec"] == "sp" else f"MSVideo1_{spec['bits']}bit",
+                "frame": f"{W}x{H}",
                 "frames_per_step": nfr,
+                "clips_per_step": len(clips),
                 "streams": args.gpus,
                 "sharding": "one independent AVI stream per GPU, no data-path collective",
-                "inputs": "host-built descriptor tables (+ MSVideo1 stream bytes) resident in HBM",
+                "inputs": ("raw stream bytes resident in HBM (on-GPU parse every step)" if spec.get("parse") == "gpu" else
+                           "host-built descriptor tables (+ MSVideo1 stream bytes) resident in HBM"),
+                "input_bytes_per_step": sum(i["stream_bytes"] if spec.get("parse") == "gpu" else i["descriptor_bytes"] + (i["stream_bytes"] if spec["codec"] == "msv1" else 0) for i in infos),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("sp_iframe_rows_reg_kernel" if spec.get("mode") == "intra" else "sp_pframe_group_kernel")
-                          if spec.get("sp") else ("msv1_parse_tiles + msv1_parse_chain + msv1_parse_emit + "
-                                                  "msv1_blocks_kernel (whole step)" if spec.get("gpu_parse")
-                                                  else ("msv1_blocks_temporal_kernel" if "inter" in spec else "msv1_blocks_kernel")),
+                "kernel": kernels,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                # measured HBM bytes / launch time: what the memory system really moved (temporal kernels keep pixels in
-                # registers from frame to frame, so their algorithmic rate can exceed it)
-                "traffic_rate": round(traffic / (kernel_us * 1e-6) / 1e9, 1) if traffic else None,
-                "traffic_frac": round(traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "algorithmic_bytes_per_launch": alg_per_launch,
-                "avg_launch_us": round(kernel_us, 2),
-                "launches_per_step": info["kernel_launches"],
+                "traffic_source": traffic_source,
+                "algorithmic_bytes_per_step": alg,
+                "moved_bytes_per_step": moved,
+                "counted": "algorithmic" if counted == alg else "moved (the plan reads the previous frame once per launch, not once per frame)",
+                "step_us": round(step_us, 2),
+                "launches_per_step": launches,
             },
             "host_stage": {
-                "parse_ms_per_step_batch": round(info["host_stage_ms"], 3),
-                "h2d_ms_per_step_batch": round(info["h2d_ms"], 3),
-                "device_parse_ms_at_staging": round(info["device_parse_ms"], 3),
-                "note": "sequential host parse + upload of one 64-frame batch; outside the timed region",
+                "host_ms_per_step_batch": round(sum(i["host_stage_ms"] for i in infos), 3),
+                "h2d_ms_per_step_batch": round(sum(i["h2d_ms"] for i in infos), 3),
+                "device_parse_ms_at_staging": round(sum(i["device_parse_ms"] for i in infos), 3),
+                "generate_s": round(t_gen, 1),
+                "note": "host stage + upload of one step's batches; outside the timed region (inside e2e)",
             },
+            "e2e": e2e,
             "total_frames": total_frames,
+            "per_rank_frames": per_rank,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, all_frames, all_keys, pal)
+            out["cpu_baseline"] = cpu_baseline(spec, clips[0])
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            if e2e:
+                out["e2e"]["vs_cpu_one_thread"] = round(e2e["value"] / out["cpu_baseline"]["value"], 2)
+                out["e2e"]["vs_cpu_all_cores"] = round(e2e["value"] / out["cpu_baseline"]["all_cores"]["value"], 2)
             try:
                 with open("/proc/cpuinfo") as f:
                     out["cpu_baseline"]["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
             except Exception:
                 pass
         print(json.dumps(out), flush=True)
-    staged.close()
-    codec.StopAndClean()
+    work.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

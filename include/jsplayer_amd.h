@@ -152,8 +152,17 @@ typedef struct jsp_staged_info {
     double host_stage_ms;      /* wall time of the host parse / entropy stage */
     double h2d_ms;             /* wall time of the uploads */
     double device_parse_ms;    /* wall time of the on-GPU parse at staging (0 with the host parser) */
+    uint64_t moved_bytes;      /* bytes the launch plan has to move through HBM at the least: every table and stream
+                                  byte read once, every destination pixel written once, the previous frame read once
+                                  per launch that carries pixels in registers from frame to frame.  Below
+                                  algorithmic_bytes for those launches (the SURVEY.md formula charges a previous-frame
+                                  read per frame), above it where host-built tables add bytes the formula leaves out. */
 } jsp_staged_info;
 int jsp_staged_get_info(const jsp_staged* s, jsp_staged_info* out);
+
+/* Names of the kernels jsp_staged_decode launches for this batch, in launch order, each name once, separated by
+ * " + " (what a rocprofv3 kernel trace of the decode shows).  Valid until the batch is destroyed. */
+const char* jsp_staged_kernels(const jsp_staged* s);
 
 /* Per-frame results of a staged batch: status[i] (DecoderState), adopted[i] (1 if dsts[i] became
  * the previous frame), significant[i] (valid after jsp_staged_decode + jsp_sync). */

@@ -33,6 +33,7 @@ class StagedInfo(C.Structure):
         ("host_stage_ms", C.c_double),
         ("h2d_ms", C.c_double),
         ("device_parse_ms", C.c_double),
+        ("moved_bytes", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "jsp_staged_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jsp_staged_destroy": (None, [C.c_void_p]),
     "jsp_staged_get_info": (C.c_int, [C.c_void_p, C.POINTER(StagedInfo)]),
+    "jsp_staged_kernels": (C.c_char_p, [C.c_void_p]),
     "jsp_staged_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "jsp_display_convert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "jsp_frames_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),

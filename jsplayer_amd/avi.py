@@ -183,14 +183,15 @@ def read_index(data: bytes) -> Optional[List[IndexEntry]]:
     return None
 
 
-def read_avi_indexed(data: bytes) -> Tuple[VideoInfo, List[bytes], List[bool]]:
+def read_avi_indexed(data: bytes) -> Tuple[VideoInfo, List[bytes], Optional[List[bool]]]:
     """Frames fetched through the index (random access, as DataLoaderAVIIndexed does) with the index's key
-    flags; an entry of size 0 is an empty frame (DataLoader.hx:389-395).  Falls back to the sequential
-    walk with key flags unknown (all False but frame 0) when there is no index."""
+    flags; an entry of size 0 is an empty frame (DataLoader.hx:389-395).  Without an index: the sequential walk,
+    and key flags None — the sequential loader takes them from the decoder, key = (first frame) or
+    decoder.IsKeyFrame(bytes) (DataLoaderAVISeq.hx:45), which is what Manager.play does when given None."""
     vi, seq_frames = read_avi(data)
     index = read_index(data)
     if index is None:
-        return vi, seq_frames, [i == 0 for i in range(len(seq_frames))]
+        return vi, seq_frames, None
     frames, keys = [], []
     for e in index:
         if e.size == 0:

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
+import weakref
 from dataclasses import dataclass
 from typing import Any, Optional, Sequence
 
@@ -85,7 +86,11 @@ class _NativeCodec:
                                              len(pal) if pal else 0, int(device))
         if not self._h:
             raise CodecError(N.last_error())
-        self._bufs = {}  # address -> caller object, to hand identical objects back
+        # address -> caller object, to hand identical objects back.  Weak: the codec keeps alive only what the
+        # reference keeps alive — the current previous frame (`_prev`) — plus the frames of live staged batches
+        # (held by the StagedBatch); a caller that allocates a fresh buffer per frame does not accumulate them here.
+        self._bufs = weakref.WeakValueDictionary()
+        self._prev = None
 
     # -- IVideoCodec ------------------------------------------------------------------------
     def Preinit(self, insignificant_lines: int) -> None:
@@ -93,8 +98,11 @@ class _NativeCodec:
             raise CodecError(N.last_error())
 
     def PreviousFrame(self):
+        return self._prev
+
+    def _track_prev(self):
         addr = self._lib.jsp_previous_frame(self._h)
-        return self._bufs.get(addr) if addr else None
+        self._prev = self._bufs.get(addr) if addr else None
 
     def IsKeyFrame(self, data) -> bool:
         keep, p, n = _src_arg(data)
@@ -110,7 +118,9 @@ class _NativeCodec:
         keep, p, n = _src_arg(src)
         addr = _frame_ptr(dst, self.X * self.Y)
         self._bufs[addr] = dst
-        return DecoderState(self._lib.jsp_decompress_i(self._h, p, n, C.c_void_p(addr)))
+        rc = self._lib.jsp_decompress_i(self._h, p, n, C.c_void_p(addr))
+        self._track_prev()
+        return DecoderState(rc)
 
     def DecompressP(self, src, dst) -> PFrameResult:
         keep, p, n = _src_arg(src)
@@ -119,10 +129,11 @@ class _NativeCodec:
         out_ptr = C.c_void_p()
         signif = C.c_int(0)
         rc = self._lib.jsp_decompress_p(self._h, p, n, C.c_void_p(addr), C.byref(out_ptr), C.byref(signif))
+        self._track_prev()
         if rc != 0:
             # the reference raises out of DecompressP here (e.g. TypeError on a null prevFrame)
             raise CodecError(N.last_error())
-        data = self._bufs.get(out_ptr.value) if out_ptr.value else None
+        data = self._prev if out_ptr.value else None   # *data_pnt is the previous frame after the call
         return PFrameResult(data, bool(signif.value))
 
     def NeedsIndex(self) -> bool:
@@ -132,7 +143,8 @@ class _NativeCodec:
         if getattr(self, "_h", None):
             self._lib.jsp_codec_destroy(self._h)
             self._h = None
-        self._bufs = {}
+        self._bufs = weakref.WeakValueDictionary()
+        self._prev = None
 
     # -- batched / resident-input extension ----------------------------------------------------
     def set_stream(self, hip_stream: Optional[int]) -> None:
@@ -164,7 +176,8 @@ class _NativeCodec:
         h = self._lib.jsp_stage_batch(self._h, n, ptrs, lens, keys, dptrs)
         if not h:
             raise CodecError(N.last_error())
-        return StagedBatch(self, h, n)
+        self._track_prev()
+        return StagedBatch(self, h, n, list(dsts))
 
     def DecompressI_batch(self, srcs: Sequence, dsts: Sequence) -> DecoderState:
         st = self.stage_batch(srcs, dsts)
@@ -187,8 +200,9 @@ class _NativeCodec:
 class StagedBatch:
     """A batch whose descriptor tables are resident in HBM (jsp_stage_batch)."""
 
-    def __init__(self, codec: _NativeCodec, handle: int, n: int):
+    def __init__(self, codec: _NativeCodec, handle: int, n: int, dsts=()):
         self._codec, self._h, self.n = codec, handle, n
+        self._dsts = dsts   # the kernels write here for as long as the batch can be decoded
 
     def decode(self) -> None:
         """Queue the reconstruction kernels (asynchronous on the codec's stream)."""
@@ -200,6 +214,10 @@ class StagedBatch:
         self._codec._lib.jsp_staged_get_info(self._h, C.byref(out))
         return out.as_dict()
 
+    def kernels(self) -> str:
+        """Names of the kernels decode() launches, " + " separated (jsp_staged_kernels)."""
+        return self._codec._lib.jsp_staged_kernels(self._h).decode()
+
     def results(self):
         st, ad, sg = (C.c_int * self.n)(), (C.c_int * self.n)(), (C.c_int * self.n)()
         self._codec._lib.jsp_staged_results(self._h, st, ad, sg)
@@ -209,6 +227,7 @@ class StagedBatch:
         if self._h:
             self._codec._lib.jsp_staged_destroy(self._h)
             self._h = None
+        self._dsts = ()
 
     def __del__(self):
         try:

@@ -19,6 +19,12 @@ struct jsp_staged {
     virtual ~jsp_staged() = default;
     virtual void decode(hipStream_t stream) = 0;  // asynchronous
     jsp_staged_info info{};
+    std::string kernels;       // jsp_staged_kernels(): names of the kernels decode() launches
+    void note_kernel(const char* name) {   // appends `name` unless it is already listed
+        if (kernels.find(name) != std::string::npos) return;
+        if (!kernels.empty()) kernels += " + ";
+        kernels += name;
+    }
     std::vector<int> status, adopted, significant;
     std::vector<int> cleared;  // frame i ended with prevFrame == null (ScreenPressor RenewI + failure)
     // significance words written by the kernels (one per frame); -1 in `significant`

@@ -155,12 +155,14 @@ void jsp_codec_destroy(jsp_codec* c) {
 }
 
 int jsp_preinit(jsp_codec* c, int lines) {
+    if (!c) { set_error("null codec"); return JSP_ERROR_OCCURED; }
     return guarded([&] { return c->preinit(lines); });
 }
 
 int32_t* jsp_previous_frame(jsp_codec* c) { return c ? c->prev_caller : nullptr; }
 
 int jsp_is_key_frame(jsp_codec* c, const uint8_t* src, size_t n) {
+    if (!c || (!src && n)) return 0;
     return guarded([&] { return c->is_key_frame(src, n); }, 0);
 }
 
@@ -242,6 +244,7 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
 }
 
 int jsp_sync(jsp_codec* c) {
+    if (!c) { set_error("null codec"); return JSP_ERROR_OCCURED; }
     return guarded([&] {
         c->activate();
         JSP_HIP(hipStreamSynchronize(c->stream));
@@ -290,6 +293,8 @@ int jsp_staged_get_info(const jsp_staged* s, jsp_staged_info* out) {
     *out = s->info;
     return 0;
 }
+
+const char* jsp_staged_kernels(const jsp_staged* s) { return s ? s->kernels.c_str() : ""; }
 
 int jsp_staged_results(jsp_staged* s, int* status, int* adopted, int* significant) {
     if (!s) return JSP_ERROR_OCCURED;

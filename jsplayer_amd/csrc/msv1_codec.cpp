@@ -390,6 +390,30 @@ struct Msv1Codec : jsp_codec {
         st->info.algorithmic_bytes = st->info.stream_bytes + 64 * st->info.units_coded + 128 * st->info.units_copied;
         // with the on-GPU parse every replay also runs tiles + chain + emit
         st->info.kernel_launches = st->groups.size() + (st->gpu_parse ? 3 : 0);
+        // what the plan moves: the stream bytes the codes occupy, the descriptor table written by the parse kernels
+        // and read by the block kernels (host-built: read only), every written block once; a previous frame is
+        // read per skipped / compared block by the per-frame kernel, once per tile by a temporal launch
+        {
+            uint64_t moved = st->info.stream_bytes * (st->gpu_parse ? 3 : 1)   // tiles + emit + blocks each read the stream
+                             + sizeof(uint32_t) * (uint64_t)geo.nblocks * nf * (st->gpu_parse ? 2 : 1);
+            for (const auto& g : st->groups) {
+                uint64_t written = 0, prev_reads = 0;
+                bool uses_prev = false;
+                for (int k = g.first; k < g.first + g.count; ++k) {
+                    if (!attr[k].noop) written += (uint64_t)geo.nblocks;
+                    uses_prev |= (h_frames[k].pad & MSV1_FRAME_USES_PREV) != 0;
+                    if (h_frames[k].pad & MSV1_FRAME_USES_PREV) prev_reads += (uint64_t)geo.nblocks;
+                }
+                moved += 64 * written + 64 * (g.temporal ? (uses_prev ? (uint64_t)geo.nblocks : 0) : prev_reads);
+            }
+            st->info.moved_bytes = moved;
+        }
+        st->kernels.clear();
+        if (st->gpu_parse) { st->note_kernel("msv1_parse_tiles"); st->note_kernel("msv1_parse_chain"); st->note_kernel("msv1_parse_emit"); }
+        for (const auto& g : st->groups) {
+            st->note_kernel(g.temporal ? "msv1_blocks_temporal_kernel" : "msv1_blocks_kernel");
+            if (g.edge_compare) st->note_kernel("msv1_edge_compare_kernel");
+        }
         st->info.host_stage_ms = now_ms() - t0 - gpu_parse_ms;
 
         if (nf) {

@@ -3,11 +3,10 @@
 // The entropy contexts are derived from reconstructed pixels (ScreenPressor.hx:274-275,462-463),
 // so the host stage keeps a shadow of the current and previous frame while it decodes symbols;
 // what it hands to the GPU is a compact description from which the frame is materialised in HBM:
-//   I-frame  : run table (8 B per run) + one row index per image row; the kernel expands the runs
-//              row by row, resolving "copy from the row above" predictors through LDS.  The frame is
-//              cut into horizontal bands, one workgroup each; the host stage — which holds every
-//              reconstructed pixel anyway — supplies the row above each band ("seed"), so bands do
-//              not wait for each other;
+//   I-frame  : run records (8 B each), cut into tiles (band of rows x 256-column span) with a per-tile row
+//              index; one wave rebuilds a tile row by row, the row above in registers.  The host stage —
+//              which holds every reconstructed pixel anyway — supplies the row above each band ("seed") and
+//              the pixel left of each span, so tiles do not wait for each other;
 //   P-frame  : one 16-byte record per 16x16 block (unchanged / motion / sub-rectangle / data) and
 //              literal pixels for the data rectangles only; the kernel copies, motion-compensates
 //              and patches against the previous frame in HBM.

@@ -193,6 +193,26 @@ struct SpCodec : jsp_codec {
         st->info.descriptor_bytes = runs.size() * sizeof(IRun) + (rows.size() + seeds.size() + tileidx.size() + left.size()) * 4 +
                                     iargs.size() * sizeof(IFrameArgs) +
                                     blocks.size() * sizeof(PBlock) + payload.size() * 4 + gframes.size() * sizeof(PGroupFrame);
+        // what the plan moves: every table read once, every frame written once, the previous frame read once per
+        // inter launch (the group kernel carries pixels in registers from frame to frame)
+        {
+            const uint64_t npx = (uint64_t)g.X * g.Y;
+            uint64_t moved = st->info.descriptor_bytes;
+            st->kernels.clear();
+            for (const auto& op : st->ops) {
+                if (op.kind == SpStaged::Op::Intra) {
+                    moved += 4 * npx * op.count;
+                    st->note_kernel(op.tiles ? "sp_iframe_tile_kernel" : "sp_iframe_rows_search_kernel");
+                } else if (op.kind == SpStaged::Op::InterGroup) {
+                    moved += 4 * npx * op.count + 4 * npx;
+                    st->note_kernel("sp_pframe_group_kernel");
+                } else {
+                    moved += 8 * npx;
+                    st->note_kernel("sp_pframe_kernel");
+                }
+            }
+            st->info.moved_bytes = moved;
+        }
         st->info.host_stage_ms = now_ms() - t0;
 
         const double t1 = now_ms();

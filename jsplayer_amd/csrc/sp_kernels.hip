@@ -1,14 +1,13 @@
 // ScreenPressor reconstruction kernels for gfx950 (MI355X).  Integer work, HBM-bound, no MFMA.
 //
-// Key frames (grid.x = frame, grid.y = band; the row above a band comes from the host stage's seed rows,
-// so bands are independent workgroups).  The run table resolves every pixel to either a constant or "the
-// pixel one row up (same column or one to the left) plus a per-run addend" (ScreenPressor.hx:242-273; the
-// gradient predictor telescopes inside a run).  Rows are produced top of the band downwards; the
-// row-to-row dependency never touches HBM.  Three kernels, picked by geometry (iframe_variant):
-//   sp_iframe_rows_reg_kernel    X % 4 == 0, X <= 4096: row above in registers, run words scattered
-//                                through LDS, one LDS-only barrier per row — the one 1080p uses;
-//   sp_iframe_rows_kernel        X % 4 == 0, X <= 8192: row above in LDS (8 pixels per lane beyond 4096);
-//   sp_iframe_rows_search_kernel any width / alignment: per-lane run search.
+// Key frames.  The run table resolves every pixel to either a constant or "the pixel one row up (same column or one
+// to the left) plus a per-run addend" (ScreenPressor.hx:242-273; the gradient predictor telescopes inside a run), so
+// the only dependency left is on the row above; the host stage cuts the frame into bands of rows and hands each band
+// the row above it ("seed"), so bands are independent.  Two kernels:
+//   sp_iframe_tile_kernel        X % 4 == 0, 16-byte aligned frame buffers (every real frame): one WAVE per tile
+//                                (band x 256-column span), row above in registers, run words scattered through a
+//                                wave-private LDS row, no barrier at all;
+//   sp_iframe_rows_search_kernel any width / alignment: one workgroup per band, per-lane run search, row above in LDS.
 // Inter frames:
 //   sp_pframe_kernel             one frame: a workgroup covers 4 horizontally adjacent 16x16 blocks (256
 //                                contiguous bytes per row), lane = 16-byte chunk of a row: unchanged / base
@@ -173,339 +172,10 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     }
 }
 
-// Fast path (X a multiple of 4, X <= PPL*WG): no per-pixel search at all.
-//   scatter : one lane per run writes (run index + 1) at the run's first column of the row — and at
-//             every wave boundary (64*PPL pixels) the run covers — into a zeroed "head" row in LDS;
-//   resolve : a lane reads the PPL heads of its pixels, takes the running maximum (heads grow with the
-//             column), and gets the carry from the nearest lower lane that saw a head through one
-//             ballot + one cross-lane read; the first lane of every wave always sees a head.
-// The scatter for row y+1 does not depend on row y's pixels, so it is issued before the single
-// end-of-row barrier: one barrier and a handful of LDS round trips per image row.  PPL = 4 pixels per lane
-// is the faster setting wherever it fits (more waves to overlap each wave's serial row step); PPL = 8
-// serves rows wider than 4096 pixels.
-template <int WG, int PPL>
-__global__ __launch_bounds__(WG) void sp_iframe_rows_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
-                                                            int run_cap, int band_rows) {
-    static_assert(PPL == 4 || PPL == 8, "4 or 8 pixels per lane");
-    constexpr int V = PPL / 4;                    // uint4 vectors per lane
-    constexpr uint32_t WAVE_PX = 64 * PPL;        // pixels one wave covers
-    extern __shared__ __align__(16) uint32_t lds[];
-    const IFrameArgs fa = args[blockIdx.x];
-    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
-    const int tid = threadIdx.x;
-    const int yb = (int)blockIdx.y * band_rows;       // this workgroup's rows: [yb, ye)
-    if (yb >= Y) return;
-    const int ye = yb + band_rows < Y ? yb + band_rows : Y;
-    if (fa.flat) {
-        for (size_t i = (size_t)yb * X + (size_t)tid * 4; i < (size_t)ye * X; i += (size_t)WG * 4)
-            store4_global(dst + i, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
-        return;
-    }
-    const int rowcap = (X + 8 + 7) & ~7;
-    uint32_t* rowbuf0 = lds;
-    uint32_t* rowbuf1 = lds + rowcap;
-    uint32_t* head0 = lds + 2 * rowcap;
-    uint32_t* head1 = lds + 3 * rowcap;
-    uint32_t* rowidx_lds = lds + 4 * rowcap;          // ye - yb + 1 entries: rows yb .. ye
-    uint32_t* lastpix = rowidx_lds + ((ye - yb + 1 + 3) & ~3);
-    uint2* win = reinterpret_cast<uint2*>(lastpix + 4);   // run_cap records {start, word}
-    const uint32_t* rowidx = rowidx_lds - yb;         // indexed by absolute row
-    for (int k = tid; k <= ye - yb; k += WG) rowidx_lds[k] = load1_global(fa.row_run + yb + k);
-    for (int k = tid; k < 2 * rowcap; k += WG) head0[k] = 0;   // head0 and head1 are contiguous
-    if (yb > 0) {  // the row above the band and the two wrap pixels, from the host stage's seed
-        const uint32_t* sd = fa.seeds + (size_t)(blockIdx.y - 1) * ((size_t)X + 1);
-        uint32_t* upbuf = (yb & 1) ? rowbuf0 : rowbuf1;
-        for (int k = tid; k < X; k += WG) upbuf[k] = load1_global(sd + 1 + k);
-        if (tid == 0) {
-            lastpix[yb & 3] = 0; lastpix[(yb + 1) & 3] = 0;
-            lastpix[(yb + 2) & 3] = load1_global(sd);        // (yb-2) & 3
-            lastpix[(yb + 3) & 3] = load1_global(sd + X);    // (yb-1) & 3
-        }
-    } else if (tid < 4) lastpix[tid] = 0;
-    __syncthreads();
-    const int x0 = tid * PPL;
-    const int lane = tid & 63;
-    const bool active = x0 < X;                       // X % 4 == 0; with PPL 8 the last lane may own 4 pixels
-    const bool half = PPL == 8 && active && x0 + 4 >= X;
-
-    auto put_heads = [&](uint32_t* head, uint32_t r, uint32_t s, uint32_t e, uint32_t row0) {
-        const uint32_t col = s <= row0 ? 0u : s - row0;
-        if (col >= (uint32_t)X) return;              // the run that opens the next row
-        head[col] = r + 1u;
-        const uint32_t ecol = e - row0 < (uint32_t)X ? e - row0 : (uint32_t)X;
-        for (uint32_t p = (col / WAVE_PX + 1u) * WAVE_PX; p < ecol; p += WAVE_PX) head[p] = r + 1u;
-    };
-    auto scatter_all = [&](int yy, uint32_t w0, uint32_t* head, int first) {
-        const uint2* rr = win + (int)(rowidx[yy] - w0);
-        const int nr = (int)(rowidx[yy + 1] - rowidx[yy]) + 1;
-        const uint32_t row0 = (uint32_t)((size_t)yy * X);
-        for (int r = first; r < nr; r += WG)
-            put_heads(head, (uint32_t)r, rr[r].x, r + 1 < nr ? rr[r + 1].x : row0 + (uint32_t)X, row0);
-    };
-
-    int y = yb;
-    while (y < ye) {
-        const uint32_t w0 = rowidx[y];
-        int y_end = y + 1;
-        while (y_end < ye && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
-        const int wn = (int)(rowidx[y_end] - w0) + 1;
-        const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
-        for (int k = tid; k < wn; k += WG) win[k] = load2_global(gruns + k);
-        __syncthreads();  // run records arrive through vmcnt: full barrier once per window
-        scatter_all(y, w0, (y & 1) ? head1 : head0, tid);
-        lds_barrier();
-        uint32_t ri0 = rowidx[y], ri1 = rowidx[y + 1];       // rolling copies of the row index
-        for (; y < y_end; ++y) {
-            uint32_t* cur = (y & 1) ? rowbuf1 : rowbuf0;
-            const uint32_t* up = (y & 1) ? rowbuf0 : rowbuf1;
-            uint32_t* head = (y & 1) ? head1 : head0;
-            uint32_t* head_next = (y & 1) ? head0 : head1;
-            const uint2* rr = win + (int)(ri0 - w0);
-            const bool more = y + 1 < y_end;
-            // ---- all loads of this row that do not depend on each other, issued together -------
-            const uint32_t ri2 = more ? rowidx[y + 2] : ri1;
-            const uint32_t wrap_left = y >= 2 ? lastpix[(y - 2) & 3] : 0u;
-            uint4 h[V], q[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) { h[v] = make_uint4(0, 0, 0, 0); q[v] = make_uint4(0, 0, 0, 0); }
-            uint32_t uleft = 0;
-            if (active) {
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    if (v == 0 || !half) {
-                        h[v] = *reinterpret_cast<const uint4*>(head + x0 + 4 * v);
-                        q[v] = *reinterpret_cast<const uint4*>(up + x0 + 4 * v);
-                    }
-                uleft = x0 > 0 ? up[x0 - 1] : wrap_left;
-            }
-            // first scatter item of the NEXT row (rows rarely have more runs than lanes)
-            const uint2* rn = win + (int)(ri1 - w0);
-            const int nr_next = more ? (int)(ri2 - ri1) + 1 : 0;
-            uint32_t ns = 0, ne = 0;
-            if (tid < nr_next) {
-                ns = rn[tid].x;
-                ne = tid + 1 < nr_next ? rn[tid + 1].x : 0xFFFFFFFFu;
-            }
-            const uint32_t row0 = (uint32_t)((size_t)y * X);
-            // ---- resolve ---------------------------------------------------------------------
-            if (active) {
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    if (v == 0 || !half) *reinterpret_cast<uint4*>(head + x0 + 4 * v) = make_uint4(0, 0, 0, 0);  // for row y+2
-                uint32_t l[PPL];
-#pragma unroll
-                for (int v = 0; v < V; ++v) { l[4 * v] = h[v].x; l[4 * v + 1] = h[v].y; l[4 * v + 2] = h[v].z; l[4 * v + 3] = h[v].w; }
-#pragma unroll
-                for (int j = 1; j < PPL; ++j) l[j] = max(l[j], l[j - 1]);
-                const unsigned long long seen = __ballot(l[PPL - 1] != 0u);
-                const unsigned long long lower = seen & ((1ull << lane) - 1ull);
-                const int src = lower ? 63 - __clzll((long long)lower) : lane;
-                uint32_t carry = (uint32_t)__shfl((int)l[PPL - 1], src);
-                if (!lower) carry = 0;
-                // run of each pixel (lane 0 of a wave always has l[0] != 0)
-                uint32_t w[PPL];
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) w[j] = rr[max(carry, l[j]) - 1u].y;
-                uint32_t u[PPL + 1];
-                u[0] = uleft;
-#pragma unroll
-                for (int v = 0; v < V; ++v) { u[4 * v + 1] = q[v].x; u[4 * v + 2] = q[v].y; u[4 * v + 3] = q[v].z; u[4 * v + 4] = q[v].w; }
-                uint32_t px[PPL];
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) {
-                    const uint32_t kind = w[j] >> 24, val = w[j] & 0xFFFFFFu;
-                    const uint32_t above = kind == RUN_ABOVE_LEFT ? u[j] : u[j + 1];
-                    uint32_t v = kind == RUN_ABOVE ? add_bytes(above, val) : above;
-                    if (y == 0) v = 0;                      // above the buffer: undefined -> 0
-                    px[j] = kind == RUN_CONST ? val : v;
-                }
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    if (v == 0 || !half) {
-                        const uint4 o = make_uint4(px[4 * v], px[4 * v + 1], px[4 * v + 2], px[4 * v + 3]);
-                        *reinterpret_cast<uint4*>(cur + x0 + 4 * v) = o;
-                        store4_global(dst + row0 + x0 + 4 * v, o);
-                    }
-                if (x0 + PPL == X) lastpix[y & 3] = px[PPL - 1];
-                else if (half) lastpix[y & 3] = px[3];
-            }
-            // ---- scatter the heads of row y+1 ------------------------------------------------
-            if (more) {
-                const uint32_t nrow0 = row0 + (uint32_t)X;
-                if (tid < nr_next) put_heads(head_next, (uint32_t)tid, ns, ne < nrow0 + (uint32_t)X ? ne : nrow0 + (uint32_t)X, nrow0);
-                if (nr_next > WG) scatter_all(y + 1, w0, head_next, tid + WG);   // rows with more runs than lanes
-            }
-            ri0 = ri1;
-            ri1 = ri2;
-            lds_barrier();
-        }
-    }
-}
-
-// Leaner fast path for X <= 4 * WG (4 pixels per lane): the previous row never leaves the registers.
-//   * a lane keeps the 4 pixels it produced for the row above; the pixel to their left comes from the
-//     neighbouring lane with one DPP move, across a wave boundary through a 2-deep LDS slot per wave;
-//   * the scatter writes the run's WORD (kind | addend, plus a "present" bit) instead of its index, so
-//     the resolve step needs no second LDS lookup: a pixel without a head inherits the word to its
-//     left, the first pixels of a lane inherit from the nearest lower lane that saw a head (ballot +
-//     one cross-lane read);
-//   * the predictor is branch-free: pixel = ((kind bit 1 ? left : above) & -(kind bit 0)) + addend.
-// Per row: one LDS-only barrier, two dependent LDS round trips, ~40 % fewer instructions than
-// sp_iframe_rows_kernel, and half the LDS (no row buffers), so four workgroups fit a CU.
 constexpr uint32_t HEAD_PRESENT = 0x80000000u;
 
 __device__ __forceinline__ uint32_t lane_to_the_left(uint32_t v) {   // lane i gets lane i-1's value (lane 0: undefined)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-
-template <int WG, int PPL>
-__global__ __launch_bounds__(WG) void sp_iframe_rows_reg_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
-                                                                int run_cap, int band_rows) {
-    static_assert(PPL == 4 || PPL == 8, "4 or 8 pixels per lane");
-    constexpr int NW = WG / 64;
-    constexpr int V = PPL / 4;                    // uint4 vectors per lane
-    constexpr uint32_t WAVE_PX = 64 * PPL;        // pixels one wave covers
-    extern __shared__ __align__(16) uint32_t lds[];
-    const IFrameArgs fa = args[blockIdx.x];
-    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
-    const int tid = threadIdx.x;
-    const int yb = (int)blockIdx.y * band_rows;       // this workgroup's rows: [yb, ye)
-    if (yb >= Y) return;
-    const int ye = yb + band_rows < Y ? yb + band_rows : Y;
-    if (fa.flat) {
-        for (size_t i = (size_t)yb * X + (size_t)tid * 4; i < (size_t)ye * X; i += (size_t)WG * 4)
-            store4_global(dst + i, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
-        return;
-    }
-    const int rowcap = (X + 8 + 7) & ~7;
-    uint32_t* head0 = lds;
-    uint32_t* head1 = lds + rowcap;
-    uint32_t* rowidx_lds = lds + 2 * rowcap;          // ye - yb + 1 entries: rows yb .. ye
-    uint32_t* lastpix = rowidx_lds + ((ye - yb + 1 + 3) & ~3);   // last pixel of the 4 most recent rows
-    uint32_t* edge = lastpix + 4;                     // [2][NW + 4]: last pixel of every wave's span, rows y-1 / y
-    constexpr int EDGE_W = NW + 4;
-    uint2* win = reinterpret_cast<uint2*>(edge + 2 * EDGE_W);    // run_cap records {start, word}
-    const uint32_t* rowidx = rowidx_lds - yb;         // indexed by absolute row
-    for (int k = tid; k <= ye - yb; k += WG) rowidx_lds[k] = load1_global(fa.row_run + yb + k);
-    for (int k = tid; k < 2 * rowcap; k += WG) head0[k] = 0;   // head0 and head1 are contiguous
-    const int x0 = tid * PPL;
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool active = x0 < X;                       // X % PPL == 0: an active lane owns PPL pixels
-    uint32_t p[PPL];                                  // this lane's pixels of the row above
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) p[j] = 0;
-    if (tid < 4 + 2 * EDGE_W) lastpix[tid] = 0;       // lastpix and edge are contiguous
-    __syncthreads();
-    if (yb > 0) {  // the row above the band and the two wrap pixels, from the host stage's seed
-        const uint32_t* sd = fa.seeds + (size_t)(blockIdx.y - 1) * ((size_t)X + 1);
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + 1 + x0 + j);
-        }
-        if (tid == 0) {
-            lastpix[(yb + 2) & 3] = load1_global(sd);        // (yb-2) & 3
-            lastpix[(yb + 3) & 3] = load1_global(sd + X);    // (yb-1) & 3
-        }
-        // what wave w (w >= 1) reads as "left of my first pixel" in row yb: pixel (w*WAVE_PX - 1, yb - 1)
-        if (tid >= 1 && tid < NW && tid * (int)WAVE_PX < X) edge[((yb + 1) & 1) * EDGE_W + tid] = load1_global(sd + tid * WAVE_PX);
-        // The seed pixels must have landed before the row loop: a vmcnt wait on their first use INSIDE the
-        // loop would also wait, every row, for the previous row's frame store (loads and stores share vmcnt).
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
-    }
-    __syncthreads();
-
-    // The host stage cuts runs at row starts and at every 256th column (sp.h kRunSplit), so the records of
-    // row yy are exactly rowidx[yy] .. rowidx[yy+1]-1, each starts inside the row, and none crosses a wave's
-    // span: scattering a record is one store.
-    static_assert(WAVE_PX % kRunSplit == 0, "a wave's span must be a whole number of run pieces");
-    auto scatter_from = [&](int yy, uint32_t w0, uint32_t* head, int first) {
-        const uint2* rr = win + (int)(rowidx[yy] - w0);
-        const int nr = (int)(rowidx[yy + 1] - rowidx[yy]);
-        const uint32_t row0 = (uint32_t)((size_t)yy * X);
-        for (int r = first; r < nr; r += WG) {
-            const uint2 rec = rr[r];
-            head[rec.x - row0] = rec.y | HEAD_PRESENT;
-        }
-    };
-
-    int y = yb;
-    while (y < ye) {
-        const uint32_t w0 = rowidx[y];
-        int y_end = y + 1;
-        while (y_end < ye && (int)(rowidx[y_end + 1] - w0) + 1 <= run_cap) ++y_end;
-        const int wn = (int)(rowidx[y_end] - w0) + 1;
-        const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs) + w0;
-        for (int k = tid; k < wn; k += WG) win[k] = load2_global(gruns + k);
-        __syncthreads();  // run records arrive through vmcnt: full barrier once per window
-        scatter_from(y, w0, (y & 1) ? head1 : head0, tid);
-        lds_barrier();
-        // rolling copies of the row index, read one row ahead so the LDS latency is off the row's critical path
-        uint32_t ri1 = rowidx[y + 1], ri2 = y + 1 < y_end ? rowidx[y + 2] : ri1;
-        for (; y < y_end; ++y) {
-            uint32_t* head = (y & 1) ? head1 : head0;
-            uint32_t* head_next = (y & 1) ? head0 : head1;
-            const bool more = y + 1 < y_end;
-            // ---- loads of this row that do not depend on each other, issued together --------------
-            const uint32_t ri3 = y + 2 < y_end ? rowidx[y + 3] : ri2;
-            // left of this wave's first pixel, one row up: wave 0 wraps to pixel (X-1, y-2)
-            const uint32_t eg = wave == 0 ? lastpix[(y + 2) & 3] : edge[((y + 1) & 1) * EDGE_W + wave];
-            uint4 hv[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) hv[v] = make_uint4(0, 0, 0, 0);
-            if (active) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) hv[v] = *reinterpret_cast<const uint4*>(head + x0 + 4 * v);
-            }
-            const uint2* rn = win + (int)(ri1 - w0);
-            const int nr_next = more ? (int)(ri2 - ri1) : 0;
-            uint2 nrec = make_uint2(0, 0);
-            if (tid < nr_next) nrec = rn[tid];
-            const uint32_t row0 = (uint32_t)((size_t)y * X);
-            uint32_t u0 = lane_to_the_left(p[PPL - 1]);
-            if (lane == 0) u0 = eg;
-            // ---- resolve ------------------------------------------------------------------------
-            if (active) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + x0 + 4 * v) = make_uint4(0, 0, 0, 0);   // ready for row y+2
-                uint32_t h[PPL];
-#pragma unroll
-                for (int v = 0; v < V; ++v) { h[4 * v] = hv[v].x; h[4 * v + 1] = hv[v].y; h[4 * v + 2] = hv[v].z; h[4 * v + 3] = hv[v].w; }
-                // last head inside the lane (0 if none) ...
-                uint32_t last = h[0];
-#pragma unroll
-                for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
-                // ... and the word in force when the lane begins: from the nearest lower lane that saw one
-                const unsigned long long seen = __ballot(last != 0u);
-                const unsigned long long lower = seen & ((1ull << lane) - 1ull);
-                const int src = lower ? 63 - __clzll((long long)lower) : lane;
-                uint32_t w = (uint32_t)__shfl((int)last, src);   // lane 0 of a wave always has h[0] != 0
-                auto predict = [](uint32_t word, uint32_t left, uint32_t above) -> uint32_t {
-                    const uint32_t use_above = 0u - ((word >> 24) & 1u), use_left = 0u - ((word >> 25) & 1u);
-                    const uint32_t base = ((left & use_left) | (above & ~use_left)) & use_above;
-                    return add_bytes(base, word);   // add_bytes keeps bytes 0..2 only: the flag byte drops out
-                };
-                uint32_t q[PPL];
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) {
-                    w = h[j] ? h[j] : w;
-                    q[j] = predict(w, j ? p[j - 1] : u0, p[j]);
-                }
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    store4_global(dst + row0 + x0 + 4 * v, make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]));
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) p[j] = q[j];
-                if (lane == 63) edge[(y & 1) * EDGE_W + wave + 1] = q[PPL - 1];
-                if (x0 + PPL == X) lastpix[y & 3] = q[PPL - 1];
-            }
-            // ---- scatter the heads of row y+1 ------------------------------------------------------
-            if (tid < nr_next) head_next[nrec.x - (row0 + (uint32_t)X)] = nrec.y | HEAD_PRESENT;
-            if (nr_next > WG) scatter_from(y + 1, w0, head_next, tid + WG);   // rows with more records than lanes
-            ri1 = ri2;
-            ri2 = ri3;
-            lds_barrier();
-        }
-    }
 }
 
 // Tile path: one WAVE per tile = a band of rows x a span of 64*PPL columns.  The host stage hands every
@@ -873,55 +543,24 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
 namespace {
 int rows_in_band(const Geometry& g, int band_rows) { return band_rows > 0 && band_rows < g.Y ? band_rows : g.Y; }
 
-// Which key-frame kernel a geometry gets.
-//   Reg    : sp_iframe_rows_reg_kernel, X % 4 == 0 and X <= 4096 (previous row in registers)
-//   Rows   : sp_iframe_rows_kernel, X % 4 == 0 and X <= 8192 (previous row in LDS; 8 pixels per lane beyond 4096)
-//   Search : sp_iframe_rows_search_kernel, any width, any alignment
-enum class IVariant { Search, Rows, Reg };
-IVariant iframe_variant(const Geometry& g) {
-    static const int forced = [] {  // JSP_SP_IFRAME_KERNEL=rows|search, JSP_SP_IFRAME_PPL=8: tuning / test knobs
-        const char* k = getenv("JSP_SP_IFRAME_KERNEL");
-        const char* ppl = getenv("JSP_SP_IFRAME_PPL");
-        if (k && k[0] == 's') return 2;
-        if ((k && k[0] == 'r') || (ppl && ppl[0] == '8')) return 1;
-        return 0;
-    }();
-    if ((g.X & 3) != 0 || g.X > 8192 || forced == 2) return IVariant::Search;
-    if (g.X > 4096 || forced == 1) return IVariant::Rows;
-    return IVariant::Reg;
-}
-// LDS words needed besides the run window
-size_t iframe_fixed_words(const Geometry& g, IVariant v, int band_rows) {
+// LDS plan of sp_iframe_rows_search_kernel: two row buffers, the band's row index, 4 wrap pixels, then the window of
+// run records — what a 52 KB budget (three workgroups per CU) leaves, at least one row's worth
+size_t search_fixed_words(const Geometry& g, int band_rows) {
     const size_t rowidx = ((size_t)rows_in_band(g, band_rows) + 1 + 3) & ~size_t(3);
-    switch (v) {
-        case IVariant::Search: return 2 * (((size_t)g.X + 4 + 3) & ~size_t(3)) + rowidx + 4;          // two row buffers
-        case IVariant::Rows: return 4 * (((size_t)g.X + 8 + 7) & ~size_t(7)) + rowidx + 4;            // + two head rows
-        case IVariant::Reg: return 2 * (((size_t)g.X + 8 + 7) & ~size_t(7)) + rowidx + 4 + 2 * (16 + 4);  // head rows + edge slots
-    }
-    return 0;
+    return 2 * (((size_t)g.X + 4 + 3) & ~size_t(3)) + rowidx + 4;
 }
-size_t iframe_lds_budget(IVariant v) {  // bytes per workgroup the run window may grow into (JSP_SP_IFRAME_LDS_KB)
-    static const long forced = [] { const char* e = getenv("JSP_SP_IFRAME_LDS_KB"); return e ? atol(e) : 0L; }();
-    if (forced >= 16 && forced <= 160) return (size_t)forced * 1024;
-    return (v == IVariant::Reg ? 40 : 52) * 1024;   // four / three workgroups per CU
-}
-// run records staged per window: what the budget leaves, at least a row
-int iframe_run_cap(const Geometry& g, int band_rows) {
-    const IVariant v = iframe_variant(g);
-    const size_t fixed = iframe_fixed_words(g, v, band_rows);
-    const size_t budget_words = iframe_lds_budget(v) / 4;
+int search_run_cap(const Geometry& g, int band_rows) {
+    const size_t fixed = search_fixed_words(g, band_rows), budget_words = 52 * 1024 / 4;
     size_t cap = budget_words > fixed ? (budget_words - fixed) / 2 : 0;
     if (cap < (size_t)g.X + 2) cap = (size_t)g.X + 2;
     return (int)cap;
 }
 }  // namespace
 size_t iframe_lds_bytes(const Geometry& g, int band_rows) {
-    return sizeof(uint32_t) * (iframe_fixed_words(g, iframe_variant(g), band_rows) + 2 * (size_t)iframe_run_cap(g, band_rows));
+    return sizeof(uint32_t) * (search_fixed_words(g, band_rows) + 2 * (size_t)search_run_cap(g, band_rows));
 }
 
 int choose_band_rows(const Geometry& g, int nframes) {
-    static const int forced = [] { const char* e = getenv("JSP_SP_IFRAME_BAND_ROWS"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced;
     if (nframes <= 0) return 0;
     // ~3000 workgroups per launch (256 CUs x 4 resident, three times over, so the last partial round is
     // short) when the batch allows it; bands of at least 24 rows keep the seed rows (one per band) near 4 %
@@ -932,67 +571,24 @@ int choose_band_rows(const Geometry& g, int nframes) {
     return rows >= g.Y ? 0 : rows;
 }
 
+// Row-major layout: any width, any alignment (the tile kernel needs X % 4 == 0 and 16-byte aligned frame buffers).
 void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream) {
     if (nframes <= 0) return;
     if (band_rows <= 0 || band_rows >= g.Y) band_rows = g.Y;
     const int bands = (g.Y + band_rows - 1) / band_rows;
-    const size_t lds = iframe_lds_bytes(g, band_rows);
-    const int cap = iframe_run_cap(g, band_rows);
-    const dim3 grid(nframes, bands);
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        auto big_lds = [](const void* f) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_search_kernel));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_reg_kernel<512, 4>));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_reg_kernel<1024, 4>));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512, 4>));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024, 4>));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_kernel<256, 8>));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_kernel<512, 8>));
-        big_lds(reinterpret_cast<const void*>(sp_iframe_rows_kernel<1024, 8>));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_rows_search_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    // frame buffers of the vector kernels must be 16-byte aligned (Geometry::aligned16, set per launch by the codec)
-    const IVariant v = g.aligned16 ? iframe_variant(g) : IVariant::Search;
-    if (v == IVariant::Reg) {
-        // (8 pixels per lane, <256, 8> / <512, 8>, measured 19 % slower at 64 x 1080p: fewer waves to overlap
-        // each wave's serial row step)
-        if (g.X <= 2048)
-            hipLaunchKernelGGL((sp_iframe_rows_reg_kernel<512, 4>), grid, dim3(512), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-        else
-            hipLaunchKernelGGL((sp_iframe_rows_reg_kernel<1024, 4>), grid, dim3(1024), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-    } else if (v == IVariant::Rows) {
-        // previous row in LDS.  4 pixels per lane beat 8 both with 64 and with 1 536 workgroups in flight (the
-        // waves hide each other's LDS round trips); 8 per lane serve frames wider than 4096 pixels.
-        static const char* ppl = getenv("JSP_SP_IFRAME_PPL");
-        const bool wide = (ppl && ppl[0] == '8') || g.X > 4096;
-        if (wide) {
-            if (g.X <= 2048)
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<256, 8>), grid, dim3(256), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-            else if (g.X <= 4096)
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 8>), grid, dim3(512), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-            else
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 8>), grid, dim3(1024), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-        } else {
-            if (g.X <= 2048)
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<512, 4>), grid, dim3(512), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-            else
-                hipLaunchKernelGGL((sp_iframe_rows_kernel<1024, 4>), grid, dim3(1024), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-        }
-    } else {
-        hipLaunchKernelGGL(sp_iframe_rows_search_kernel, grid, dim3(IWG), lds, stream, d_args, g.X, g.Y, cap, band_rows);
-    }
+    hipLaunchKernelGGL(sp_iframe_rows_search_kernel, dim3(nframes, bands), dim3(IWG), iframe_lds_bytes(g, band_rows), stream,
+                       d_args, g.X, g.Y, search_run_cap(g, band_rows), band_rows);
 }
 
-bool iframe_tiles_ok(const Geometry& g) {
-    static const bool off = [] { const char* k = getenv("JSP_SP_IFRAME_KERNEL"); return k && k[0] != 't'; }();   // reg|rows|search: the older paths
-    return !off && (g.X & 3) == 0 && g.aligned16;
-}
-int iframe_tile_span(const Geometry& g) {
-    static const int forced = [] { const char* e = getenv("JSP_SP_TILE_PPL"); return e ? atoi(e) : 0; }();
-    // 4 pixels per lane (256-column spans) is the default: at 64 x 1080p the 8-pixel variant took 189 us against
-    // 147 us (half as many waves, each with a longer serial row step).  JSP_SP_TILE_PPL=8 selects it for tuning.
-    return (forced == 8 && (g.X & 7) == 0) ? 512 : 256;
-}
+bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; }
+// 4 pixels per lane, 256-column spans (8 per lane measured 189 us against 147 us at 64 x 1080p: half as many waves,
+// each with a longer serial row step)
+int iframe_tile_span(const Geometry&) { return 256; }
 namespace {
 struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {
@@ -1002,8 +598,7 @@ TilePlan tile_plan(const Geometry& g, int band_rows) {
     t.nspans = (g.X + t.span - 1) / t.span;
     // per wave: head row + row index + left column + record window; ~4.5 KB keeps 32 waves on a CU
     const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + (((size_t)t.rows + 3) & ~size_t(3));
-    static const size_t budget_bytes = [] { const char* e = getenv("JSP_SP_TILE_LDS_BYTES"); const long v = e ? atol(e) : 0; return (size_t)(v >= 2048 && v <= 65536 ? v : 4608); }();
-    const size_t budget = budget_bytes / 4;
+    const size_t budget = 4608 / 4;
     size_t cap = budget > fixed ? (budget - fixed) / 2 : 0;
     if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
     t.win_cap = (int)cap;
@@ -1016,10 +611,7 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
     const dim3 grid(nframes, bands * t.nspans);
-    if (t.span == 512)
-        hipLaunchKernelGGL(sp_iframe_tile_kernel<8>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
-    else
-        hipLaunchKernelGGL(sp_iframe_tile_kernel<4>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
+    hipLaunchKernelGGL(sp_iframe_tile_kernel<4>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,

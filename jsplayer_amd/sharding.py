@@ -29,3 +29,17 @@ def reduce_counters(frames: int, pixels: int, elapsed_s: float, device=None) -> 
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return int(counts[0]), int(counts[1]), float(tmax[0])
+
+
+def gather_per_rank(value: int, device=None) -> List[int]:
+    """Every rank's `value` (frames decoded), in rank order, on every rank: what shows that the collective saw
+    all N ranks.  Single process: [value]."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(value)]
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [int(t[0]) for t in out]

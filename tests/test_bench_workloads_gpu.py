@@ -1,0 +1,41 @@
+"""Full-size parity of exactly what bench.py times (run with -m gpu): every 1920x1080 workload is staged through
+the same code (jsplayer_amd.workloads.StagedWorkload: jsp_stage_batch + jsp_staged_decode), decoded by the kernels
+the bench launches, and every frame left in HBM is compared with the CPU oracle's digest of that frame
+(tests/golden/bench_digests.json, written by tests/golden/make_bench_digests.py).  The kernel list of each workload
+is pinned too, so a change of launch plan cannot slip past these tests."""
+import pytest
+
+from jsplayer_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # workload, kernels the staged decode must launch
+    ("msvideo1_16_1080p_keyframes_m1", ["msv1_"]),                       # 512 M1 key frames from raw stream bytes
+    ("msvideo1_16_1080p_keyframes_m1_hostdesc", ["msv1_blocks_kernel"]),  # host-built descriptor table
+    ("msvideo1_8_1080p_keyframes_m1", ["msv1_"]),
+    ("msvideo1_16_1080p_inter70", ["msv1_blocks_temporal_kernel"]),       # 511 inter frames, one temporal launch
+    ("screenpressor_v4_1080p_iframes", ["sp_iframe_tile_kernel"]),        # 256 key frames, wave-per-tile kernel
+    ("screenpressor_v4_1080p_pclip300", ["sp_pframe_group_kernel"]),      # 2 x 299 inter frames, group kernel
+]
+
+
+@pytest.mark.parametrize("name,kernels", CASES, ids=[c[0] for c in CASES])
+def test_staged_workload_matches_oracle_digests(name, kernels):
+    gold = wl.golden_digests(name, 0)
+    assert gold is not None, "run tests/golden/make_bench_digests.py"
+    work = wl.StagedWorkload(name, wl.build_clips(name, 0))
+    try:
+        for k in kernels:
+            assert k in work.kernels(), work.kernels()
+        assert work.frames_per_step == sum(len(g) for g in gold) - (len(gold) if work.inter else 0)
+        work.step()
+        work.sync()
+        assert work.mismatches(gold) == []
+        # a replay (what the timed steps are) leaves the same frames
+        work.step()
+        work.step()
+        work.sync()
+        assert work.mismatches(gold) == []
+    finally:
+        work.close()

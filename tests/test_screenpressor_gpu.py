@@ -108,23 +108,6 @@ def test_frame_buffers_that_are_not_16_byte_aligned(size):
     st.close()
 
 
-@pytest.mark.parametrize("env", [dict(JSP_SP_IFRAME_KERNEL="reg"), dict(JSP_SP_IFRAME_KERNEL="rows"),
-                                 dict(JSP_SP_IFRAME_KERNEL="rows", JSP_SP_IFRAME_PPL="8"), dict(JSP_SP_IFRAME_KERNEL="search"),
-                                 dict(JSP_SP_TILE_PPL="8")],
-                         ids=lambda e: "-".join(f"{k[7:].lower()}={v}" for k, v in e.items()))
-def test_kernel_variants_behind_the_tuning_knobs(env):
-    """The key-frame kernels kept for A/B measurements (selected by environment variables read once per process)
-    are held to the same bit-exactness: each runs tests/sp_variant_check.py in a process of its own."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    res = subprocess.run([sys.executable, os.path.join(here, "sp_variant_check.py")], env={**os.environ, **env},
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert res.returncode == 0, res.stderr.decode()[-2000:]
-    assert b"variant ok" in res.stdout
-
-
 def test_noise_key_frame_rows_with_more_runs_than_the_tile_window():
     """Almost every pixel its own run: a 512-column span row then has more records than a tile's LDS window
     holds, and the kernel scatters that row straight from global memory."""

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from jsplayer_amd.sharding import assign_streams, reduce_counters
+from jsplayer_amd.sharding import assign_streams, gather_per_rank, reduce_counters
 
 
 def test_assignment_is_a_partition():
@@ -38,7 +38,7 @@ def _worker(rank, world, port, out):
         elapsed = 0.5 + rank  # rank 1 is the slow one
         dist.barrier()
         tf, tp, te = reduce_counters(frames, pixels, elapsed)
-        out.put((rank, mine, tf, tp, te))
+        out.put((rank, mine, tf, tp, te, gather_per_rank(frames)))
     finally:
         dist.destroy_process_group()
 
@@ -56,9 +56,11 @@ def test_two_rank_counter_reduce_over_gloo():
         assert p.exitcode == 0
     results.sort()
     assert results[0][1] == [0, 2, 4] and results[1][1] == [1, 3]
-    for _, _, tf, tp, te in results:
+    for _, _, tf, tp, te, per_rank in results:
         assert tf == 15 and tp == 15 * 1920 * 1080 and te == 1.5
+        assert per_rank == [9, 6]
 
 
 def test_single_process_passthrough():
     assert reduce_counters(3, 30, 0.25) == (3, 30, 0.25)
+    assert gather_per_rank(7) == [7]
