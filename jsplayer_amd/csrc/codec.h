@@ -33,6 +33,7 @@ struct jsp_staged {
     jsp::PinnedBuffer h_signif;
     bool decoded = false;
     void finish_results();  // after the stream has been synchronised
+    virtual void after_sync() {}   // codec-specific checks of what the kernels reported (called by finish_results)
 };
 
 struct jsp_codec {

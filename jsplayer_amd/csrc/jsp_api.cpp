@@ -42,6 +42,7 @@ void jsp_codec::activate() { JSP_HIP(hipSetDevice(device)); }
 
 void jsp_staged::finish_results() {
     if (!decoded) return;
+    after_sync();
     const auto* words = static_cast<const uint32_t*>(h_signif.p);
     for (size_t i = 0; i < significant.size(); ++i)
         if (significant[i] < 0) significant[i] = words[i] ? 1 : 0;

@@ -78,6 +78,14 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
                        uint32_t* d_tile_entry, uint32_t* d_tile_block0, uint32_t* d_desc, Msv1FrameInfo* d_info,
                        int insignificant_blocks, hipStream_t stream);
 
+// Fused parse + reconstruction of tiles [tile0, tile0 + ntiles) in one launch (no descriptor table).  `d_agg`: 9 words
+// per tile of the batch, zeroed once; `epoch` (> 0) must differ from launch to launch on the same `d_agg`;
+// `ticket_base` = tiles launched so far on `d_ticket`.  *d_fault becomes non-zero if a tile gave up waiting.
+void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_pframes,
+                       const uint32_t* d_tile_frame, const Msv1FrameArgs* d_fargs, const int32_t* d_palette,
+                       unsigned long long* d_agg, uint32_t* d_ticket, uint32_t ticket_base, uint32_t epoch, uint32_t tile0,
+                       int ntiles, uint32_t* d_fault, hipStream_t stream);
+
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
                         const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,

@@ -23,6 +23,7 @@ struct Msv1Staged : jsp_staged {
         int first, count;
         bool edge_compare;
         bool temporal;   // inter-frame group: one launch, frames walked in registers per spatial tile
+        bool fused;      // parse + reconstruction in one launch straight from the stream bytes (no descriptor table)
     };
     std::vector<Group> groups;
     bool need_signif = false;  // some frame asked for the stage-2 compare
@@ -32,6 +33,12 @@ struct Msv1Staged : jsp_staged {
     int ntiles = 0, max_tiles = 0, insignificant_blocks = 0;
     DeviceBuffer d_pframes, d_tile_frame, d_tile_tab, d_tile_entry, d_tile_block0, d_info;
     PinnedBuffer h_pframes, h_tile_frame, h_info;
+    // fused parse + reconstruction (msv1_fused_kernel): published tile tables, ticket / fault words
+    DeviceBuffer d_agg, d_sync;
+    PinnedBuffer h_fault;
+    uint32_t epoch = 0, tickets = 0;
+    bool needs_desc = false;   // some launch reads the descriptor table the parse kernels build
+    bool any_fused = false;
 
     void launch_parse(hipStream_t stream) {
         msv1_launch_parse(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
@@ -46,11 +53,22 @@ struct Msv1Staged : jsp_staged {
         // A replay re-executes the whole device pipeline: with the on-GPU parse that includes the
         // parse kernels, so a staged batch can be timed from raw stream bytes.  (The first decode
         // uses the tables the staging pass left behind.)
-        if (gpu_parse && decoded) launch_parse(stream);
+        if (gpu_parse && decoded && needs_desc) launch_parse(stream);
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
         for (const Group& g : groups) {
-            if (g.temporal)
+            if (g.fused) {
+                const auto* pf = static_cast<const Msv1ParseFrame*>(h_pframes.p);
+                const uint32_t tile0 = pf[g.first].first_tile;
+                const Msv1ParseFrame& last = pf[g.first + g.count - 1];
+                const int nt = (int)(last.first_tile + last.ntiles - tile0);
+                auto* sync_words = static_cast<uint32_t*>(d_sync.p);
+                msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
+                                  static_cast<const uint32_t*>(d_tile_frame.p), frames, d_palette,
+                                  static_cast<unsigned long long*>(d_agg.p), sync_words, tickets, ++epoch, tile0, nt,
+                                  sync_words + 1, stream);
+                tickets += (uint32_t)nt;
+            } else if (g.temporal)
                 msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
                                             static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette,
                                             stream);
@@ -64,7 +82,16 @@ struct Msv1Staged : jsp_staged {
         if (need_signif)
             JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
                                    stream));
+        if (any_fused)
+            JSP_HIP(hipMemcpyAsync(h_fault.p, static_cast<uint32_t*>(d_sync.p) + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         decoded = true;
+    }
+    void after_sync() override {
+        if (any_fused && *static_cast<const uint32_t*>(h_fault.p)) {   // a tile gave up waiting for its predecessors' tables
+            for (const Group& g : groups)
+                if (g.fused) std::fill(status.begin() + g.first, status.begin() + g.first + g.count, (int)JSP_ERROR_OCCURED);
+            set_error("msv1_fused_kernel: look-back timed out");
+        }
     }
 };
 
@@ -261,6 +288,7 @@ struct Msv1Codec : jsp_codec {
         bool vec_ok = (X & 3) == 0;
         struct Attr { bool dependent, noop, special, edge; };
         std::vector<Attr> attr(nf, Attr{false, false, false, false});
+        std::vector<uint64_t> frame_stream(nf, 0);   // stream bytes each frame's codes occupy
         int last_gpu_frame = -1;
         bool pframes_dirty = false;
         for (int i = 0; i < nf; ++i) {
@@ -332,6 +360,7 @@ struct Msv1Codec : jsp_codec {
             st->info.units_coded += pr.n_coded;
             st->info.units_copied += pr.n_skipped;
             st->info.stream_bytes += pr.consumed;
+            frame_stream[i] = pr.consumed;
 
             attr[i].dependent = dependent;
             attr[i].noop = pr.early_out;
@@ -353,7 +382,7 @@ struct Msv1Codec : jsp_codec {
         {
             int i = 0;
             while (i < nf) {
-                if (attr[i].special) { st->groups.push_back({i, 1, attr[i].edge, false}); ++i; continue; }
+                if (attr[i].special) { st->groups.push_back({i, 1, attr[i].edge, false, false}); ++i; continue; }
                 int j = i;
                 bool any_dep = false;
                 while (j < nf && !attr[j].special) { any_dep |= attr[j].dependent; ++j; }
@@ -363,13 +392,16 @@ struct Msv1Codec : jsp_codec {
                     // program order, so buffers may even repeat inside the group
                     bool edge = false;
                     for (int k = i; k < j; ++k) edge |= attr[k].edge;
-                    st->groups.push_back({i, j - i, edge, true});
+                    st->groups.push_back({i, j - i, edge, true, false});
                 } else {
+                    // frames that do not read their predecessor: one launch per run of them with grid.y = frame —
+                    // or, straight from the stream bytes, one fused launch per run of GPU-parsed frames
                     bool closed = true;
                     for (int k = i; k < j; ++k) {
                         const bool writes = !attr[k].noop;
-                        if (attr[k].dependent || closed || (writes && seen.count(frames[k].dst))) {
-                            st->groups.push_back({k, 1, attr[k].edge, false});
+                        const bool fusable = st->gpu_parse && vec_ok && !attr[k].dependent && !attr[k].noop && !h_pf[k].host_parsed;
+                        if (attr[k].dependent || closed || (writes && seen.count(frames[k].dst)) || st->groups.back().fused != fusable) {
+                            st->groups.push_back({k, 1, attr[k].edge, false, fusable});
                             seen.clear();
                             closed = attr[k].dependent;
                         } else {
@@ -388,31 +420,54 @@ struct Msv1Codec : jsp_codec {
         st->info.descriptor_bytes = sizeof(uint32_t) * (uint64_t)geo.nblocks * nf + sizeof(Msv1FrameArgs) * nf;
         // A = S + 64*N_coded + 128*N_skipped
         st->info.algorithmic_bytes = st->info.stream_bytes + 64 * st->info.units_coded + 128 * st->info.units_copied;
-        // with the on-GPU parse every replay also runs tiles + chain + emit
-        st->info.kernel_launches = st->groups.size() + (st->gpu_parse ? 3 : 0);
-        // what the plan moves: the stream bytes the codes occupy, the descriptor table written by the parse kernels
-        // and read by the block kernels (host-built: read only), every written block once; a previous frame is
-        // read per skipped / compared block by the per-frame kernel, once per tile by a temporal launch
+        // What the plan launches and moves.  Fused launches read their frames' stream bytes once and write every block
+        // once.  Descriptor launches read stream + table, write the blocks, and read a previous frame per skipped /
+        // compared block (per-frame kernel) or once per tile (temporal launch); when the table of any of them comes from
+        // the parse kernels, every replay also runs tiles + chain + emit over the whole batch (two more reads of the
+        // stream, one write of the table).
         {
-            uint64_t moved = st->info.stream_bytes * (st->gpu_parse ? 3 : 1)   // tiles + emit + blocks each read the stream
-                             + sizeof(uint32_t) * (uint64_t)geo.nblocks * nf * (st->gpu_parse ? 2 : 1);
+            st->needs_desc = false;
+            st->any_fused = false;
+            st->kernels.clear();
+            uint64_t moved = 0;
             for (const auto& g : st->groups) {
-                uint64_t written = 0, prev_reads = 0;
-                bool uses_prev = false;
+                uint64_t written = 0, prev_reads = 0, sbytes = 0;
+                bool uses_prev = false, gpu_table = false;
                 for (int k = g.first; k < g.first + g.count; ++k) {
                     if (!attr[k].noop) written += (uint64_t)geo.nblocks;
                     uses_prev |= (h_frames[k].pad & MSV1_FRAME_USES_PREV) != 0;
                     if (h_frames[k].pad & MSV1_FRAME_USES_PREV) prev_reads += (uint64_t)geo.nblocks;
+                    sbytes += frame_stream[k];
+                    gpu_table |= st->gpu_parse && !h_pf[k].host_parsed;
                 }
-                moved += 64 * written + 64 * (g.temporal ? (uses_prev ? (uint64_t)geo.nblocks : 0) : prev_reads);
+                moved += sbytes + 64 * written;
+                if (g.fused) {
+                    st->any_fused = true;
+                    st->note_kernel("msv1_fused_kernel");
+                } else {
+                    st->needs_desc |= gpu_table;
+                    moved += sizeof(uint32_t) * (uint64_t)geo.nblocks * g.count +
+                             64 * (g.temporal ? (uses_prev ? (uint64_t)geo.nblocks : 0) : prev_reads);
+                    st->note_kernel(g.temporal ? "msv1_blocks_temporal_kernel" : "msv1_blocks_kernel");
+                }
+                if (g.edge_compare) st->note_kernel("msv1_edge_compare_kernel");
+            }
+            if (st->needs_desc) {
+                moved += 2 * st->info.stream_bytes + sizeof(uint32_t) * (uint64_t)geo.nblocks * nf;
+                st->kernels = "msv1_parse_tiles + msv1_parse_chain + msv1_parse_emit" + (st->kernels.empty() ? std::string() : " + " + st->kernels);
             }
             st->info.moved_bytes = moved;
-        }
-        st->kernels.clear();
-        if (st->gpu_parse) { st->note_kernel("msv1_parse_tiles"); st->note_kernel("msv1_parse_chain"); st->note_kernel("msv1_parse_emit"); }
-        for (const auto& g : st->groups) {
-            st->note_kernel(g.temporal ? "msv1_blocks_temporal_kernel" : "msv1_blocks_kernel");
-            if (g.edge_compare) st->note_kernel("msv1_edge_compare_kernel");
+            st->info.kernel_launches = st->groups.size() + (st->needs_desc ? 3 : 0);
+            if (st->any_fused) {
+                st->d_agg.reserve(sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1));
+                st->d_sync.reserve(2 * sizeof(uint32_t));
+                st->h_fault.reserve(sizeof(uint32_t));
+                *static_cast<uint32_t*>(st->h_fault.p) = 0;
+                st->epoch = 0;
+                st->tickets = 0;
+                JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1), stream));
+                JSP_HIP(hipMemsetAsync(st->d_sync.p, 0, 2 * sizeof(uint32_t), stream));
+            }
         }
         st->info.host_stage_ms = now_ms() - t0 - gpu_parse_ms;
 

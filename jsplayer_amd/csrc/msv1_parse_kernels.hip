@@ -274,6 +274,292 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused parse + reconstruction: raw stream bytes -> pixels in ONE launch, no descriptor table in HBM.
+//
+// One workgroup per 16 KiB tile of a frame's stream, tiles taken in stream order through a ticket counter
+// (so every tile with a lower number is already resident: what the look-back below relies on).  Per tile:
+//   1. the tile's bytes go to LDS once (bytes past the frame's end zeroed); every lane builds the table of
+//      its 32 slots (register-resident reverse DP) and the 256 tables are reduced by composition -> the
+//      tile's table "entry slot 0..8 -> (exit slot, blocks covered)";
+//   2. the tile publishes its table: 9 words of {launch epoch, value}, each a single 8-byte agent-scope
+//      atomic store — a word is its own flag, there is no payload to order behind it;
+//   3. look-back: the tile reads the tables of ALL earlier tiles of its frame (contiguous, 72 B per tile, polled
+//      with agent-scope atomic loads until their epoch matches) and chains them from entry slot 0 — the first
+//      tile of a frame starts immediately, so no tile ever waits for a prefix, only for tables that every
+//      resident tile publishes a few microseconds after it starts;
+//   4. down-sweep of one value per tree node: where the real chain enters each lane's slots and which block
+//      comes first; lanes replay their slots and drop, per coded block, the offset of its code into a
+//      16-bit staging window in LDS (skipped blocks keep the SKIP mark) — the descriptor table of the 3-kernel
+//      path, but only ever in LDS;
+//   5. reconstruction straight from the staged bytes: lane = block, raster order, so a wave still writes 1 KiB
+//      contiguous per pixel row; a code is two LDS reads (4 + 16 bytes at 2-byte alignment).
+// The whole frame batch is one launch; the stream is read from HBM exactly once.
+// Frames the host parser has to settle (Msv1ParseFrame::host_parsed) are skipped here and take the
+// descriptor path.  Requires X % 4 == 0 and 16-byte aligned frame buffers (msv1_codec.cpp checks).
+constexpr int FSTAGE = TSLOTS;                 // blocks per staging window
+constexpr uint32_t F_SKIP = 0xFFFFu;
+constexpr uint32_t TILE_BYTES = TSLOTS * 2;
+constexpr int LOOKBACK_BATCH = PWG / 9;        // 28 earlier tiles per poll
+constexpr int LOOKBACK_SPIN_LIMIT = 1 << 18;   // polls before the tile gives up and raises the fault word
+
+typedef uint32_t fu32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) fu32x4 fgu32x4;
+typedef const __attribute__((address_space(1))) fu32x4 fcgu32x4;
+
+__device__ __forceinline__ uint32_t rgb555(uint32_t c) {
+    return ((c & 0x1Fu) << 3) | ((c & 0x3E0u) << 6) | ((c & 0x7C00u) << 9);
+}
+
+// The 16 pixels of one coded block from its code in LDS.  `avail` = bytes between the code's first byte and the
+// end of the frame's data (8-bit only: the 16-bit stream is zeroed past its end in LDS, and a zero word decodes
+// as the reference decodes a missing one).
+template <int BITS>
+__device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail, const uint32_t* s_pal, uint32_t (&px)[16]) {
+    uint32_t c[8], flags;
+    if (BITS == 16) {
+        uint32_t w0;
+        fu32x4 q;
+        __builtin_memcpy(&w0, __builtin_assume_aligned(code, 2), 4);        // code word + first colour
+        __builtin_memcpy(&q, __builtin_assume_aligned(code + 4, 2), 16);    // colours 1..7 (+ 2 bytes of whatever follows)
+        const uint32_t cw = w0 & 0xFFFFu, q0 = w0 >> 16;
+        if ((cw >> 8) < 0x80u) {
+            flags = cw ^ 0xFFFFu;
+            c[0] = rgb555(q0);
+            c[1] = rgb555(q.x);
+            if (q0 & 0x8000u) {
+                c[2] = rgb555(q.x >> 16); c[3] = rgb555(q.y); c[4] = rgb555(q.y >> 16);
+                c[5] = rgb555(q.z); c[6] = rgb555(q.z >> 16); c[7] = rgb555(q.w);
+            } else {
+                c[2] = c[4] = c[6] = c[0];
+                c[3] = c[5] = c[7] = c[1];
+            }
+        } else {
+            flags = 0;
+            const uint32_t v = rgb555(cw);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = v;
+        }
+    } else {
+        const uint32_t w = (uint32_t)code[0] | ((uint32_t)code[1] << 8), b = w >> 8;
+        if (b < 0x80u) {
+            flags = w;
+            // first index byte is the colour of SET bits (p2[1]), second of clear bits (p2[0])
+            const uint32_t i0 = avail > 2u ? s_pal[code[2]] : 0u;
+            const uint32_t i1 = avail > 3u ? s_pal[code[3]] : 0u;
+            c[0] = c[2] = c[4] = c[6] = i1;
+            c[1] = c[3] = c[5] = c[7] = i0;
+        } else if (b >= 0x90u) {
+            flags = w ^ 0xFFFFu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = avail > 2u + k ? s_pal[code[2 + k]] : 0u;
+        } else {
+            flags = 0;
+            const uint32_t v = s_pal[w & 0xFFu];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = v;
+        }
+    }
+    // pixel (x,y): quadrant q = ((y&2)<<1) + (x&2) is static, only the flag bit is dynamic
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int q = ((y & 2) << 1) + (x & 2);
+            px[y * 4 + x] = ((flags >> (y * 4 + x)) & 1u) ? c[q + 1] : c[q];
+        }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(PWG) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
+                                                         const Msv1ParseFrame* __restrict__ pframes,
+                                                         const uint32_t* __restrict__ tile_frame,
+                                                         const Msv1FrameArgs* __restrict__ fargs,
+                                                         const int32_t* __restrict__ palette,
+                                                         unsigned long long* __restrict__ agg, uint32_t* __restrict__ ticket,
+                                                         uint32_t ticket_base, uint32_t epoch, uint32_t tile0,
+                                                         uint32_t* __restrict__ fault, uint32_t nblocks, int nbx, int X) {
+    // one LDS arena: [tile bytes | composition tree | per-node entry]; the tree's space becomes the staging
+    // window once every lane knows where the chain enters its slots; `enter` doubles as the look-back scratch
+    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = 2 * PWG;
+    static_assert(TREE_W * 2 >= FSTAGE, "staging window must fit in the tree's space");
+    static_assert(LOOKBACK_BATCH * 9 <= ENTER_W, "look-back scratch must fit in `enter`");
+    __shared__ __align__(16) uint32_t arena[BYTES_W + TREE_W + ENTER_W];
+    __shared__ uint32_t s_pal[BITS == 8 ? 256 : 1];
+    __shared__ uint32_t s_tile, s_entry;
+    uint8_t* lds_bytes = reinterpret_cast<uint8_t*>(arena);
+    uint32_t (*tree)[9] = reinterpret_cast<uint32_t (*)[9]>(arena + BYTES_W);
+    uint32_t* enter = arena + BYTES_W + TREE_W;
+    uint16_t* stage = reinterpret_cast<uint16_t*>(arena + BYTES_W);
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = tile0 + (atomicAdd(ticket, 1u) - ticket_base);
+    if (BITS == 8) s_pal[tid] = (uint32_t)palette[tid];
+    __syncthreads();
+    const uint32_t t = s_tile;
+    const uint32_t f = tile_frame[t];
+    const Msv1ParseFrame fr = pframes[f];
+    if (fr.host_parsed) return;
+    const Msv1FrameArgs fa = fargs[f];
+    const uint32_t k = t - fr.first_tile;                      // which tile of its frame
+    const uint32_t tile_byte0 = fr.beg + k * TILE_BYTES;
+    const uint32_t data_end = BITS == 16 ? fr.end : fa.stream_end;   // 16-bit: whole code units only
+
+    // ---- 1. tile bytes -> LDS (zero past the end of the frame's data), lane tables, composition tree ----
+    for (uint32_t o = tid * 16u; o < (uint32_t)BYTES_W * 4u; o += PWG * 16u) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const uint32_t at = tile_byte0 + o;
+        if (at < data_end) {
+            v = *reinterpret_cast<const uint4*>(stream + at);  // buffers are padded
+            const uint32_t nvalid = data_end - at;
+            if (nvalid < 16u) {
+                auto keep = [&](uint32_t word, uint32_t first) -> uint32_t {
+                    if (nvalid >= first + 4u) return word;
+                    if (nvalid <= first) return 0u;
+                    return word & ((1u << (8u * (nvalid - first))) - 1u);
+                };
+                v.x = keep(v.x, 0); v.y = keep(v.y, 4); v.z = keep(v.z, 8); v.w = keep(v.w, 12);
+            }
+        }
+        *reinterpret_cast<uint4*>(lds_bytes + o) = v;
+    }
+    __syncthreads();
+    uint32_t w[17], cls[LSLOTS], tab[9];
+    {
+        const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
+#pragma unroll
+        for (int i = 0; i < 17; ++i) w[i] = mine_w[i];
+    }
+    const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
+    lane_table<BITS>(w, p0, fr.end, cls, tab);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tree[tid][e] = tab[e];
+    __syncthreads();
+    for (int l = 1; l <= 8; ++l) {
+        const int nodes = PWG >> l, lo = tree_row(l - 1), hi = tree_row(l);
+        for (int i = tid; i < nodes * 9; i += PWG) {
+            const int j = i / 9, e = i - j * 9;
+            tree[hi + j][e] = compose(tree[lo + 2 * j][e], tree[lo + 2 * j + 1]);
+        }
+        __syncthreads();
+    }
+    // ---- 2. publish the tile's table (the last tile of a frame has no reader) -------------------------------
+    if (k + 1u < fr.ntiles && tid < 9)
+        __hip_atomic_store(agg + (size_t)t * 9u + tid, ((unsigned long long)epoch << 32) | tree[tree_row(8)][tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- 3. look-back over the earlier tiles of the frame, LOOKBACK_BATCH at a time -------------------------
+    {
+        uint32_t e = 0, blocks = 0;                            // thread 0 carries the chain
+        for (uint32_t j0 = 0; j0 < k; j0 += LOOKBACK_BATCH) {
+            const uint32_t nj = k - j0 < (uint32_t)LOOKBACK_BATCH ? k - j0 : (uint32_t)LOOKBACK_BATCH;
+            const bool wanted = (uint32_t)tid < nj * 9u;
+            const unsigned long long* src = agg + (size_t)(fr.first_tile + j0) * 9u + tid;
+            unsigned long long v = 0;
+            bool have = !wanted;
+            for (int spin = 0;; ++spin) {
+                if (!have) {
+                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    have = (uint32_t)(v >> 32) == epoch;
+                }
+                if (__syncthreads_and(have)) break;
+                if (spin > LOOKBACK_SPIN_LIMIT) {              // uniform: every lane counts the same rounds
+                    if (tid == 0) atomicOr(fault, 1u);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (wanted) enter[tid] = (uint32_t)v;
+            __syncthreads();
+            if (tid == 0) {
+                for (uint32_t j = 0; j < nj; ++j) {
+                    const uint32_t tv = enter[j * 9u + e];
+                    e = tv & 15u;
+                    blocks = blocks + (tv >> 4) > BSAT ? BSAT : blocks + (tv >> 4);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_entry = pack(e, blocks);
+    }
+    __syncthreads();
+    // ---- 4. down-sweep of ONE value per node: where the chain enters the node and with which block ----------
+    const uint32_t entry = s_entry;
+    const uint32_t tb0 = entry >> 4;
+    if (tid == 0) enter[tree_row(8)] = entry;
+    __syncthreads();
+    for (int l = 8; l >= 1; --l) {
+        const int nodes = PWG >> l, hi = tree_row(l), lo = tree_row(l - 1);
+        if (tid < nodes) {
+            const uint32_t v = enter[hi + tid];
+            enter[lo + 2 * tid] = v;
+            enter[lo + 2 * tid + 1] = add_blocks(tree[lo + 2 * tid][v & 15u], v >> 4);
+        }
+        __syncthreads();
+    }
+    const uint32_t mine = enter[tid];
+    const uint32_t whole = add_blocks(tree[tree_row(8)][entry & 15u], tb0) >> 4;   // blocks covered once this tile is done
+    const uint32_t span_end = whole < nblocks ? whole : nblocks;
+    __syncthreads();                                           // tree and enter are dead: the staging window takes their place
+
+    const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev);
+    uint32_t* __restrict__ dstf = reinterpret_cast<uint32_t*>(fa.dst);
+    for (uint32_t w0 = tb0; w0 < span_end; w0 += FSTAGE) {     // more than one window only behind long skip runs
+        const uint32_t wn = span_end - w0 < (uint32_t)FSTAGE ? span_end - w0 : (uint32_t)FSTAGE;
+        for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG) reinterpret_cast<uint32_t*>(stage)[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        {
+            uint32_t pos = mine & 15u, blk = mine >> 4;
+#pragma unroll
+            for (int s = 0; s < LSLOTS; ++s) {
+                if (pos == (uint32_t)s && blk < nblocks) {
+                    const uint32_t c = cls[s];
+                    if (p0 + 2u * s < fr.end) {
+                        if ((c & 16u) && blk - w0 < wn) stage[blk - w0] = (uint16_t)(tid * (LSLOTS * 2) + 2 * s);
+                        const uint32_t nb = blk + (c >> 8);
+                        blk = nb > BSAT ? BSAT : nb;
+                    }
+                    pos += c & 15u;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 5. reconstruction: lane = block, raster order ----------------------------------------------------
+        for (uint32_t i = tid; i < wn; i += PWG) {
+            const uint32_t blk = w0 + i;
+            const uint32_t o = stage[i];
+            const uint32_t by = blk / (uint32_t)nbx, bx = blk - by * (uint32_t)nbx;
+            const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
+            uint32_t* __restrict__ dst = dstf + di;
+            if (o == F_SKIP) {
+                const uint32_t* __restrict__ pv = prev + di;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const fu32x4 r = *(fcgu32x4*)(pv + (size_t)y * X);
+                    __builtin_nontemporal_store(r, (fgu32x4*)(dst + (size_t)y * X));
+                }
+                continue;
+            }
+            uint32_t px[16];
+            decode_block<BITS>(lds_bytes + o, data_end - (tile_byte0 + o), s_pal, px);
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
+            if (fa.cmp_row_lo != 0xFFFFFFFFu) {                // stage-2 significance, MSVideo1.hx:195-204
+                const uint32_t* __restrict__ pv = prev + di;
+                bool diff = false;
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    if (by * 4u + y >= fa.cmp_row_lo) {
+                        const fu32x4 r = *(fcgu32x4*)(pv + (size_t)y * X);
+                        diff |= (r.x != px[y * 4]) | (r.y != px[y * 4 + 1]) | (r.z != px[y * 4 + 2]) | (r.w != px[y * 4 + 3]);
+                    }
+                if (diff && __hip_atomic_load(fa.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(fa.signif, 1u);
+            }
+        }
+        __syncthreads();                                       // the window is refilled by the next round
+    }
+}
+
 }  // namespace
 
 uint32_t msv1_parse_tile_bytes() { return TSLOTS * 2; }
@@ -298,6 +584,20 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
         hipLaunchKernelGGL(msv1_parse_emit<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_frames, d_tile_frame, d_tile_entry,
                            d_tile_block0, d_desc, d_info, (uint32_t)geo.nblocks, s1_first);
     }
+}
+
+
+void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_pframes,
+                       const uint32_t* d_tile_frame, const Msv1FrameArgs* d_fargs, const int32_t* d_palette,
+                       unsigned long long* d_agg, uint32_t* d_ticket, uint32_t ticket_base, uint32_t epoch, uint32_t tile0,
+                       int ntiles, uint32_t* d_fault, hipStream_t stream) {
+    if (ntiles <= 0) return;
+    if (geo.bits == 16)
+        hipLaunchKernelGGL(msv1_fused_kernel<16>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_pframes, d_tile_frame, d_fargs,
+                           d_palette, d_agg, d_ticket, ticket_base, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
+    else
+        hipLaunchKernelGGL(msv1_fused_kernel<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_pframes, d_tile_frame, d_fargs,
+                           d_palette, d_agg, d_ticket, ticket_base, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
 }
 
 }  // namespace jsp

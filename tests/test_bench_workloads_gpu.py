@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 
 CASES = [
     # workload, kernels the staged decode must launch
-    ("msvideo1_16_1080p_keyframes_m1", ["msv1_"]),                       # 512 M1 key frames from raw stream bytes
+    ("msvideo1_16_1080p_keyframes_m1", ["msv1_fused_kernel"]),           # 512 M1 key frames from raw stream bytes
     ("msvideo1_16_1080p_keyframes_m1_hostdesc", ["msv1_blocks_kernel"]),  # host-built descriptor table
-    ("msvideo1_8_1080p_keyframes_m1", ["msv1_"]),
+    ("msvideo1_8_1080p_keyframes_m1", ["msv1_fused_kernel"]),
     ("msvideo1_16_1080p_inter70", ["msv1_blocks_temporal_kernel"]),       # 511 inter frames, one temporal launch
     ("screenpressor_v4_1080p_iframes", ["sp_iframe_tile_kernel"]),        # 256 key frames, wave-per-tile kernel
     ("screenpressor_v4_1080p_pclip300", ["sp_pframe_group_kernel"]),      # 2 x 299 inter frames, group kernel

@@ -189,7 +189,9 @@ def test_batch_matches_sequential_and_full_size_properties():
     dsts = [dev_buf(w * h, -1) for _ in range(n)]
     st = gpu.stage_batch(frames, dsts)
     info = st.info()
-    assert info["kernel_launches"] == (1 if PARSE_MODE == "host" else 4)
+    assert info["kernel_launches"] == 1     # host tables: the block kernel; raw bytes: the fused parse + block kernel
+    assert st.kernels() == ("msv1_blocks_kernel" if PARSE_MODE == "host" else "msv1_fused_kernel")
+    assert info["moved_bytes"] == info["algorithmic_bytes"] + (n * 129600 * 4 if PARSE_MODE == "host" else 0)
     assert info["units_coded"] == n * 129600 and info["units_copied"] == 0
     assert info["algorithmic_bytes"] == sum(len(f) for f in frames) + n * w * h * 4
     st.decode()

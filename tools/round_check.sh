@@ -1,26 +1,47 @@
 #!/bin/bash
-# Usage: tools/round_check.sh [all|profile-only] [workload] [kernel substring]
-# One GPU-box pass: the whole GPU test suite, smoke(), the default bench line, then kernel-trace and
-# PMC profiles of the ScreenPressor key-frame workload.  Everything lands in gpurun_out/.
+# Usage: tools/round_check.sh [tests] [smoke] [bench] [all-workloads] [profile:<workload>] ...
+# One GPU-box pass; every step is optional and lands in gpurun_out/<tag>_*.  TAG=<prefix> names the files.
+# Steps are chained: the first failure stops the pass (no GPU step runs after a failed one).
 set -eo pipefail
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 O="$R/gpurun_out"; mkdir -p "$O"
+T="${TAG:-run}"
 export TMPDIR=/tmp
 cd "$R"
-if [ "$1" != "profile-only" ]; then
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$O/gpu_tests.log" 2>&1
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1
-timeout -k 10 400 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
-fi
-W="${2:-screenpressor_v4_1080p_iframes}"; K="${3:-sp_iframe_rows_kernel}"
-cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_spi" -o spi -- python3 "$R/bench.py" --workload $W --steps 20 --warmup 3 --no-cpu-baseline > "$O/spi_bench_under_rocprof.json" 2> "$O/spi_rocprof.err"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_spi_fetch" -- python3 "$R/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/spi_pmc_f.err"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_spi_write" -- python3 "$R/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/spi_pmc_w.err"
-cd "$R"
-python tools/pmc_summary.py "$O/pmc_spi_fetch" "$O/pmc_spi_write" "$K" $W scratch > "$O/spi_traffic.json"
-rm -rf "$O/pmc_spi_fetch" "$O/pmc_spi_write"
-find "$O/prof_spi" -name "*kernel_stats.csv" -exec cp {} "$O/spi_kernel_stats.csv" \;
-rm -rf "$O/prof_spi"
-[ "$1" = "profile-only" ] || { tail -2 "$O/gpu_tests.log"; tail -1 "$O/smoke.log"; cat "$O/bench_default.json"; }
-cat "$O/spi_traffic.json"; head -5 "$O/spi_kernel_stats.csv"
+for step in "$@"; do
+  case "$step" in
+    tests)
+      timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$O/${T}_gpu_tests.log" 2>&1 || { tail -30 "$O/${T}_gpu_tests.log"; exit 1; }
+      tail -2 "$O/${T}_gpu_tests.log" ;;
+    newtests)
+      timeout -k 10 900 python -m pytest tests/test_bench_workloads_gpu.py -m gpu -x -q > "$O/${T}_gpu_newtests.log" 2>&1 || { tail -30 "$O/${T}_gpu_newtests.log"; exit 1; }
+      tail -2 "$O/${T}_gpu_newtests.log" ;;
+    smoke)
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/${T}_smoke.log" 2>&1 || { tail -20 "$O/${T}_smoke.log"; exit 1; }
+      tail -1 "$O/${T}_smoke.log" ;;
+    bench)
+      timeout -k 10 500 python bench.py > "$O/${T}_bench_default.json" 2> "$O/${T}_bench_default.err" || { tail -20 "$O/${T}_bench_default.err"; exit 1; }
+      cat "$O/${T}_bench_default.json" ;;
+    all-workloads)
+      : > "$O/${T}_bench_all.jsonl"
+      for w in msvideo1_16_1080p_keyframes_m1_hostdesc msvideo1_8_1080p_keyframes_m1 msvideo1_16_1080p_keyframes_solid \
+               msvideo1_16_1080p_keyframes_eight msvideo1_16_1080p_inter70 screenpressor_v4_1080p_iframes \
+               screenpressor_v2_1080p_iframes screenpressor_v4_1080p_pclip300; do
+        timeout -k 10 600 python bench.py --workload $w --steps 20 --warmup 3 >> "$O/${T}_bench_all.jsonl" 2>> "$O/${T}_bench_all.err" || { tail -20 "$O/${T}_bench_all.err"; exit 1; }
+        echo "done $w"
+      done ;;
+    profile:*)
+      W="${step#profile:}"
+      cd /tmp
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$W" -o p -- python3 "$R/bench.py" --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > "$O/${T}_${W}_bench_under_rocprof.json" 2> "$O/${T}_${W}_rocprof.err" || { tail -20 "$O/${T}_${W}_rocprof.err"; exit 1; }
+      find "$O/prof_$W" -name "*kernel_stats.csv" -exec cp {} "$O/${T}_${W}_kernel_stats.csv" \;
+      rm -rf "$O/prof_$W"
+      timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > /dev/null 2> "$O/${T}_${W}_pmc_f.err" || { tail -20 "$O/${T}_${W}_pmc_f.err"; exit 1; }
+      timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > /dev/null 2> "$O/${T}_${W}_pmc_w.err" || { tail -20 "$O/${T}_${W}_pmc_w.err"; exit 1; }
+      cd "$R"
+      python tools/pmc_summary.py "$O/pmc_f_$W" "$O/pmc_w_$W" "$O/${T}_${W}_bench_under_rocprof.json" "$O/${T}_${W}_traffic.json" || exit 1
+      rm -rf "$O/pmc_f_$W" "$O/pmc_w_$W"
+      head -8 "$O/${T}_${W}_kernel_stats.csv"; cat "$O/${T}_${W}_traffic.json" ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+done
