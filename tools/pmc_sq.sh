@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$O/pmc_sq_$i" -- python3 "$R/bench.py" --workload "$W" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_sq_$i.err"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$O/pmc_sq_$i" -- python3 "$R/bench.py" --workload "$W" --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > /dev/null 2> "$O/pmc_sq_$i.err"
 done
 cd "$R"
 python3 - "$O" "$K" "$W" <<'PY'
