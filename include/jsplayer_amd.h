@@ -16,6 +16,10 @@
  *     (compatibility mode for an unmodified Manager; PCIe-bound).
  * The two kinds must not be mixed on one codec instance.
  *
+ * Ordering: a codec's own HIP stream is a blocking stream, i.e. ordered after work the caller queued on the legacy
+ * default stream; work the caller has pending on other non-blocking streams that touches `dst` or the previous
+ * frame must have finished before the call (or give the codec that stream with jsp_set_stream).
+ *
  * Threading (reference: single-threaded, not re-entrant): one thread per codec instance at a
  * time; distinct instances may be used concurrently from distinct threads.
  * No exceptions cross this boundary; failures are reported by status + jsp_last_error().

@@ -26,6 +26,7 @@ struct jsp_staged {
         kernels += name;
     }
     std::vector<int> status, adopted, significant;
+    std::string why;           // what made a frame fail, for jsp_last_error()
     std::vector<int> cleared;  // frame i ended with prevFrame == null (ScreenPressor RenewI + failure)
     // significance words written by the kernels (one per frame); -1 in `significant`
     // marks "take it from the device word"

@@ -34,7 +34,10 @@ void jsp_codec::init_device(int device_id) {
     if (device_id < 0 || device_id >= count) throw std::runtime_error("device_id out of range");
     device = device_id;
     JSP_HIP(hipSetDevice(device));
-    JSP_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    // a BLOCKING stream: ordered after whatever the caller queued on the legacy default stream (e.g. the fill that
+    // initialised a freshly allocated frame buffer) — a caller that fills and decodes back to back needs no sync of
+    // its own.  Distinct codec instances still overlap each other.  (jsp_set_stream replaces it.)
+    JSP_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamDefault));
     stream = own_stream;
 }
 
@@ -114,7 +117,8 @@ int decompress_one(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, boo
     if (st->adopted[0]) c->prev_caller = dst;
     if (data_pnt) *data_pnt = c->prev_caller;
     if (significant) *significant = st->significant[0];
-    if (st->status[0] != JSP_ZERO_STATE) set_error("decode aborted: the reference raises on this stream");
+    if (st->status[0] != JSP_ZERO_STATE)
+        set_error("%s", st->why.empty() ? "decode aborted: the reference raises on this stream" : st->why.c_str());
     return st->status[0];
 }
 

@@ -78,13 +78,30 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
                        uint32_t* d_tile_entry, uint32_t* d_tile_block0, uint32_t* d_desc, Msv1FrameInfo* d_info,
                        int insignificant_blocks, hipStream_t stream);
 
-// Fused parse + reconstruction of tiles [tile0, tile0 + ntiles) in one launch (no descriptor table).  `d_agg`: 9 words
-// per tile of the batch, zeroed once; `epoch` (> 0) must differ from launch to launch on the same `d_agg`;
-// `ticket_base` = tiles launched so far on `d_ticket`.  *d_fault becomes non-zero if a tile gave up waiting.
-void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_pframes,
-                       const uint32_t* d_tile_frame, const Msv1FrameArgs* d_fargs, const int32_t* d_palette,
-                       unsigned long long* d_agg, uint32_t* d_ticket, uint32_t ticket_base, uint32_t epoch, uint32_t tile0,
-                       int ntiles, uint32_t* d_fault, hipStream_t stream);
+// Fused parse + reconstruction (msv1_fused_kernel): everything one 16 KiB tile of a frame's stream needs, in one
+// 64-byte record the workgroup reads with a single scalar load.
+constexpr uint32_t MSV1_TILE_SKIP = 1u;   // the frame takes the descriptor path (host-parsed)
+struct alignas(16) Msv1TileRec {
+    uint32_t byte0;        // first byte of the tile in the batch stream buffer
+    uint32_t frame_end;    // end of the frame's whole code units (even)
+    uint32_t data_end;     // end of the bytes a code may read: frame_end (16-bit) or the frame's true end (8-bit)
+    uint32_t k;            // index of the tile within its frame
+    uint32_t first_tile;   // index of the frame's first tile within the batch
+    uint32_t ntiles;       // tiles of the frame
+    uint32_t cmp_row_lo;   // first pixel row of the stage-2 compare; ~0u = none
+    uint32_t flags;        // MSV1_TILE_SKIP
+    int32_t* dst;
+    const int32_t* prev;
+    uint32_t* signif;
+    uint64_t pad;
+};
+static_assert(sizeof(Msv1TileRec) == 64, "one record = 64 bytes");
+// Tiles [tile0, tile0 + ntiles) in one launch (no descriptor table).  `d_agg`: 9 words per tile of the batch, zeroed
+// once; `epoch` (> 0) must differ from launch to launch on the same `d_agg`.  *d_fault becomes non-zero if a tile
+// gave up waiting for the tables of the tiles before it (the caller reports the batch as failed).
+void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
+                       unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
+                       hipStream_t stream);
 
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,

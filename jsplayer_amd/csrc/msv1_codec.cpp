@@ -34,9 +34,9 @@ struct Msv1Staged : jsp_staged {
     DeviceBuffer d_pframes, d_tile_frame, d_tile_tab, d_tile_entry, d_tile_block0, d_info;
     PinnedBuffer h_pframes, h_tile_frame, h_info;
     // fused parse + reconstruction (msv1_fused_kernel): published tile tables, ticket / fault words
-    DeviceBuffer d_agg, d_sync;
-    PinnedBuffer h_fault;
-    uint32_t epoch = 0, tickets = 0;
+    DeviceBuffer d_agg, d_sync, d_recs;
+    PinnedBuffer h_fault, h_recs;
+    uint32_t epoch = 0;
     bool needs_desc = false;   // some launch reads the descriptor table the parse kernels build
     bool any_fused = false;
 
@@ -61,13 +61,9 @@ struct Msv1Staged : jsp_staged {
                 const auto* pf = static_cast<const Msv1ParseFrame*>(h_pframes.p);
                 const uint32_t tile0 = pf[g.first].first_tile;
                 const Msv1ParseFrame& last = pf[g.first + g.count - 1];
-                const int nt = (int)(last.first_tile + last.ntiles - tile0);
-                auto* sync_words = static_cast<uint32_t*>(d_sync.p);
-                msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
-                                  static_cast<const uint32_t*>(d_tile_frame.p), frames, d_palette,
-                                  static_cast<unsigned long long*>(d_agg.p), sync_words, tickets, ++epoch, tile0, nt,
-                                  sync_words + 1, stream);
-                tickets += (uint32_t)nt;
+                msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs.p), d_palette,
+                                  static_cast<unsigned long long*>(d_agg.p), ++epoch, tile0, (int)(last.first_tile + last.ntiles - tile0),
+                                  static_cast<uint32_t*>(d_sync.p), stream);
             } else if (g.temporal)
                 msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
                                             static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette,
@@ -83,14 +79,17 @@ struct Msv1Staged : jsp_staged {
             JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
                                    stream));
         if (any_fused)
-            JSP_HIP(hipMemcpyAsync(h_fault.p, static_cast<uint32_t*>(d_sync.p) + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            JSP_HIP(hipMemcpyAsync(h_fault.p, d_sync.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         decoded = true;
     }
     void after_sync() override {
         if (any_fused && *static_cast<const uint32_t*>(h_fault.p)) {   // a tile gave up waiting for its predecessors' tables
             for (const Group& g : groups)
                 if (g.fused) std::fill(status.begin() + g.first, status.begin() + g.first + g.count, (int)JSP_ERROR_OCCURED);
-            set_error("msv1_fused_kernel: look-back timed out");
+            char buf[96];
+            std::snprintf(buf, sizeof buf, "msv1_fused_kernel: look-back timed out (fault word %u)", *static_cast<const uint32_t*>(h_fault.p));
+            why = buf;
+            set_error("%s", buf);
         }
     }
 };
@@ -194,6 +193,7 @@ struct Msv1Codec : jsp_codec {
         st->adopted.assign(nf, 0);
         st->significant.assign(nf, 0);
         st->info = jsp_staged_info{};
+        st->why.clear();
         st->insignificant_blocks = insignificant_blocks;
         // the on-GPU parse packs block counts in 20 bits
         st->gpu_parse = opt_gpu_parse && geo.nblocks > 0 && geo.nblocks < (1 << 20);
@@ -204,11 +204,14 @@ struct Msv1Codec : jsp_codec {
         st->d_palette = static_cast<const int32_t*>(d_palette.p);
 
         // ---- lay the frames out in one stream buffer (16-byte aligned starts) ----------------
+        // With the on-GPU parse every frame starts on a tile boundary of the stream buffer, so tile t of the batch is the
+        // bytes [t * tile, (t + 1) * tile): a workgroup of the fused kernel knows where its bytes are from its index alone.
         std::vector<size_t> beg(nf);
         size_t total_stream = 0;
+        const size_t frame_align = st->gpu_parse ? (size_t)msv1_parse_tile_bytes() : 16;
         for (int i = 0; i < nf; ++i) {
             beg[i] = total_stream;
-            total_stream += (frames[i].n + 15) & ~size_t(15);
+            total_stream += (frames[i].n + frame_align - 1) / frame_align * frame_align;
         }
         if (total_stream + 64 > 0xFFFFFFF0u) throw std::runtime_error("batch stream exceeds 4 GiB");
         st->h_stream.reserve(total_stream + 64);
@@ -225,7 +228,7 @@ struct Msv1Codec : jsp_codec {
         auto* d_signif = static_cast<uint32_t*>(st->d_signif.p);
         for (int i = 0; i < nf; ++i) {
             if (frames[i].n) std::memcpy(h_stream + beg[i], frames[i].src, frames[i].n);
-            const size_t padded = (frames[i].n + 15) & ~size_t(15);
+            const size_t padded = (frames[i].n + 15) & ~size_t(15);   // (the rest of the frame's slot is never read)
             std::memset(h_stream + beg[i] + frames[i].n, 0, padded - frames[i].n);
         }
         // uploads are queued on the codec's stream and waited for once, where the host needs them
@@ -251,7 +254,9 @@ struct Msv1Codec : jsp_codec {
                 // an odd trailing byte is left to the host parser (it only matters when the chain reaches it,
                 // and then the stream counts as too short)
                 const size_t n_even = frames[i].n & ~size_t(1);
-                const int t = (int)((n_even + tile_bytes - 1) / tile_bytes);
+                // the frame's slot in the stream buffer, in tiles (the last one is all padding when an odd trailing
+                // byte is the only thing in it: it parses as "covers nothing")
+                const int t = (int)((frames[i].n + tile_bytes - 1) / tile_bytes);
                 // 16-bit early-outs (MSVideo1.hx:109-110) are settled by the host parser
                 const bool pre_host = geo.bits == 16 && frames[i].n < size_of_just_skips;
                 h_pf[i] = Msv1ParseFrame{(uint32_t)beg[i], (uint32_t)(beg[i] + n_even), (uint32_t)(i * nblk), (uint32_t)ntiles,
@@ -340,6 +345,7 @@ struct Msv1Codec : jsp_codec {
                 // nothing to paint: every block untouched, the frame rides along as a no-op
             } else if (pr.aborted) {
                 st->status[i] = JSP_ERROR_OCCURED;  // the reference raises out of DecompressP here
+                st->why = "skip code before any frame was decoded: the reference raises here";
             } else {
                 // significance, MSVideo1.hx:187-204 / 372-388
                 int sg = 0;
@@ -464,9 +470,31 @@ struct Msv1Codec : jsp_codec {
                 st->h_fault.reserve(sizeof(uint32_t));
                 *static_cast<uint32_t*>(st->h_fault.p) = 0;
                 st->epoch = 0;
-                st->tickets = 0;
+                // one record per tile: what msv1_fused_kernel needs to know about it
+                st->h_recs.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
+                st->d_recs.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
+                auto* recs = static_cast<Msv1TileRec*>(st->h_recs.p);
+                const uint32_t tile_bytes = msv1_parse_tile_bytes();
+                for (int i = 0; i < nf; ++i)
+                    for (uint32_t k = 0; k < h_pf[i].ntiles; ++k) {
+                        Msv1TileRec& r = recs[h_pf[i].first_tile + k];
+                        r.byte0 = h_pf[i].beg + k * tile_bytes;   // == (first_tile + k) * tile_bytes: frames start on tile boundaries
+                        r.frame_end = h_pf[i].end;
+                        r.data_end = geo.bits == 16 ? h_pf[i].end : h_frames[i].stream_end;
+                        r.k = k;
+                        r.first_tile = h_pf[i].first_tile;
+                        r.ntiles = h_pf[i].ntiles;
+                        r.cmp_row_lo = h_frames[i].cmp_row_lo;
+                        r.flags = h_pf[i].host_parsed ? MSV1_TILE_SKIP : 0u;
+                        r.dst = h_frames[i].dst;
+                        r.prev = h_frames[i].prev;
+                        r.signif = h_frames[i].signif;
+                        r.pad = 0;
+                    }
+                JSP_HIP(hipMemcpyAsync(st->d_recs.p, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
+                // published tile tables carry the launch epoch (first launch: 1), so stale words must read as epoch 0
                 JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1), stream));
-                JSP_HIP(hipMemsetAsync(st->d_sync.p, 0, 2 * sizeof(uint32_t), stream));
+                JSP_HIP(hipMemsetAsync(st->d_sync.p, 0, 2 * sizeof(uint32_t), stream));   // the fault word
             }
         }
         st->info.host_stage_ms = now_ms() - t0 - gpu_parse_ms;

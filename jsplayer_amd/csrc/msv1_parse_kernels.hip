@@ -19,6 +19,10 @@
 // Frames the reference treats specially (stream ends before all blocks are covered, 8-bit end
 // marker, skip code with no previous frame, 16-bit early-outs) are detected from the counters these
 // kernels return and re-done by the host parser (msv1_host.cpp), which is exact for every input.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "msv1.h"
 
 namespace jsp {
@@ -89,6 +93,51 @@ __device__ __forceinline__ void lane_table(const uint32_t (&w)[17], uint32_t p0,
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) tab[e] = d[e];
+}
+
+// lane_table for a lane whose 32 slots and their 4-byte halo lie wholly inside the frame's data (every tile of a frame
+// but the last): no end-of-data tests, the two slots of a dword classified straight from its halves, block counts
+// added with the hardware's saturating add.  A saturated value is all ones: its exit-slot bits (15) then point past the
+// 9 table entries, which is harmless — every consumer sees "more blocks than the frame has" first, and the LDS rows
+// read through such an index lie inside the kernels' own arenas.
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
+
+template <int BITS>
+__device__ __forceinline__ void lane_table_fast(const uint32_t (&w)[17], uint32_t (&cls)[LSLOTS], uint32_t (&tab)[9]) {
+    // one reverse pass: a slot is classified and folded into the 9-deep window (dw[k] = value of slot s+1+k) while
+    // its predicates are still in flight
+    uint32_t dw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dw[k] = pack(k, 0);
+#pragma unroll
+    for (int s = LSLOTS - 1; s >= 0; --s) {
+        const uint32_t d = w[s >> 1], dn = w[(s + 1) >> 1];
+        const int sh = (s & 1) * 16, shn = ((s + 1) & 1) * 16;       // where the slot's / the next slot's 16-bit word sits
+        const bool skip = (d & (0xFC00u << sh)) == (0x8400u << sh);
+        const uint32_t n = (d >> sh) & 0x3FFu;                         // skip count (valid when `skip`)
+        const uint32_t nblk = n ? n : 0xFFFFFu;                        // 0 = "the rest of the frame"
+        uint32_t c, nx;
+        if (BITS == 16) {
+            const bool pattern = (d & (0x8000u << sh)) == 0u;          // high byte < 0x80
+            const bool eight = (dn & (0x8000u << shn)) != 0u;          // bit 15 of the first colour
+            c = pattern ? (eight ? 9u | 0x110u : 3u | 0x110u) : 1u | 0x110u;
+            nx = pattern ? (eight ? dw[8] : dw[2]) : dw[0];
+        } else {
+            const uint32_t cw = (d >> sh) & 0xFFFFu;
+            const bool two = cw < 0x8000u, eight = cw >= 0x9000u;
+            c = two ? 2u | 0x110u : (eight ? 5u | 0x110u : 1u | 0x110u);
+            nx = two ? dw[1] : (eight ? dw[4] : dw[0]);
+            if (cw == 0u) c = 1u | 32u;                                // end marker: covers nothing
+        }
+        c = skip ? ((nblk << 8) | 1u) : c;
+        cls[s] = c;
+        const uint32_t v = sat_add(nx, (c >> 4) & 0xFFFFFFF0u);
+#pragma unroll
+        for (int k = 8; k > 0; --k) dw[k] = dw[k - 1];
+        dw[0] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tab[e] = dw[e];
 }
 
 // Stage a tile through LDS and hand every lane its 17 dwords.
@@ -278,8 +327,9 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // Fused parse + reconstruction: raw stream bytes -> pixels in ONE launch, no descriptor table in HBM.
 //
-// One workgroup per 16 KiB tile of a frame's stream, tiles taken in stream order through a ticket counter
-// (so every tile with a lower number is already resident: what the look-back below relies on).  Per tile:
+// One workgroup per 16 KiB tile of a frame's stream, in stream order (workgroups are dispatched in increasing
+// index, so every tile with a lower number is already resident or done: what the look-back below relies on; a
+// tile that waits too long raises a fault word: the batch is then reported as failed, never silently wrong).  Per tile:
 //   1. the tile's bytes go to LDS once (bytes past the frame's end zeroed); every lane builds the table of
 //      its 32 slots (register-resident reverse DP) and the 256 tables are reduced by composition -> the
 //      tile's table "entry slot 0..8 -> (exit slot, blocks covered)";
@@ -301,7 +351,8 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
 constexpr int FSTAGE = TSLOTS;                 // blocks per staging window
 constexpr uint32_t F_SKIP = 0xFFFFu;
 constexpr uint32_t TILE_BYTES = TSLOTS * 2;
-constexpr int LOOKBACK_BATCH = PWG / 9;        // 28 earlier tiles per poll
+constexpr int LOOKBACK_BATCH = 3 * PWG / 9;    // 85 earlier tiles per poll (3 words per lane)
+constexpr int LOOKBACK_SEGS = 7;               // the chain through a batch is walked in 7 segments side by side
 constexpr int LOOKBACK_SPIN_LIMIT = 1 << 18;   // polls before the tile gives up and raises the fault word
 
 typedef uint32_t fu32x4 __attribute__((ext_vector_type(4)));
@@ -315,33 +366,64 @@ __device__ __forceinline__ uint32_t rgb555(uint32_t c) {
 // The 16 pixels of one coded block from its code in LDS.  `avail` = bytes between the code's first byte and the
 // end of the frame's data (8-bit only: the 16-bit stream is zeroed past its end in LDS, and a zero word decodes
 // as the reference decodes a missing one).
+typedef unsigned short fus2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fus2 as_us2(uint32_t v) { fus2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(fus2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+
+// Two RGB555 colours (one per 16-bit half of `p`) -> two 0x00RRGGBB words (MSVideo1.hx:211-214), with packed
+// 16-bit arithmetic: the green/blue bytes and the red byte of both colours are built side by side.
+__device__ __forceinline__ void rgb555_pair(uint32_t p, uint32_t& lo, uint32_t& hi) {
+    const fus2 v = as_us2(p);
+    const fus2 m_g = {0x03E0, 0x03E0}, m_b = {0x001F, 0x001F}, m_r = {0x7C00, 0x7C00};
+    const uint32_t gb = as_u32((fus2)(((v & m_g) << (fus2){6, 6}) | ((v & m_b) << (fus2){3, 3})));
+    const uint32_t r = as_u32((fus2)((v & m_r) >> (fus2){7, 7}));
+    lo = __builtin_amdgcn_perm(r, gb, 0x05040100u);   // {gb.b0, gb.b1, r.b0, r.b1}
+    hi = __builtin_amdgcn_perm(r, gb, 0x07060302u);   // {gb.b2, gb.b3, r.b2, r.b3}
+}
+
+// The 16 pixels of one coded block from its code in LDS.  `avail` = bytes between the code's first byte and the
+// end of the frame's data (8-bit only: the 16-bit stream is zeroed past its end in LDS, and a zero word decodes
+// as the reference decodes a missing one).
 template <int BITS>
 __device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail, const uint32_t* s_pal, uint32_t (&px)[16]) {
-    uint32_t c[8], flags;
     if (BITS == 16) {
+        // Branch-free.  The code word's own bits select: bit set -> first colour of the quadrant's pair, clear ->
+        // second (MSVideo1.hx:140-168: flags ^= 0xFFFF, then pal[q + (flags & 1)]).  A 2-colour code uses its pair in
+        // every quadrant; a solid code (high byte >= 0x80) is the pair {word, word}.
         uint32_t w0;
         fu32x4 q;
-        __builtin_memcpy(&w0, __builtin_assume_aligned(code, 2), 4);        // code word + first colour
+        __builtin_memcpy(&w0, __builtin_assume_aligned(code, 2), 4);        // code word | first colour << 16
         __builtin_memcpy(&q, __builtin_assume_aligned(code + 4, 2), 16);    // colours 1..7 (+ 2 bytes of whatever follows)
-        const uint32_t cw = w0 & 0xFFFFu, q0 = w0 >> 16;
-        if ((cw >> 8) < 0x80u) {
-            flags = cw ^ 0xFFFFu;
-            c[0] = rgb555(q0);
-            c[1] = rgb555(q.x);
-            if (q0 & 0x8000u) {
-                c[2] = rgb555(q.x >> 16); c[3] = rgb555(q.y); c[4] = rgb555(q.y >> 16);
-                c[5] = rgb555(q.z); c[6] = rgb555(q.z >> 16); c[7] = rgb555(q.w);
-            } else {
-                c[2] = c[4] = c[6] = c[0];
-                c[3] = c[5] = c[7] = c[1];
-            }
-        } else {
-            flags = 0;
-            const uint32_t v = rgb555(cw);
+        const bool pattern = (w0 & 0x8000u) == 0u;                          // high byte < 0x80
+        const bool eight = (w0 & 0x80008000u) == 0x80000000u;               // ... and bit 15 of the first colour set
+        uint32_t p0 = __builtin_amdgcn_alignbit(q.x, w0, 16);               // {c0, c1}
+        uint32_t p1 = __builtin_amdgcn_alignbit(q.y, q.x, 16);              // {c2, c3}
+        uint32_t p2 = __builtin_amdgcn_alignbit(q.z, q.y, 16);
+        uint32_t p3 = __builtin_amdgcn_alignbit(q.w, q.z, 16);
+        p0 = pattern ? p0 : __builtin_amdgcn_perm(w0, w0, 0x01000100u);     // solid: {word, word}
+        p1 = eight ? p1 : p0;
+        p2 = eight ? p2 : p0;
+        p3 = eight ? p3 : p0;
+        uint32_t c[8];
+        rgb555_pair(p0, c[0], c[1]);
+        rgb555_pair(p1, c[2], c[3]);
+        rgb555_pair(p2, c[4], c[5]);
+        rgb555_pair(p3, c[6], c[7]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = v;
-        }
-    } else {
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int qd = ((y & 2) << 1) + (x & 2);
+                // 0 or ~0 from the pixel's bit, then a bit-field insert: two instructions per pixel (written as
+                // asm so that the compiler does not turn the pair back into and + compare + select)
+                uint32_t m;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w0), "n"(y * 4 + x));
+                px[y * 4 + x] = (c[qd] & m) | (c[qd + 1] & ~m);
+            }
+        return;
+    }
+    uint32_t c[8], flags;
+    {
         const uint32_t w = (uint32_t)code[0] | ((uint32_t)code[1] << 8), b = w >> 8;
         if (b < 0x80u) {
             flags = w;
@@ -371,39 +453,56 @@ __device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail
         }
 }
 
+// One launch: grid = tiles, in stream order.
+// Measured and dropped (profiles/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
+// prefetched into registers, 2-bit packed slot kinds instead of 32 classification registers) hid the tile load but ran
+// the workgroups of a CU in lockstep — every phase then competes for the same issue slots — and was 10 % slower.
 template <int BITS>
-__global__ __launch_bounds__(PWG) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
-                                                         const Msv1ParseFrame* __restrict__ pframes,
-                                                         const uint32_t* __restrict__ tile_frame,
-                                                         const Msv1FrameArgs* __restrict__ fargs,
-                                                         const int32_t* __restrict__ palette,
-                                                         unsigned long long* __restrict__ agg, uint32_t* __restrict__ ticket,
-                                                         uint32_t ticket_base, uint32_t epoch, uint32_t tile0,
-                                                         uint32_t* __restrict__ fault, uint32_t nblocks, int nbx, int X) {
+__global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
+                                                            const Msv1TileRec* __restrict__ recs,
+                                                            const int32_t* __restrict__ palette,
+                                                            unsigned long long* __restrict__ agg, uint32_t epoch,
+                                                            uint32_t tile0, uint32_t* __restrict__ fault,
+                                                            uint32_t nblocks, int nbx, int X) {
     // one LDS arena: [tile bytes | composition tree | per-node entry]; the tree's space becomes the staging
     // window once every lane knows where the chain enters its slots; `enter` doubles as the look-back scratch
-    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = 2 * PWG;
+    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = LOOKBACK_BATCH * 9 + 4;
     static_assert(TREE_W * 2 >= FSTAGE, "staging window must fit in the tree's space");
-    static_assert(LOOKBACK_BATCH * 9 <= ENTER_W, "look-back scratch must fit in `enter`");
+    static_assert(ENTER_W >= 2 * PWG, "`enter` holds one word per tree node");
     __shared__ __align__(16) uint32_t arena[BYTES_W + TREE_W + ENTER_W];
     __shared__ uint32_t s_pal[BITS == 8 ? 256 : 1];
-    __shared__ uint32_t s_tile, s_entry;
+    __shared__ uint32_t s_entry, s_root[9], s_seg[LOOKBACK_SEGS][9];
     uint8_t* lds_bytes = reinterpret_cast<uint8_t*>(arena);
     uint32_t (*tree)[9] = reinterpret_cast<uint32_t (*)[9]>(arena + BYTES_W);
     uint32_t* enter = arena + BYTES_W + TREE_W;
     uint16_t* stage = reinterpret_cast<uint16_t*>(arena + BYTES_W);
-    const int tid = threadIdx.x;
-    if (tid == 0) s_tile = tile0 + (atomicAdd(ticket, 1u) - ticket_base);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    // Tiles are taken in grid order: workgroups are dispatched in increasing index, so every earlier tile of the
+    // frame is resident (or done) when this one polls for its table.  Everything a tile needs to know comes in ONE
+    // record (a uniform, scalar load); its bytes sit at t * TILE_BYTES (frames start on tile boundaries), so the
+    // stream loads do not wait for the record: under a saturated write stream every dependent global round trip
+    // costs microseconds.
+    const uint32_t t = tile0 + blockIdx.x;
+    const Msv1TileRec r = recs[t];
+    if (r.flags & MSV1_TILE_SKIP) return;
     if (BITS == 8) s_pal[tid] = (uint32_t)palette[tid];
-    __syncthreads();
-    const uint32_t t = s_tile;
-    const uint32_t f = tile_frame[t];
-    const Msv1ParseFrame fr = pframes[f];
-    if (fr.host_parsed) return;
-    const Msv1FrameArgs fa = fargs[f];
-    const uint32_t k = t - fr.first_tile;                      // which tile of its frame
-    const uint32_t tile_byte0 = fr.beg + k * TILE_BYTES;
-    const uint32_t data_end = BITS == 16 ? fr.end : fa.stream_end;   // 16-bit: whole code units only
+    const uint32_t k = r.k;                                    // which tile of its frame
+    const uint32_t tile_byte0 = t * TILE_BYTES;                // == r.byte0
+    const uint32_t data_end = r.data_end;                      // 16-bit: whole code units only; 8-bit: every byte
+
+    // ---- 0. look-back loads go out first: the tables of the nearest earlier tiles of the frame (up to LOOKBACK_BATCH
+    //         of them, 3 words per lane) travel while this tile builds its own -----------------------------------
+    const uint32_t nlook = k < (uint32_t)LOOKBACK_BATCH ? k : (uint32_t)LOOKBACK_BATCH;
+    const uint32_t look0 = k - nlook;                          // first tile (within the frame) of that batch
+    unsigned long long lv[3] = {0, 0, 0};
+    {
+        const unsigned long long* look_src = agg + (size_t)(r.first_tile + look0) * 9u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if ((uint32_t)(tid + q * PWG) < nlook * 9u)
+                lv[q] = __hip_atomic_load(look_src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- 1. tile bytes -> LDS (zero past the end of the frame's data), lane tables, composition tree ----
     for (uint32_t o = tid * 16u; o < (uint32_t)BYTES_W * 4u; o += PWG * 16u) {
@@ -424,55 +523,95 @@ __global__ __launch_bounds__(PWG) void msv1_fused_kernel(const uint8_t* __restri
         *reinterpret_cast<uint4*>(lds_bytes + o) = v;
     }
     __syncthreads();
-    uint32_t w[17], cls[LSLOTS], tab[9];
+    uint32_t cls[LSLOTS];
+    const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
+    const bool inside = tile_byte0 + TILE_BYTES + 4u <= r.frame_end;   // every tile of a frame but the last: no end-of-data tests
     {
+        uint32_t w[17], tab[9];
         const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
 #pragma unroll
         for (int i = 0; i < 17; ++i) w[i] = mine_w[i];
-    }
-    const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
-    lane_table<BITS>(w, p0, fr.end, cls, tab);
+        if (inside) lane_table_fast<BITS>(w, cls, tab);
+        else lane_table<BITS>(w, p0, r.frame_end, cls, tab);
 #pragma unroll
-    for (int e = 0; e < 9; ++e) tree[tid][e] = tab[e];
-    __syncthreads();
-    for (int l = 1; l <= 8; ++l) {
-        const int nodes = PWG >> l, lo = tree_row(l - 1), hi = tree_row(l);
-        for (int i = tid; i < nodes * 9; i += PWG) {
-            const int j = i / 9, e = i - j * 9;
+        for (int e = 0; e < 9; ++e) tree[tid][e] = tab[e];
+    }
+    // Composition tree, levels 1..6 inside each wave: a wave's LDS accesses execute in order, so no workgroup
+    // barrier is needed between levels — only the wave's own writes have to have been issued (wave_sync).
+    wave_sync();
+    for (int l = 1; l <= 6; ++l) {
+        const int nodes = 64 >> l, lo = tree_row(l - 1), hi = tree_row(l), base = (wave * 64) >> l;
+        for (int i = lane; i < nodes * 9; i += 64) {
+            const int j = base + i / 9, e = i % 9;
             tree[hi + j][e] = compose(tree[lo + 2 * j][e], tree[lo + 2 * j + 1]);
         }
-        __syncthreads();
+        wave_sync();
     }
-    // ---- 2. publish the tile's table (the last tile of a frame has no reader) -------------------------------
-    if (k + 1u < fr.ntiles && tid < 9)
-        __hip_atomic_store(agg + (size_t)t * 9u + tid, ((unsigned long long)epoch << 32) | tree[tree_row(8)][tid],
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- 3. look-back over the earlier tiles of the frame, LOOKBACK_BATCH at a time -------------------------
+    __syncthreads();                                           // the four wave tables (level 6) are in place
+    // the tile's table = the four wave tables chained, one entry slot per lane
+    if (tid < 9) {
+        uint32_t v = tree[tree_row(6)][tid];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) v = compose(v, tree[tree_row(6) + u]);
+        s_root[tid] = v;
+        // ---- 2. publish the tile's table (the last tile of a frame has no reader): a word is its own flag --------
+        if (k + 1u < r.ntiles)
+            __hip_atomic_store(agg + (size_t)t * 9u + tid, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- 3. look-back: chain the earlier tiles' tables from entry slot 0 of the frame --------------------------
     {
         uint32_t e = 0, blocks = 0;                            // thread 0 carries the chain
+        // frames with more than LOOKBACK_BATCH earlier tiles: the far ones first, batch by batch (rare: > 1.3 MB frames)
         for (uint32_t j0 = 0; j0 < k; j0 += LOOKBACK_BATCH) {
-            const uint32_t nj = k - j0 < (uint32_t)LOOKBACK_BATCH ? k - j0 : (uint32_t)LOOKBACK_BATCH;
-            const bool wanted = (uint32_t)tid < nj * 9u;
-            const unsigned long long* src = agg + (size_t)(fr.first_tile + j0) * 9u + tid;
-            unsigned long long v = 0;
-            bool have = !wanted;
-            for (int spin = 0;; ++spin) {
-                if (!have) {
-                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    have = (uint32_t)(v >> 32) == epoch;
-                }
-                if (__syncthreads_and(have)) break;
+            const bool last = j0 + LOOKBACK_BATCH >= k;        // the batch whose loads are already in flight
+            const uint32_t b0 = last ? look0 : j0, nj = last ? nlook : (uint32_t)LOOKBACK_BATCH;
+            const unsigned long long* src = agg + (size_t)(r.first_tile + b0) * 9u;
+            unsigned long long v[3];
+            bool have = true;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
+                v[q] = last ? lv[q] : (wanted ? __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+                have &= !wanted || (uint32_t)(v[q] >> 32) == epoch;
+            }
+            for (int spin = 0; !__syncthreads_and(have); ++spin) {
                 if (spin > LOOKBACK_SPIN_LIMIT) {              // uniform: every lane counts the same rounds
-                    if (tid == 0) atomicOr(fault, 1u);
+                    if (tid == 0) atomicOr(fault, 1u);         // reported by jsp_staged_results / the call as an error
                     return;
                 }
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(8);
+                have = true;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
+                    if (wanted && (uint32_t)(v[q] >> 32) != epoch)
+                        v[q] = __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    have &= !wanted || (uint32_t)(v[q] >> 32) == epoch;
+                }
             }
-            if (wanted) enter[tid] = (uint32_t)v;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if ((uint32_t)(tid + q * PWG) < nj * 9u) enter[tid + q * PWG] = (uint32_t)v[q];
+            __syncthreads();
+            // chain tables [skip, nj) of the batch: LOOKBACK_SEGS segments walked side by side for all 9 entry slots
+            // (lane = segment x entry), then thread 0 hops over the segment results
+            const uint32_t skip = last ? j0 - b0 : 0u;         // already chained by the batch before
+            const uint32_t todo = nj - skip, per = (todo + LOOKBACK_SEGS - 1) / LOOKBACK_SEGS;
+            if (tid < LOOKBACK_SEGS * 9) {
+                const uint32_t g = tid / 9u, e0 = tid - g * 9u;
+                uint32_t se = e0, sb = 0;
+                const uint32_t lo = skip + g * per, hi = lo + per < nj ? lo + per : nj;
+                for (uint32_t j = lo; j < hi; ++j) {
+                    const uint32_t tv = enter[j * 9u + se];
+                    se = tv & 15u;
+                    sb = sb + (tv >> 4) > BSAT ? BSAT : sb + (tv >> 4);
+                }
+                s_seg[g][e0] = pack(se, sb);
+            }
             __syncthreads();
             if (tid == 0) {
-                for (uint32_t j = 0; j < nj; ++j) {
-                    const uint32_t tv = enter[j * 9u + e];
+                for (uint32_t g = 0; g < (uint32_t)LOOKBACK_SEGS; ++g) {
+                    const uint32_t tv = s_seg[g][e];
                     e = tv & 15u;
                     blocks = blocks + (tv >> 4) > BSAT ? BSAT : blocks + (tv >> 4);
                 }
@@ -485,35 +624,41 @@ __global__ __launch_bounds__(PWG) void msv1_fused_kernel(const uint8_t* __restri
     // ---- 4. down-sweep of ONE value per node: where the chain enters the node and with which block ----------
     const uint32_t entry = s_entry;
     const uint32_t tb0 = entry >> 4;
-    if (tid == 0) enter[tree_row(8)] = entry;
-    __syncthreads();
-    for (int l = 8; l >= 1; --l) {
-        const int nodes = PWG >> l, hi = tree_row(l), lo = tree_row(l - 1);
-        if (tid < nodes) {
-            const uint32_t v = enter[hi + tid];
-            enter[lo + 2 * tid] = v;
-            enter[lo + 2 * tid + 1] = add_blocks(tree[lo + 2 * tid][v & 15u], v >> 4);
+    if (lane == 0) {                                           // where the chain enters this wave
+        uint32_t v = entry;
+        for (int u = 0; u < wave; ++u) v = compose(v, tree[tree_row(6) + u]);
+        enter[tree_row(6) + wave] = v;
+    }
+    wave_sync();
+    for (int l = 6; l >= 1; --l) {
+        const int nodes = 64 >> l, hi = tree_row(l), lo = tree_row(l - 1), base = (wave * 64) >> l;
+        if (lane < nodes) {
+            const int j = base + lane;
+            const uint32_t v = enter[hi + j];
+            enter[lo + 2 * j] = v;
+            enter[lo + 2 * j + 1] = add_blocks(tree[lo + 2 * j][v & 15u], v >> 4);
         }
-        __syncthreads();
+        wave_sync();
     }
     const uint32_t mine = enter[tid];
-    const uint32_t whole = add_blocks(tree[tree_row(8)][entry & 15u], tb0) >> 4;   // blocks covered once this tile is done
+    const uint32_t whole = add_blocks(s_root[entry & 15u], tb0) >> 4;   // blocks covered once this tile is done
     const uint32_t span_end = whole < nblocks ? whole : nblocks;
     __syncthreads();                                           // tree and enter are dead: the staging window takes their place
 
-    const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(fa.prev);
-    uint32_t* __restrict__ dstf = reinterpret_cast<uint32_t*>(fa.dst);
+    const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(r.prev);
+    uint32_t* __restrict__ dstf = reinterpret_cast<uint32_t*>(r.dst);
     for (uint32_t w0 = tb0; w0 < span_end; w0 += FSTAGE) {     // more than one window only behind long skip runs
         const uint32_t wn = span_end - w0 < (uint32_t)FSTAGE ? span_end - w0 : (uint32_t)FSTAGE;
         for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG) reinterpret_cast<uint32_t*>(stage)[i] = 0xFFFFFFFFu;
         __syncthreads();
         {
+            // replay the lane's slots: the chain visits slot `pos`; a coded block leaves the offset of its code
             uint32_t pos = mine & 15u, blk = mine >> 4;
 #pragma unroll
             for (int s = 0; s < LSLOTS; ++s) {
                 if (pos == (uint32_t)s && blk < nblocks) {
                     const uint32_t c = cls[s];
-                    if (p0 + 2u * s < fr.end) {
+                    if (inside || p0 + 2u * s < r.frame_end) {
                         if ((c & 16u) && blk - w0 < wn) stage[blk - w0] = (uint16_t)(tid * (LSLOTS * 2) + 2 * s);
                         const uint32_t nb = blk + (c >> 8);
                         blk = nb > BSAT ? BSAT : nb;
@@ -523,19 +668,21 @@ __global__ __launch_bounds__(PWG) void msv1_fused_kernel(const uint8_t* __restri
             }
         }
         __syncthreads();
-        // ---- 5. reconstruction: lane = block, raster order ----------------------------------------------------
+        // ---- 5. reconstruction: lane = block, raster order; block coordinates advance by PWG blocks per round ----
+        uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
         for (uint32_t i = tid; i < wn; i += PWG) {
-            const uint32_t blk = w0 + i;
             const uint32_t o = stage[i];
-            const uint32_t by = blk / (uint32_t)nbx, bx = blk - by * (uint32_t)nbx;
-            const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
+            const uint32_t di = (by * (uint32_t)X + bx) * 4u;          // pixel index: a frame has fewer than 2^28 pixels
             uint32_t* __restrict__ dst = dstf + di;
+            const uint32_t by_now = by;
+            bx += PWG;
+            while (bx >= (uint32_t)nbx) { bx -= (uint32_t)nbx; ++by; }
             if (o == F_SKIP) {
                 const uint32_t* __restrict__ pv = prev + di;
 #pragma unroll
                 for (int y = 0; y < 4; ++y) {
-                    const fu32x4 r = *(fcgu32x4*)(pv + (size_t)y * X);
-                    __builtin_nontemporal_store(r, (fgu32x4*)(dst + (size_t)y * X));
+                    const fu32x4 q = *(fcgu32x4*)(pv + (size_t)y * X);
+                    __builtin_nontemporal_store(q, (fgu32x4*)(dst + (size_t)y * X));
                 }
                 continue;
             }
@@ -544,19 +691,19 @@ __global__ __launch_bounds__(PWG) void msv1_fused_kernel(const uint8_t* __restri
 #pragma unroll
             for (int y = 0; y < 4; ++y)
                 __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
-            if (fa.cmp_row_lo != 0xFFFFFFFFu) {                // stage-2 significance, MSVideo1.hx:195-204
+            if (r.cmp_row_lo != 0xFFFFFFFFu) {                  // stage-2 significance, MSVideo1.hx:195-204
                 const uint32_t* __restrict__ pv = prev + di;
                 bool diff = false;
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
-                    if (by * 4u + y >= fa.cmp_row_lo) {
-                        const fu32x4 r = *(fcgu32x4*)(pv + (size_t)y * X);
-                        diff |= (r.x != px[y * 4]) | (r.y != px[y * 4 + 1]) | (r.z != px[y * 4 + 2]) | (r.w != px[y * 4 + 3]);
+                    if (by_now * 4u + y >= r.cmp_row_lo) {
+                        const fu32x4 q = *(fcgu32x4*)(pv + (size_t)y * X);
+                        diff |= (q.x != px[y * 4]) | (q.y != px[y * 4 + 1]) | (q.z != px[y * 4 + 2]) | (q.w != px[y * 4 + 3]);
                     }
-                if (diff && __hip_atomic_load(fa.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(fa.signif, 1u);
+                if (diff && __hip_atomic_load(r.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(r.signif, 1u);
             }
         }
-        __syncthreads();                                       // the window is refilled by the next round
+        if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
     }
 }
 
@@ -587,17 +734,16 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 }
 
 
-void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_pframes,
-                       const uint32_t* d_tile_frame, const Msv1FrameArgs* d_fargs, const int32_t* d_palette,
-                       unsigned long long* d_agg, uint32_t* d_ticket, uint32_t ticket_base, uint32_t epoch, uint32_t tile0,
-                       int ntiles, uint32_t* d_fault, hipStream_t stream) {
+void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
+                       unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
+                       hipStream_t stream) {
     if (ntiles <= 0) return;
     if (geo.bits == 16)
-        hipLaunchKernelGGL(msv1_fused_kernel<16>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_pframes, d_tile_frame, d_fargs,
-                           d_palette, d_agg, d_ticket, ticket_base, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
+        hipLaunchKernelGGL(msv1_fused_kernel<16>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, d_agg, epoch,
+                           tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
     else
-        hipLaunchKernelGGL(msv1_fused_kernel<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_pframes, d_tile_frame, d_fargs,
-                           d_palette, d_agg, d_ticket, ticket_base, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
+        hipLaunchKernelGGL(msv1_fused_kernel<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, d_agg, epoch,
+                           tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
 }
 
 }  // namespace jsp

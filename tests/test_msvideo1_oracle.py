@@ -14,6 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 KATS = json.load(open(os.path.join(HERE, "golden", "msv1_kat.json")))
 
 
+def _why(codec):
+    """the native library's description of the last failure (product codecs only)"""
+    try:
+        from jsplayer_amd import _native
+        return _native.last_error() if hasattr(codec, "_h") else ""
+    except Exception:
+        return ""
+
+
 def run_kat(make_codec, new_buf, read_buf, kat):
     """Drive one known-answer vector through a codec with the IVideoCodec call protocol."""
     w, h = kat["w"], kat["h"]
@@ -25,7 +34,7 @@ def run_kat(make_codec, new_buf, read_buf, kat):
         dst = next(b for b in bufs if b is not prev)
         src = bytes(fr["src"])
         if fr["key"]:
-            assert codec.DecompressI(src, dst) == 0
+            assert codec.DecompressI(src, dst) == 0, _why(codec)
             got = codec.PreviousFrame()
         else:
             res = codec.DecompressP(src, dst)
