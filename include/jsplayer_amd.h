@@ -120,9 +120,33 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
  *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its
  *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame. */
+/*   "async_depth" = "1".."16" (default "4") : any codec.  Frames that may be in flight between jsp_decompress_*_async and
+ *       jsp_wait. */
 int jsp_set_option(jsp_codec* c, const char* key, const char* value);
-/* Block until everything queued by this codec has finished. */
+/* Block until everything queued by this codec has finished (frames in flight on the asynchronous path stay to be
+ * collected with jsp_wait). */
 int jsp_sync(jsp_codec* c);
+
+/* ---- asynchronous per-frame calls: the `_async` variant SURVEY.md 8(b) allows for the one-call-per-tick surface
+ * (Manager.hx:507,511) --------------------------------------------------------------------------------------------
+ * jsp_decompress_i_async / jsp_decompress_p_async run the frame's HOST stage, queue its uploads and kernels and return
+ * at once with a ticket; jsp_wait(ticket) blocks until that frame is complete and hands back exactly what the
+ * synchronous call would have returned (DecoderState, *data_pnt, *significant_changes).  So the host stage of frame
+ * n+1 (entropy decode, parse pre-scan, copy into pinned memory) overlaps the uploads and kernels of frame n.
+ *   - device frame buffers only; frames complete in submission order; tickets must be waited for in that order;
+ *   - at most "async_depth" frames (jsp_set_option, default 4, 1..16) may be in flight: a further submission fails;
+ *   - `src` must stay valid and unchanged, and `dst` untouched, until the frame's ticket has been waited for; if `src`
+ *     lies in memory from jsp_host_alloc (pinned), it is uploaded from where it is, without a staging copy;
+ *   - jsp_previous_frame() answers for the last SUBMITTED frame (adoption is decided by the host stage);
+ *   - a frame the GPU cannot settle alone (MSVideo1: truncated stream, 8-bit end marker, skip code with nothing to
+ *     copy from) is transparently re-run through the synchronous path inside jsp_wait, together with the frames
+ *     submitted after it. */
+int jsp_decompress_i_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, uint64_t* ticket);
+int jsp_decompress_p_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, uint64_t* ticket);
+int jsp_wait(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* significant_changes);
+/* Pinned host memory for compressed frames (what an AVI reader fills): uploads from it need no staging copy. */
+void* jsp_host_alloc(size_t bytes);
+void jsp_host_free(void* p);
 
 /* Equivalent to calling DecompressI on frames 0..n-1 in order (Manager.hx:507 in a loop); device
  * `dsts` only.  Key-frame-only MSVideo1 batches decode in ONE launch (grid.y = frame). */

@@ -91,6 +91,7 @@ class _NativeCodec:
         # (held by the StagedBatch); a caller that allocates a fresh buffer per frame does not accumulate them here.
         self._bufs = weakref.WeakValueDictionary()
         self._prev = None
+        self._inflight = {}   # ticket -> (src bytes, dst) of frames between *_async and wait()
 
     # -- IVideoCodec ------------------------------------------------------------------------
     def Preinit(self, insignificant_lines: int) -> None:
@@ -135,6 +136,42 @@ class _NativeCodec:
             raise CodecError(N.last_error())
         data = self._prev if out_ptr.value else None   # *data_pnt is the previous frame after the call
         return PFrameResult(data, bool(signif.value))
+
+    # -- asynchronous form of DecompressI / DecompressP (jsp_decompress_*_async ... jsp_wait) ------------------
+    def DecompressI_async(self, src, dst) -> int:
+        """Host stage now, uploads and kernels queued; returns a ticket for wait().  `src` and `dst` are kept alive here
+        until then; device frame buffers only."""
+        return self._submit(self._lib.jsp_decompress_i_async, src, dst, True)
+
+    def DecompressP_async(self, src, dst) -> int:
+        return self._submit(self._lib.jsp_decompress_p_async, src, dst, False)
+
+    def _submit(self, fn, src, dst, key: bool) -> int:
+        keep, p, n = _src_arg(src)
+        addr = _frame_ptr(dst, self.X * self.Y)
+        self._bufs[addr] = dst
+        ticket = C.c_uint64(0)
+        if fn(self._h, p, n, C.c_void_p(addr), C.byref(ticket)) != 0:
+            raise CodecError(N.last_error())
+        self._inflight[ticket.value] = (keep, dst, key)
+        self._track_prev()
+        return ticket.value
+
+    def wait(self, ticket: int):
+        """What the synchronous call would have returned for the frame submitted under `ticket` (tickets are waited for
+        in submission order): a DecoderState for DecompressI_async, a PFrameResult for DecompressP_async (CodecError
+        where DecompressP raises)."""
+        if ticket not in self._inflight:
+            raise CodecError(f"no frame in flight under ticket {ticket}")
+        out_ptr, signif = C.c_void_p(), C.c_int(0)
+        rc = self._lib.jsp_wait(self._h, ticket, C.byref(out_ptr), C.byref(signif))
+        _, _, key = self._inflight.pop(ticket)
+        self._track_prev()
+        if key:
+            return DecoderState(rc)
+        if rc != 0:
+            raise CodecError(N.last_error())
+        return PFrameResult(self._bufs.get(out_ptr.value) if out_ptr.value else None, bool(signif.value))
 
     def NeedsIndex(self) -> bool:
         return bool(self._lib.jsp_needs_index(self._h))
@@ -259,6 +296,30 @@ class ScreenPressor(_NativeCodec):
 
     def __init__(self, width: int, height: int, bits_per_pixel: int, device: int = 0):
         super().__init__(width, height, bits_per_pixel, None, device)
+
+
+class HostBuffer:
+    """Pinned host memory for compressed frames (jsp_host_alloc): uploads from it need no staging copy.  `.array` is a
+    numpy uint8 view; frames handed to the *_async calls as slices of it are uploaded from where they are."""
+
+    def __init__(self, nbytes: int):
+        self._lib = N.lib()
+        self._p = self._lib.jsp_host_alloc(max(int(nbytes), 1))
+        if not self._p:
+            raise CodecError("jsp_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 1)).from_address(self._p))
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            self._lib.jsp_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- the two Manager passes that follow the codec (Manager.hx:325-390, 413-419), on the GPU --------

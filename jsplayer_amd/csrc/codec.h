@@ -37,6 +37,19 @@ struct jsp_staged {
     virtual void after_sync() {}   // codec-specific checks of what the kernels reported (called by finish_results)
 };
 
+// One frame in flight on the asynchronous path (jsp_decompress_i_async / _p_async ... jsp_wait).
+struct jsp_async_job {
+    uint64_t ticket = 0;                 // 0 = slot free
+    std::unique_ptr<jsp_staged> st;      // kept from frame to frame: its buffers are recycled
+    hipEvent_t done = nullptr;
+    jsp_frame_in frame{};                // src stays valid until the ticket has been waited for (caller's contract)
+    int32_t* prev_caller_before = nullptr;   // codec state before this frame: what a synchronous re-run starts from
+    int32_t* prev_dev_before = nullptr;
+    int32_t* prev_caller_after = nullptr;    // PreviousFrame() once this frame is done
+    bool redone = false;                 // results already final (the frame was re-run through the synchronous path)
+    int status = 0, significant = 0;
+};
+
 struct jsp_codec {
     int kind = 0;
     int X = 0, Y = 0;
@@ -54,6 +67,11 @@ struct jsp_codec {
 
     std::unique_ptr<jsp_staged> scratch;  // reused by the per-frame entry points
 
+    // asynchronous path: a ring of jobs, tickets count up from 1, frames complete in submission order
+    std::vector<jsp_async_job> jobs;
+    int async_depth = 4;
+    uint64_t next_ticket = 1, oldest_ticket = 1;   // [oldest_ticket, next_ticket) are in flight
+
     virtual ~jsp_codec();
     virtual int preinit(int lines) = 0;
     virtual int is_key_frame(const uint8_t* src, size_t n) = 0;
@@ -65,6 +83,16 @@ struct jsp_codec {
     // has to be uploaded first to keep them as the caller had them).
     virtual bool may_leave_pixels(const jsp_frame_in& f) = 0;
     virtual int set_option(const char*, const char*) { return -1; }
+    // Host stage of ONE frame for the asynchronous path: like stage(), but it must not wait for the GPU (uploads come
+    // from pinned memory owned by the returned object).  What cannot be known without the GPU's answer is settled in
+    // async_finish(), called after the frame's event: false = the frame has to be re-run through the synchronous path.
+    virtual jsp_staged* stage_async(const jsp_frame_in& f, jsp_staged* reuse) {
+        return stage(std::vector<jsp_frame_in>{f}, reuse);
+    }
+    virtual bool async_finish(jsp_staged*) { return true; }
+    // Called (stream idle) before frames are re-run through the synchronous path: undo whatever made the frames in
+    // flight behind the failed one stand still.
+    virtual void async_reset() {}
 
     void init_device(int device_id);
     void activate();

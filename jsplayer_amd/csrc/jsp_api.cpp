@@ -1,4 +1,5 @@
 // extern "C" surface of libjsplayer_amd.so (declared in include/jsplayer_amd.h).
+#include <cstdlib>
 #include <mutex>
 
 #include "codec.h"
@@ -23,6 +24,10 @@ using namespace jsp;
 // ---- jsp_codec common parts ---------------------------------------------------------------
 
 jsp_codec::~jsp_codec() {
+    for (auto& j : jobs) {
+        j.st.reset();
+        if (j.done) (void)hipEventDestroy(j.done);
+    }
     scratch.reset();
     if (own_stream) (void)hipStreamDestroy(own_stream);
 }
@@ -245,8 +250,105 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream) {
 
 int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
     if (!c || !key || !value) return -1;
+    if (std::strcmp(key, "async_depth") == 0) {
+        char* end = nullptr;
+        const long v = std::strtol(value, &end, 10);
+        if (end == value || *end || v < 1 || v > 16 || c->next_ticket != c->oldest_ticket) return -1;
+        c->async_depth = (int)v;
+        return 0;
+    }
     return c->set_option(key, value);
 }
+
+// ---- asynchronous per-frame path ---------------------------------------------------------------------------
+
+namespace {
+
+int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool key, uint64_t* ticket) {
+    if (!c || !dst || !ticket || (!src && n)) throw std::runtime_error("null argument");
+    c->activate();
+    if (classify_pointer(dst) != 1) throw std::runtime_error("asynchronous calls take device frame buffers only");
+    if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
+    c->ptr_mode = 1;
+    if ((int)(c->next_ticket - c->oldest_ticket) >= c->async_depth) throw std::runtime_error("too many frames in flight: jsp_wait for the oldest first");
+    if ((int)c->jobs.size() != c->async_depth) c->jobs.resize(c->async_depth);
+    jsp_async_job& j = c->jobs[c->next_ticket % c->async_depth];
+    if (!j.done) JSP_HIP(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+    j.frame = jsp_frame_in{src, n, key, dst};
+    j.prev_caller_before = c->prev_caller;
+    j.prev_dev_before = c->prev_dev;
+    j.redone = false;
+    jsp_staged* st = c->stage_async(j.frame, j.st.get());
+    if (st != j.st.get()) j.st.reset(st);
+    st->decode(c->stream);
+    JSP_HIP(hipEventRecord(j.done, c->stream));
+    if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
+    if (st->adopted[0]) c->prev_caller = dst;
+    j.prev_caller_after = c->prev_caller;
+    j.ticket = c->next_ticket++;
+    *ticket = j.ticket;
+    return JSP_ZERO_STATE;
+}
+
+// The frame of job `from` could not be settled by the GPU alone: everything from it on is re-run, in order, through
+// the synchronous path (the codec's state is put back to what it was before that frame).
+void redo_from(jsp_codec* c, uint64_t from) {
+    JSP_HIP(hipStreamSynchronize(c->stream));
+    c->async_reset();
+    jsp_async_job& first = c->jobs[from % c->async_depth];
+    c->prev_caller = first.prev_caller_before;
+    c->prev_dev = first.prev_dev_before;
+    for (uint64_t t = from; t < c->next_ticket; ++t) {
+        jsp_async_job& j = c->jobs[t % c->async_depth];
+        int32_t* data = nullptr;
+        int sig = 0;
+        j.status = decompress_one(c, j.frame.src, j.frame.n, j.frame.dst, j.frame.key, &data, &sig);
+        j.significant = sig;
+        j.prev_caller_after = c->prev_caller;
+        j.redone = true;
+    }
+}
+
+}  // namespace
+
+extern "C" int jsp_decompress_i_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, uint64_t* ticket) {
+    return guarded([&] { return submit_async(c, src, n, dst, true, ticket); });
+}
+extern "C" int jsp_decompress_p_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, uint64_t* ticket) {
+    return guarded([&] { return submit_async(c, src, n, dst, false, ticket); });
+}
+extern "C" int jsp_wait(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* significant_changes) {
+    if (data_pnt) *data_pnt = nullptr;
+    if (significant_changes) *significant_changes = 0;
+    return guarded([&] {
+        if (!c) throw std::runtime_error("null codec");
+        if (ticket != c->oldest_ticket || ticket >= c->next_ticket) throw std::runtime_error("tickets are waited for in submission order");
+        c->activate();
+        jsp_async_job& j = c->jobs[ticket % c->async_depth];
+        if (!j.redone) {
+            JSP_HIP(hipEventSynchronize(j.done));
+            j.st->finish_results();
+            if (!c->async_finish(j.st.get())) redo_from(c, ticket);
+            else {
+                j.status = j.st->status[0];
+                j.significant = j.st->significant[0] < 0 ? 0 : j.st->significant[0];
+                if (j.status != JSP_ZERO_STATE)
+                    set_error("%s", j.st->why.empty() ? "decode aborted: the reference raises on this stream" : j.st->why.c_str());
+            }
+        }
+        ++c->oldest_ticket;
+        j.ticket = 0;
+        if (data_pnt) *data_pnt = j.prev_caller_after;
+        if (significant_changes) *significant_changes = j.significant;
+        return j.status;
+    });
+}
+extern "C" void* jsp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void jsp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int jsp_sync(jsp_codec* c) {
     if (!c) { set_error("null codec"); return JSP_ERROR_OCCURED; }

@@ -99,9 +99,24 @@ static_assert(sizeof(Msv1TileRec) == 64, "one record = 64 bytes");
 // Tiles [tile0, tile0 + ntiles) in one launch (no descriptor table).  `d_agg`: 9 words per tile of the batch, zeroed
 // once; `epoch` (> 0) must differ from launch to launch on the same `d_agg`.  *d_fault becomes non-zero if a tile
 // gave up waiting for the tables of the tiles before it (the caller reports the batch as failed).
+// mode 1 / 2 (one frame per launch, `d_info` != null): the scout pass that reports what the descriptor path's parse would
+// have told the host (Msv1AsyncInfo), then the decode pass, which does nothing when d_info->flags & bad_mask; the
+// frame's significance word is d_info->signif; *d_poison (one word per codec instance) is set by a vetoed decode pass
+// and vetoes every later one until the host clears it.  mode 0: the batch form.
+constexpr uint32_t MSV1_ASYNC_SHORT = 1u;     // the stream does not cover every block: the host parser has to settle it
+constexpr uint32_t MSV1_ASYNC_S1 = 2u;        // a coded block lies in a significant block row (MSVideo1.hx:187-194)
+constexpr uint32_t MSV1_ASYNC_END = 4u;       // an 8-bit end-of-data marker sits on the code chain
+constexpr uint32_t MSV1_ASYNC_SKIPCODE = 8u;  // a skip code sits on the code chain
+struct Msv1AsyncInfo {
+    uint32_t flags;
+    uint32_t signif;   // stage-2 significance word (OR-ed with 1 when a compared pixel differs)
+    uint32_t fault;    // look-back gave up
+    uint32_t pad;
+};
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
-                       hipStream_t stream);
+                       hipStream_t stream, Msv1AsyncInfo* d_info = nullptr, int insignificant_blocks = 0, int mode = 0,
+                       uint32_t bad_mask = 0, uint32_t* d_poison = nullptr);
 
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,

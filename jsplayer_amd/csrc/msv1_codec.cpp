@@ -94,6 +94,36 @@ struct Msv1Staged : jsp_staged {
     }
 };
 
+// One frame on the asynchronous path (jsp_decompress_*_async) with the on-GPU parse: the raw bytes, one record per
+// tile and a zeroed report go up, a scout launch and the fused launch parse and rebuild the frame, the report comes back.  Nothing here
+// waits for the GPU; what the host could not know (stage-1 / stage-2 significance, a stream the host parser has to
+// settle) is read from the report once the frame's event has fired (Msv1Codec::async_finish).
+struct Msv1AsyncStaged : jsp_staged {
+    Msv1Geometry geo{};
+    const int32_t* d_palette = nullptr;
+    int ntiles = 0, insignificant_blocks = 0;
+    size_t nbytes = 0;
+    bool have_prev = false, compare = false, key = false;
+    uint32_t* d_poison = nullptr;             // the codec's veto word (see msv1_launch_fused)
+    DeviceBuffer d_stream, d_meta, d_agg;     // d_meta = [tile records | Msv1AsyncInfo]
+    PinnedBuffer h_stream, h_meta, h_info;
+    uint32_t epoch = 0;                        // never reset: d_agg is zeroed only when it is (re)allocated
+    size_t agg_tiles = 0;
+
+    Msv1AsyncInfo* d_info() const { return reinterpret_cast<Msv1AsyncInfo*>(static_cast<uint8_t*>(d_meta.p) + sizeof(Msv1TileRec) * (size_t)ntiles); }
+    void decode(hipStream_t stream) override {
+        auto* info_dev = d_info();
+        const uint32_t bad = MSV1_ASYNC_SHORT | MSV1_ASYNC_END | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE);
+        for (int mode = 1; mode <= 2; ++mode)   // scout, then the decode it may veto
+            msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_meta.p), d_palette,
+                              static_cast<unsigned long long*>(d_agg.p), ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev,
+                              insignificant_blocks, mode, bad, d_poison);
+        JSP_HIP(hipGetLastError());
+        JSP_HIP(hipMemcpyAsync(h_info.p, info_dev, sizeof(Msv1AsyncInfo), hipMemcpyDeviceToHost, stream));
+        decoded = true;
+    }
+};
+
 struct Msv1Codec : jsp_codec {
     Msv1Geometry geo{};
     size_t size_of_just_skips = 0;
@@ -109,6 +139,13 @@ struct Msv1Codec : jsp_codec {
     // rebuilt on demand from the bytes of the last fully parsed frame
     bool block_changes_stale = false;
     std::vector<uint8_t> last_full_frame;
+    // asynchronous path: the last fully parsed frame's bytes stay where they are, in HBM, until somebody needs them
+    const void* last_full_dev = nullptr;
+    size_t last_full_dev_bytes = 0;
+    DeviceBuffer d_poison;   // asynchronous path: set by a vetoed decode pass, cleared by async_reset()
+    void async_reset() override {
+        if (d_poison.p) JSP_HIP(hipMemsetAsync(d_poison.p, 0, sizeof(uint32_t), stream));
+    }
 
     Msv1Codec(int bits, int w, int h, const uint8_t* pal, int pal_bytes) {
         kind = bits == 16 ? JSP_CODEC_MSVIDEO1_16 : JSP_CODEC_MSVIDEO1_8;
@@ -166,6 +203,12 @@ struct Msv1Codec : jsp_codec {
 
     // Host parse of one frame into `desc`, keeping block_changes exact.
     void host_parse(const uint8_t* src, size_t n, uint32_t base, uint32_t* desc, Msv1Parse& pr) {
+        if (block_changes_stale && last_full_dev) {   // (asynchronous path) fetch that frame's bytes from HBM first
+            JSP_HIP(hipStreamSynchronize(stream));
+            last_full_frame.resize(last_full_dev_bytes);
+            if (last_full_dev_bytes) JSP_HIP(hipMemcpy(last_full_frame.data(), last_full_dev, last_full_dev_bytes, hipMemcpyDeviceToHost));
+            last_full_dev = nullptr;
+        }
         if (block_changes_stale) {  // replay the last GPU-parsed frame to recover the per-row flags
             std::vector<uint32_t> scratch((size_t)std::max(geo.nblocks, 1));
             Msv1Parse tmp;
@@ -175,6 +218,136 @@ struct Msv1Codec : jsp_codec {
         }
         msv1_parse(geo, src, n, prev_dev != nullptr, size_of_just_skips, insignificant_blocks, base, desc,
                    block_changes, pr);
+    }
+
+    // What the host can tell about a frame without parsing it: `changes` (a coded block is on the chain — the chain
+    // starts at byte 0 and leading skip codes are one slot each, so the first coded block is found by walking them) and
+    // whether the frame is one the asynchronous path leaves to the synchronous one.
+    struct Prescan { bool sync_path, changes; };
+    Prescan prescan(const uint8_t* src, size_t n) const {
+        if (n < 2 || (geo.bits == 16 && n < size_of_just_skips)) return {true, false};   // early-outs / tiny frames: host parser
+        long covered = 0;
+        for (size_t si = 0; si + 1 < n && covered < geo.nblocks; si += 2) {
+            const unsigned a = src[si], b = src[si + 1];
+            if (geo.bits == 8 && a == 0 && b == 0) return {true, false};                 // end marker at the head of the chain
+            if ((b & 0xFC) != 0x84) return {false, true};                                // a coded block
+            const long cnt = (long)(((b - 0x84) << 8) + a);
+            if (cnt == 0) return {true, false};                                          // "skip -1": everything left is copied
+            covered += cnt;
+        }
+        return {covered < geo.nblocks, false};   // all skip codes: nothing coded; too short = host parser
+    }
+
+    jsp_staged* stage_async(const jsp_frame_in& f, jsp_staged* reuse) override {
+        activate();
+        const bool aligned = (X & 3) == 0 && !(reinterpret_cast<uintptr_t>(f.dst) & 15) && !(reinterpret_cast<uintptr_t>(prev_dev) & 15);
+        const size_t tile_bytes = msv1_parse_tile_bytes();
+        const Prescan ps = prescan(f.src, f.n);
+        if (!opt_gpu_parse || !aligned || (Y & 3) || ps.sync_path || geo.nblocks <= 0 || geo.nblocks >= (1 << 20) ||
+            f.n + tile_bytes > 0xFFFFFFF0u || (geo.bits == 8 && !d_palette.p)) {
+            // the synchronous staging (it may wait for the GPU: tiny, odd or pre-parsed frames only)
+            return stage(std::vector<jsp_frame_in>{f}, dynamic_cast<Msv1Staged*>(reuse));
+        }
+        const double t0 = now_ms();
+        auto* st = dynamic_cast<Msv1AsyncStaged*>(reuse);
+        std::unique_ptr<Msv1AsyncStaged> guard;
+        if (!st) { st = new Msv1AsyncStaged(); guard.reset(st); }
+        st->geo = geo;
+        st->d_palette = static_cast<const int32_t*>(d_palette.p);
+        st->insignificant_blocks = insignificant_blocks;
+        st->decoded = false;
+        st->why.clear();
+        st->status.assign(1, JSP_ZERO_STATE);
+        st->adopted.assign(1, ps.changes ? 1 : 0);
+        st->significant.assign(1, 0);
+        st->cleared.assign(1, 0);
+        st->nbytes = f.n;
+        st->have_prev = prev_dev != nullptr;
+        st->key = f.key;
+        if (!d_poison.p) {
+            d_poison.reserve(sizeof(uint32_t));
+            JSP_HIP(hipMemsetAsync(d_poison.p, 0, sizeof(uint32_t), stream));
+        }
+        st->d_poison = static_cast<uint32_t*>(d_poison.p);
+        // inter frames with a previous frame are compared against it in any case (whether the result counts is known
+        // only with the stage-1 flag the kernel reports)
+        st->compare = geo.bits == 16 && insign_lines_set && !f.key && prev_dev != nullptr;
+        const size_t n_even = f.n & ~size_t(1);
+        const int nt = (int)((f.n + tile_bytes - 1) / tile_bytes);
+        st->ntiles = nt;
+        const size_t slot = (size_t)nt * tile_bytes;
+        st->d_stream.reserve(slot + 64);
+        const size_t meta_bytes = sizeof(Msv1TileRec) * (size_t)nt + sizeof(Msv1AsyncInfo);
+        st->d_meta.reserve(meta_bytes);
+        st->h_meta.reserve(meta_bytes);
+        st->h_info.reserve(sizeof(Msv1AsyncInfo));
+        if ((size_t)nt > st->agg_tiles) {   // published tile tables carry the launch epoch: fresh memory must read as epoch 0
+            st->d_agg.reserve(sizeof(unsigned long long) * 9 * (size_t)nt);
+            st->agg_tiles = st->d_agg.cap / (sizeof(unsigned long long) * 9);
+            JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, st->d_agg.cap, stream));
+        }
+        auto* recs = static_cast<Msv1TileRec*>(st->h_meta.p);
+        auto* info_dev = st->d_info();
+        for (int k = 0; k < nt; ++k) {
+            Msv1TileRec& r = recs[k];
+            r.byte0 = (uint32_t)(k * tile_bytes);
+            r.frame_end = (uint32_t)n_even;
+            r.data_end = geo.bits == 16 ? (uint32_t)n_even : (uint32_t)f.n;
+            r.k = (uint32_t)k;
+            r.first_tile = 0;
+            r.ntiles = (uint32_t)nt;
+            r.cmp_row_lo = st->compare ? (uint32_t)std::max(insign_lines, 0) : 0xFFFFFFFFu;
+            r.flags = 0;
+            r.dst = f.dst;
+            r.prev = prev_dev;
+            r.signif = &info_dev->signif;
+            r.pad = 0;
+        }
+        std::memset(recs + nt, 0, sizeof(Msv1AsyncInfo));
+        // the frame's bytes: from where they are when the caller keeps them in pinned memory, else through our own
+        const void* up = f.src;
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, f.src) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            st->h_stream.reserve(f.n + 16);
+            std::memcpy(st->h_stream.p, f.src, f.n);
+            up = st->h_stream.p;
+        }
+        JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, stream));
+        JSP_HIP(hipMemcpyAsync(st->d_meta.p, recs, meta_bytes, hipMemcpyHostToDevice, stream));
+        // codec state, as the synchronous path leaves it
+        if (ps.changes) prev_dev = f.dst;
+        block_changes_stale = true;
+        last_full_dev = st->d_stream.p;
+        last_full_dev_bytes = f.n;
+        st->info = jsp_staged_info{};
+        st->info.frames = 1;
+        st->info.pixels = (uint64_t)X * Y;
+        st->info.stream_bytes = f.n;
+        st->info.kernel_launches = 1;
+        st->info.host_stage_ms = now_ms() - t0;
+        st->kernels = "msv1_fused_kernel";
+        guard.release();
+        return st;
+    }
+
+    bool async_finish(jsp_staged* base) override {
+        auto* st = dynamic_cast<Msv1AsyncStaged*>(base);
+        if (!st) return true;                                    // went through the synchronous staging: already settled
+        const Msv1AsyncInfo& in = *static_cast<const Msv1AsyncInfo*>(st->h_info.p);
+        if (in.fault) { st->status[0] = JSP_ERROR_OCCURED; st->why = "msv1_fused_kernel: look-back timed out"; return true; }
+        if ((in.flags & (MSV1_ASYNC_SHORT | MSV1_ASYNC_END)) || ((in.flags & MSV1_ASYNC_SKIPCODE) && !st->have_prev))
+            return false;                                        // the host parser has to settle this stream
+        // significance, MSVideo1.hx:187-204 / 372-388 (key frames report none)
+        const bool s1 = st->adopted[0] && (in.flags & MSV1_ASYNC_S1);
+        int sg = 0;
+        if (s1 && !st->key) {
+            if (!st->have_prev) sg = 1;
+            else if (st->compare) sg = in.signif ? 1 : 0;
+            // 8-bit: NaN loop bound -> no pixel is compared -> false
+        }
+        st->significant[0] = sg;
+        return true;
     }
 
     jsp_staged* stage(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse) override {
@@ -321,6 +494,7 @@ struct Msv1Codec : jsp_codec {
                 if (st->gpu_parse && last_gpu_frame >= 0 && block_changes_stale) {
                     const jsp_frame_in& g = frames[last_gpu_frame];
                     last_full_frame.assign(g.src, g.src + g.n);
+                    last_full_dev = nullptr;
                 }
                 host_parse(f.src, f.n, (uint32_t)beg[i], desc, pr);
                 if (pr.early_out) std::fill(desc, desc + geo.nblocks, MSV1_DESC_UNTOUCHED);
@@ -378,6 +552,7 @@ struct Msv1Codec : jsp_codec {
         if (st->gpu_parse && last_gpu_frame >= 0 && block_changes_stale) {
             const jsp_frame_in& g = frames[last_gpu_frame];
             last_full_frame.assign(g.src, g.src + g.n);
+                    last_full_dev = nullptr;
         }
         st->vec_ok = vec_ok;
         // ---- launch plan ---------------------------------------------------------------------

@@ -457,13 +457,23 @@ __device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail
 // Measured and dropped (profiles/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
 // prefetched into registers, 2-bit packed slot kinds instead of 32 classification registers) hid the tile load but ran
 // the workgroups of a CU in lockstep — every phase then competes for the same issue slots — and was 10 % slower.
-template <int BITS>
+// The asynchronous per-frame path (one frame per launch) runs the kernel twice:
+//   MODE 1, "scout": everything up to the replay, no pixel is written; reports in `info` what the host stage of the
+//           descriptor path learns from its parse — stream too short, coded block in a significant block row (stage-1
+//           significance), 8-bit end marker or skip code on the chain;
+//   MODE 2: the decode proper, which returns at once when the scout found one of the conditions in `bad_mask` — such a
+//           frame is re-done by the synchronous path, and must find `dst` exactly as the caller left it.
+// MODE 0 is the batch form (no report).
+template <int BITS, int MODE>
 __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
                                                             const Msv1TileRec* __restrict__ recs,
                                                             const int32_t* __restrict__ palette,
                                                             unsigned long long* __restrict__ agg, uint32_t epoch,
                                                             uint32_t tile0, uint32_t* __restrict__ fault,
-                                                            uint32_t nblocks, int nbx, int X) {
+                                                            uint32_t nblocks, int nbx, int X,
+                                                            Msv1AsyncInfo* __restrict__ info, uint32_t s1_first_block,
+                                                            uint32_t bad_mask, uint32_t* __restrict__ poison) {
+    constexpr bool INFO = MODE == 1;
     // one LDS arena: [tile bytes | composition tree | per-node entry]; the tree's space becomes the staging
     // window once every lane knows where the chain enters its slots; `enter` doubles as the look-back scratch
     constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = LOOKBACK_BATCH * 9 + 4;
@@ -486,6 +496,14 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     const uint32_t t = tile0 + blockIdx.x;
     const Msv1TileRec r = recs[t];
     if (r.flags & MSV1_TILE_SKIP) return;
+    if (MODE == 2) {
+        // (uniform) the scout handed this frame — or an earlier one still in flight — to the host path: nothing may be
+        // written from here on (later frames reuse, as destination, buffers the re-run still needs to read), until the
+        // host has re-run them and cleared the word
+        const bool bad = (info->flags & bad_mask) != 0u;
+        if (bad && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(poison, 1u);
+        if (bad || __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
     if (BITS == 8) s_pal[tid] = (uint32_t)palette[tid];
     const uint32_t k = r.k;                                    // which tile of its frame
     const uint32_t tile_byte0 = t * TILE_BYTES;                // == r.byte0
@@ -643,14 +661,18 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     const uint32_t mine = enter[tid];
     const uint32_t whole = add_blocks(s_root[entry & 15u], tb0) >> 4;   // blocks covered once this tile is done
     const uint32_t span_end = whole < nblocks ? whole : nblocks;
+    if (INFO && tid == 0 && k + 1u == r.ntiles && whole < nblocks) atomicOr(&info->flags, MSV1_ASYNC_SHORT);   // the stream ends early
     __syncthreads();                                           // tree and enter are dead: the staging window takes their place
 
+    uint32_t seen = 0;                                         // INFO: what this lane's codes on the chain were
     const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(r.prev);
     uint32_t* __restrict__ dstf = reinterpret_cast<uint32_t*>(r.dst);
     for (uint32_t w0 = tb0; w0 < span_end; w0 += FSTAGE) {     // more than one window only behind long skip runs
         const uint32_t wn = span_end - w0 < (uint32_t)FSTAGE ? span_end - w0 : (uint32_t)FSTAGE;
-        for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG) reinterpret_cast<uint32_t*>(stage)[i] = 0xFFFFFFFFu;
-        __syncthreads();
+        if (MODE != 1) {
+            for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG) reinterpret_cast<uint32_t*>(stage)[i] = 0xFFFFFFFFu;
+            __syncthreads();
+        }
         {
             // replay the lane's slots: the chain visits slot `pos`; a coded block leaves the offset of its code
             uint32_t pos = mine & 15u, blk = mine >> 4;
@@ -659,7 +681,9 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                 if (pos == (uint32_t)s && blk < nblocks) {
                     const uint32_t c = cls[s];
                     if (inside || p0 + 2u * s < r.frame_end) {
-                        if ((c & 16u) && blk - w0 < wn) stage[blk - w0] = (uint16_t)(tid * (LSLOTS * 2) + 2 * s);
+                        if (INFO && w0 == tb0)
+                            seen |= (c & 16u) ? (blk >= s1_first_block ? MSV1_ASYNC_S1 : 0u) : ((c & 32u) ? MSV1_ASYNC_END : MSV1_ASYNC_SKIPCODE);
+                        if (MODE != 1 && (c & 16u) && blk - w0 < wn) stage[blk - w0] = (uint16_t)(tid * (LSLOTS * 2) + 2 * s);
                         const uint32_t nb = blk + (c >> 8);
                         blk = nb > BSAT ? BSAT : nb;
                     }
@@ -667,6 +691,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                 }
             }
         }
+        if (MODE == 1) break;                                  // the scout only needed the replay of the first window
         __syncthreads();
         // ---- 5. reconstruction: lane = block, raster order; block coordinates advance by PWG blocks per round ----
         uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
@@ -705,6 +730,11 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         }
         if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
     }
+    if (INFO) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
+        if (lane == 0 && seen) atomicOr(&info->flags, seen);
+    }
 }
 
 }  // namespace
@@ -736,14 +766,16 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
-                       hipStream_t stream) {
+                       hipStream_t stream, Msv1AsyncInfo* d_info, int insignificant_blocks, int mode, uint32_t bad_mask,
+                       uint32_t* d_poison) {
     if (ntiles <= 0) return;
-    if (geo.bits == 16)
-        hipLaunchKernelGGL(msv1_fused_kernel<16>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, d_agg, epoch,
-                           tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
-    else
-        hipLaunchKernelGGL(msv1_fused_kernel<8>, dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, d_agg, epoch,
-                           tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X);
+    const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
+#define JSP_FUSED(BITS, MODE)                                                                                            \
+    hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
+                       d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison)
+    if (geo.bits == 16) { if (mode == 1) JSP_FUSED(16, 1); else if (mode == 2) JSP_FUSED(16, 2); else JSP_FUSED(16, 0); }
+    else { if (mode == 1) JSP_FUSED(8, 1); else if (mode == 2) JSP_FUSED(8, 2); else JSP_FUSED(8, 0); }
+#undef JSP_FUSED
 }
 
 }  // namespace jsp

@@ -25,6 +25,7 @@ struct SpStaged : jsp_staged {
     };
     std::vector<Op> ops;
     DeviceBuffer d_runs, d_rows, d_seeds, d_tileidx, d_left, d_iargs, d_blocks, d_payload, d_gframes;
+    PinnedBuffer h_pack;   // every table of the batch, back to back: the uploads read from here, nobody waits for them
 
     void decode(hipStream_t stream) override {
         for (const Op& op : ops) {
@@ -232,19 +233,25 @@ struct SpCodec : jsp_codec {
             iargs[k].tile_idx = static_cast<const uint32_t*>(st->d_tileidx.p) + iarg_tile_off[k];
             iargs[k].left = static_cast<const uint32_t*>(st->d_left.p) + iarg_left_off[k];
         }
-        auto up = [&](DeviceBuffer& d, const void* h, size_t bytes) {
-            if (bytes) JSP_HIP(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, stream));
-        };
-        up(st->d_runs, runs.data(), runs.size() * sizeof(IRun));
-        up(st->d_rows, rows.data(), rows.size() * 4);
-        up(st->d_seeds, seeds.data(), seeds.size() * 4);
-        up(st->d_tileidx, tileidx.data(), tileidx.size() * 4);
-        up(st->d_left, left.data(), left.size() * 4);
-        up(st->d_iargs, iargs.data(), iargs.size() * sizeof(IFrameArgs));
-        up(st->d_blocks, blocks.data(), blocks.size() * sizeof(PBlock));
-        up(st->d_payload, payload.data(), payload.size() * 4);
-        up(st->d_gframes, gframes.data(), gframes.size() * sizeof(PGroupFrame));
-        JSP_HIP(hipStreamSynchronize(stream));  // the host vectors go out of scope below
+        // the tables go up from pinned memory that belongs to the staged batch: nothing waits for the copies (a batch
+        // is decoded on the same stream, behind them)
+        struct Part { DeviceBuffer* d; const void* h; size_t bytes; };
+        const Part parts[] = {{&st->d_runs, runs.data(), runs.size() * sizeof(IRun)}, {&st->d_rows, rows.data(), rows.size() * 4},
+                              {&st->d_seeds, seeds.data(), seeds.size() * 4}, {&st->d_tileidx, tileidx.data(), tileidx.size() * 4},
+                              {&st->d_left, left.data(), left.size() * 4}, {&st->d_iargs, iargs.data(), iargs.size() * sizeof(IFrameArgs)},
+                              {&st->d_blocks, blocks.data(), blocks.size() * sizeof(PBlock)}, {&st->d_payload, payload.data(), payload.size() * 4},
+                              {&st->d_gframes, gframes.data(), gframes.size() * sizeof(PGroupFrame)}};
+        size_t total = 0;
+        for (const Part& p : parts) total += (p.bytes + 15) & ~size_t(15);
+        st->h_pack.reserve(total + 16);
+        size_t at = 0;
+        for (const Part& p : parts) {
+            if (!p.bytes) continue;
+            uint8_t* h = static_cast<uint8_t*>(st->h_pack.p) + at;
+            std::memcpy(h, p.h, p.bytes);
+            JSP_HIP(hipMemcpyAsync(p.d->p, h, p.bytes, hipMemcpyHostToDevice, stream));
+            at += (p.bytes + 15) & ~size_t(15);
+        }
         st->info.h2d_ms = now_ms() - t1;
         guard.release();
         return st;

@@ -1,0 +1,156 @@
+"""The asynchronous per-frame calls (jsp_decompress_i_async / _p_async ... jsp_wait; run with -m gpu): with several
+frames in flight every frame must come back exactly as the synchronous call — and the CPU oracle — deliver it: same
+DecoderState / PFrameResult (buffer identity, significant_changes), same pixels, including the frames the GPU cannot
+settle alone and hands back to the synchronous path (truncated streams, 8-bit end markers, skip codes with nothing
+to copy from)."""
+import numpy as np
+import pytest
+
+from jsplayer_amd import CodecError, DecoderState, HostBuffer, MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
+from jsplayer_amd import streamgen as sg
+from oracle_binding import OracleAbort, OracleMSVideo1, OracleScreenPressor
+
+pytestmark = pytest.mark.gpu
+
+
+def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36):
+    import torch
+    gpu.Preinit(lines)
+    orc.Preinit(lines)
+    gpu.set_option("async_depth", str(depth))
+    nbuf = 2 * depth + 3   # in flight: a destination each, plus the picture each frame is checked against
+    gbufs = [torch.full((w * h,), 0x00A5A5A5, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    obufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) for _ in range(nbuf)]
+    torch.cuda.synchronize()
+    arena = None
+    if pinned:   # the compressed frames live in pinned memory: uploaded from where they are
+        arena = HostBuffer(sum(len(c) for c in chunks) + 64)
+        pos, srcs = 0, []
+        for c in chunks:
+            arena.array[pos:pos + len(c)] = np.frombuffer(c, dtype=np.uint8)
+            srcs.append(arena.array[pos:pos + len(c)])
+            pos += len(c)
+    else:
+        srcs = list(chunks)
+    inflight = []   # (ticket, frame index, buffer index, oracle result, oracle picture)
+
+    def collect():
+        ticket, i, k, want, picture = inflight.pop(0)
+        if want == "raise":
+            with pytest.raises(CodecError):
+                gpu.wait(ticket)
+            return
+        got = gpu.wait(ticket)
+        if keys[i]:
+            assert (got == DecoderState.zero_state) == (want == 0), f"frame {i}: {got} vs oracle {want}"
+        else:
+            odata_idx, osig = want
+            assert got.significant_changes == osig, f"frame {i}"
+            gi = next((j for j in range(nbuf) if gbufs[j] is got.data_pnt), None)
+            assert gi == odata_idx, f"frame {i}: data_pnt is buffer {gi}, the oracle's is {odata_idx}"
+        if picture is not None:
+            assert np.array_equal(gbufs[picture[0]].cpu().numpy(), picture[1]), f"frame {i}: pixels differ"
+
+    for i, (src, key) in enumerate(zip(srcs, keys)):
+        if len(inflight) == depth:
+            collect()
+        busy = {k for _, _, k, _, _ in inflight} | {p[0] for _, _, _, _, p in inflight if p is not None}
+        oprev = orc.PreviousFrame()
+        k = next(j for j in range(nbuf) if obufs[j] is not oprev and j not in busy)
+        assert gbufs[k] is not gpu.PreviousFrame()
+        raw = bytes(chunks[i])
+        if key:
+            want = orc.DecompressI(raw, obufs[k])
+            t = gpu.DecompressI_async(src, gbufs[k])
+        else:
+            try:
+                odata, osig = orc.DecompressP(raw, obufs[k])
+                want = (next((j for j in range(nbuf) if obufs[j] is odata), None), osig)
+            except OracleAbort:
+                want = "raise"
+            t = gpu.DecompressP_async(src, gbufs[k])
+        onow = orc.PreviousFrame()
+        picture = None
+        if onow is not None and want != "raise":
+            picture = (next(j for j in range(nbuf) if obufs[j] is onow), onow.copy())
+            # adoption is decided by the host stage: PreviousFrame() already answers for the frame just submitted
+            assert gpu.PreviousFrame() is gbufs[picture[0]], f"frame {i}: previous frame after submission"
+        inflight.append((t, i, k, want, picture))
+    while inflight:
+        collect()
+    gpu.StopAndClean()
+    if arena is not None:
+        arena.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
+@pytest.mark.parametrize("bits,size", [(16, (320, 240)), (8, (320, 240)), (16, (1920, 1080)), (16, (64, 48))],
+                         ids=["16-320x240", "8-320x240", "16-1080p", "16-64x48"])
+def test_msvideo1_async_matches_oracle(bits, size, pinned):
+    w, h = size
+    n = 10 if w * h > 500000 else 24
+    frames, keys, pal = sg.msv1_clip(51, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=9)
+    gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
+    gpu.set_option("msv1_parse", "gpu")
+    drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, pinned=pinned)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 8])
+def test_msvideo1_async_hands_unsettled_frames_to_the_synchronous_path(depth):
+    """Truncated streams, an all-skip frame, a skip count of zero ("the rest"), random bytes — in the middle of a clip,
+    with later frames already in flight behind them."""
+    w, h = 320, 240
+    frames, keys, _ = sg.msv1_clip(52, w, h, 14, p_mix=sg.msv1_p_mix(0.6, 10.0))
+    rng = np.random.default_rng(5)
+    frames[3] = frames[3][:len(frames[3]) // 2]                  # stream ends early
+    frames[5] = bytes([0x20, 0x84] * 200)                         # skip codes only, longer than size_of_just_skips
+    frames[7] = bytes([0x00, 0x84]) + frames[7][2:]              # "skip -1": everything after is copied
+    frames[9] = rng.integers(0, 256, 3001, dtype=np.uint8).tobytes()   # noise, odd length
+    frames[11] = frames[11][:17]                                  # a few codes only
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, depth=depth)
+
+
+def test_msvideo1_8bit_end_marker_and_first_frame_skip_code():
+    w, h = 64, 32
+    frames, keys, pal = sg.msv1_clip(53, w, h, 6, bits=8, p_mix=sg.msv1_p_mix(0.5, 6.0))
+    cut = frames[2][:40] + b"\x00\x00" + frames[2][42:]          # end-of-data marker mid frame
+    gpu = MSVideo1_8bit(w, h, pal)
+    gpu.set_option("msv1_parse", "gpu")
+    drive(gpu, OracleMSVideo1(8, w, h, pal), w, h, [frames[0], frames[1], cut, frames[3]], [True, False, False, False], lines=4)
+    # a skip code before anything was decoded: the reference raises out of DecompressP, wait() raises too
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    f16, _, _ = sg.msv1_clip(54, w, h, 3, p_mix=sg.msv1_p_mix(0.5, 6.0))
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, [f16[1], f16[0], f16[2]], [False, True, False])
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_screenpressor_async_matches_oracle(version):
+    w, h = 320, 240
+    chunks, keys, _ = sg.sp_clip(55, w, h, 14, version=version, key_every=6, flat_at=(8,), unchanged_at=(3,))
+    drive(ScreenPressor(w, h, 24), OracleScreenPressor(w, h, 24), w, h, chunks, keys)
+
+
+def test_async_usage_errors():
+    import torch
+    w, h = 64, 48
+    frames, keys, _ = sg.msv1_clip(56, w, h, 4)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.Preinit(36)
+    gpu.set_option("async_depth", "2")
+    bufs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(4)]
+    t0 = gpu.DecompressI_async(frames[0], bufs[0])
+    t1 = gpu.DecompressI_async(frames[1], bufs[1])
+    with pytest.raises(CodecError):
+        gpu.DecompressI_async(frames[2], bufs[2])               # depth reached
+    with pytest.raises(CodecError):
+        gpu.set_option("async_depth", "4")                      # not while frames are in flight
+    assert gpu.wait(t0) == DecoderState.zero_state
+    with pytest.raises(CodecError):
+        gpu.wait(t0)                                            # already collected
+    assert gpu.wait(t1) == DecoderState.zero_state
+    with pytest.raises(CodecError):
+        gpu.DecompressI_async(frames[0], np.zeros(w * h, dtype=np.int32))   # host frame buffers are for the synchronous calls
+    gpu.StopAndClean()
