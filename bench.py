@@ -175,43 +175,39 @@ def main():
             dist.destroy_process_group()
         raise SystemExit("bench.py: decoded frames differ from the oracle: no value printed")
 
-    # ---- end to end: compressed frames in (pinned) host memory -> host stage -> H2D -> kernels, same frames, through the
-    #      asynchronous per-frame calls: the host stage of frame n+1 overlaps the uploads and kernels of frame n ------------
+    # ---- end to end, from the bytes of an AVI file in pinned host memory: AVI walk -> host stage -> H2D -> kernels, one
+    #      frame per call through the asynchronous entry points (the host stage of frame n+1 overlaps the uploads and
+    #      kernels of frame n), by examples/jsp_play — C++ over the C ABI only — for one stream and for one stream per host
+    #      thread (independent codec instances, the way streams shard) ------------------------------------
     e2e = None
-    if not args.no_e2e:
-        from jsplayer_amd import HostBuffer
-        depth = 8
-        ncap = min(len(clips[0].frames), 512 if spec["codec"] == "msv1" else 64)   # a bounded sample of the first clip
-        fr, ky = clips[0].frames[:ncap], clips[0].keys[:ncap]
-        arena = HostBuffer(sum(len(f) for f in fr) + 64)      # what an AVI reader would have filled
-        srcs, pos = [], 0
-        for f in fr:
-            arena.array[pos:pos + len(f)] = np.frombuffer(f, dtype=np.uint8)
-            srcs.append(arena.array[pos:pos + len(f)])
-            pos += len(f)
-        codec = wl.make_codec(name, clips[0].palette, device=local_rank)
-        codec.set_stream(stream.cuda_stream)
-        codec.set_option("async_depth", str(depth))
-        pool = work.dsts[0][:2 * depth + 2]
-        torch.cuda.synchronize()
-        te = time.perf_counter()
-        tickets = []
-        for i, (src, key) in enumerate(zip(srcs, ky)):
-            if len(tickets) == depth:
-                codec.wait(tickets.pop(0)[0])
-            busy = {id(d) for _, d in tickets}
-            prev = codec.PreviousFrame()
-            dst = next(d for d in pool if d is not prev and id(d) not in busy)
-            tickets.append(((codec.DecompressI_async if key else codec.DecompressP_async)(src, dst), dst))
-        while tickets:
-            codec.wait(tickets.pop(0)[0])
-        te = time.perf_counter() - te
-        e2e = {"value": round(len(fr) * W * H / te / 1e6, 1), "unit": "Mpixels/s", "frames": len(fr),
-               "ms_per_frame": round(te * 1e3 / len(fr), 4),
-               "includes": f"compressed frames in pinned host memory -> host stage + H2D + kernels per frame, one frame per call "
-                           f"(jsp_decompress_*_async / jsp_wait, {depth} frames in flight), one host thread"}
-        codec.StopAndClean()
-        arena.close()
+    if not args.no_e2e and args.gpus == 1:
+        import subprocess
+        import tempfile
+        from jsplayer_amd import avi
+        exe = os.path.join(ROOT, "examples", "jsp_play")
+        ncap = min(len(clips[0].frames), 256 if spec["codec"] == "msv1" else (64 if not inter else 150))   # a bounded sample of the first clip
+        fr = clips[0].frames[:ncap]
+        blob = avi.write_avi(W, H, fr, fourcc=b"SCPR" if spec["codec"] == "sp" else b"CRAM",
+                             bpp=24 if spec["codec"] == "sp" else spec["bits"], palette=clips[0].palette, key_flags=clips[0].keys[:ncap])
+        with tempfile.NamedTemporaryFile(suffix=".avi", dir=os.environ.get("TMPDIR", "/tmp")) as tf:
+            tf.write(blob)
+            tf.flush()
+            threads = max(1, min(16, (os.cpu_count() or 1) // max(1, args.gpus)))
+
+            def run(streams, repeat):
+                res = subprocess.run([exe, tf.name, "--pipelined", "--quiet", "--depth", "8", "--streams", str(streams), "--repeat", str(repeat)],
+                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                if res.returncode != 0:
+                    raise SystemExit("examples/jsp_play failed: " + res.stderr.decode()[-500:])
+                return json.loads(res.stdout.decode().strip().splitlines()[-1])
+            rep = 4 if spec["codec"] == "msv1" else 1
+            one, many = run(1, rep), run(threads, rep)
+        e2e = {"value": one["mpixels_per_s"], "unit": "Mpixels/s", "streams": 1, "frames": one["frames"],
+               "ms_per_frame": round(one["seconds"] * 1e3 / one["frames"], 4),
+               "all_threads": {"value": many["mpixels_per_s"], "unit": "Mpixels/s", "streams": threads, "frames": many["frames"],
+                               "note": f"{threads} independent streams (host threads, a codec instance each) playing the same file, one GPU"},
+               "includes": "AVI bytes in pinned host memory -> chunk walk + host stage + H2D + kernels, one frame per call "
+                           "(jsp_decompress_*_async / jsp_wait, 8 frames in flight per stream), examples/jsp_play over the C ABI"}
 
     # trivial counter reduce over RCCL (north_star): frames and pixels decoded by the whole job,
     # time = max over ranks

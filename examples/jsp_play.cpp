@@ -2,6 +2,12 @@
 // what a native host (or an hxcpp build of the player) would do with libjsplayer_amd.so.
 //
 //   jsp_play clip.avi            prints one line per frame:  index key|inter slot significant crc32
+//   jsp_play clip.avi --pipelined [--depth D]
+//                                the same lines, decoded through jsp_decompress_*_async / jsp_wait with D frames in
+//                                flight: the host stage of frame n+1 overlaps the uploads and kernels of frame n
+//   jsp_play clip.avi --pipelined --quiet [--streams T] [--repeat R] [--depth D]
+//                                end-to-end rate: T independent streams (threads, a codec instance each) play the clip R
+//                                times from the file's bytes in pinned memory; prints one JSON line
 //
 // It restates, in this project's own words, only what touches the codec:
 //   * the container facts that select and feed it (AVIParser.hx:42-88,142-171; ParserUtils.hx:24-27):
@@ -14,7 +20,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <deque>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "jsplayer_amd.h"
@@ -41,7 +50,14 @@ struct Clip {
     int X = 0, Y = 0, bpp = 32, kind = JSP_CODEC_SCREENPRESSOR;
     std::vector<uint8_t> palette;
     std::vector<std::pair<size_t, size_t>> frames;   // offset, padded size inside `bytes`
-    std::vector<uint8_t> bytes;
+    std::vector<uint8_t> index_key;                  // idx1 key flags of the video chunks, in file order (empty: no index)
+    struct Bytes {                                   // the file, in pinned host memory (jsp_host_alloc): uploads need no copy
+        uint8_t* p = nullptr;
+        size_t n = 0;
+        const uint8_t* data() const { return p; }
+        size_t size() const { return n; }
+        ~Bytes() { jsp_host_free(p); }
+    } bytes;
 };
 
 bool is_msvc(const uint8_t* f) {
@@ -71,6 +87,9 @@ void walk(Clip& c, size_t lo, size_t hi, bool in_movi, uint8_t (&fourcc)[4], boo
             have_video = true;
         } else if (in_movi && (!std::memcmp(tag, "00dc", 4) || !std::memcmp(tag, "00db", 4))) {
             c.frames.emplace_back(body, std::min(padded, c.bytes.size() - body));
+        } else if (!std::memcmp(tag, "idx1", 4)) {   // AVIOLDINDEX: ckid, flags (0x10 = key frame), offset, size
+            for (size_t e = body; e + 16 <= std::min(body + size, hi); e += 16)
+                if (!std::memcmp(d + e, "00dc", 4) || !std::memcmp(d + e, "00db", 4)) c.index_key.push_back((le32(d + e + 4) & 0x10) ? 1 : 0);
         }
         pos = body + padded;
     }
@@ -82,21 +101,152 @@ bool load(const char* path, Clip& c) {
     std::fseek(f, 0, SEEK_END);
     const long n = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
-    c.bytes.resize(n > 0 ? (size_t)n : 0);
-    const bool ok = n > 12 && std::fread(c.bytes.data(), 1, (size_t)n, f) == (size_t)n;
+    c.bytes.n = n > 0 ? (size_t)n : 0;
+    c.bytes.p = static_cast<uint8_t*>(jsp_host_alloc(c.bytes.n + 64));
+    const bool ok = c.bytes.p && n > 12 && std::fread(c.bytes.p, 1, (size_t)n, f) == (size_t)n;
     std::fclose(f);
     if (!ok || std::memcmp(c.bytes.data(), "RIFF", 4) || std::memcmp(c.bytes.data() + 8, "AVI ", 4)) return false;
     uint8_t fourcc[4] = {0, 0, 0, 0};
     bool video_stream = false, have_video = false;
     walk(c, 12, std::min(c.bytes.size(), (size_t)8 + le32(c.bytes.data() + 4)), false, fourcc, video_stream, have_video);
+    if (c.index_key.size() != c.frames.size()) c.index_key.clear();   // an index that does not describe these chunks is ignored
     return c.X > 0 && c.Y > 0;
+}
+// Key flag of frame i as the loaders attach it: the index's when the file has one (DataLoader.hx:373-401), else
+// (first frame) || IsKeyFrame(bytes) (DataLoaderAVISeq.hx:45).
+bool frame_is_key(const Clip& c, jsp_codec* dec, size_t i) {
+    if (!c.index_key.empty()) return c.index_key[i] != 0;
+    return i == 0 || jsp_is_key_frame(dec, c.bytes.data() + c.frames[i].first, c.frames[i].second);
 }
 }  // namespace
 
+// The same loop with up to `depth` frames in flight.  A slot is handed out when it is neither the previous frame of the
+// last submitted frame, nor a destination in flight, nor showing a frame the oldest frame in flight may still be compared
+// with.  Returns frames decoded, or -1.
+long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet) {
+    jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
+                                      (int)clip.palette.size(), 0);
+    if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return -1; }
+    jsp_preinit(dec, kInsignificantLines);
+    if (clip.kind != JSP_CODEC_SCREENPRESSOR) jsp_set_option(dec, "msv1_parse", "gpu");
+    char dbuf[16];
+    std::snprintf(dbuf, sizeof dbuf, "%d", depth);
+    jsp_set_option(dec, "async_depth", dbuf);
+    jsp_pool* pool = jsp_pool_create(0, clip.X, clip.Y, kNumBuffers + 1 + depth);
+    if (!pool) { std::fprintf(stderr, "jsp_pool_create: %s\n", jsp_last_error()); jsp_codec_destroy(dec); return -1; }
+    const int nbuf = jsp_pool_count(pool);
+    const size_t npx = (size_t)clip.X * clip.Y;
+    std::vector<long> first(nbuf, -1), last(nbuf, -1);
+    std::vector<int32_t> host(quiet ? 0 : npx);
+    struct Flight { uint64_t ticket; size_t index; long gindex; bool key; int slot, prev_slot; int32_t* prev; bool cmp_bytes, first_ever; };
+    std::deque<Flight> flying;
+    long done = 0;
+    bool failed = false;
+    auto collect = [&] {
+        const Flight f = flying.front();
+        flying.pop_front();
+        int32_t* shown_ptr = nullptr;
+        int signif = -1, shown = f.slot;
+        const int state = jsp_wait(dec, f.ticket, &shown_ptr, &signif);
+        if (f.key) {
+            if (state != JSP_ZERO_STATE) { if (!quiet) std::printf("%zu key error %d %s\n", f.index, state, jsp_last_error()); return; }
+            signif = -1;
+            if (!quiet) {   // frames_differ_significantly, Manager.hx:392-421
+                const uint8_t* src = clip.bytes.data() + clip.frames[f.index].first;
+                const size_t len = clip.frames[f.index].second;
+                if (f.first_ever) signif = 1;
+                else if (f.cmp_bytes) {
+                    const uint8_t* psrc = clip.bytes.data() + clip.frames[f.index - 1].first;
+                    signif = !(clip.frames[f.index - 1].second == len && !std::memcmp(psrc, src, len));
+                } else if (!f.prev) signif = 1;
+                else jsp_frames_differ(jsp_pool_buffer(pool, f.slot), f.prev, (size_t)kInsignificantLines * clip.X, npx, &signif, nullptr);
+            }
+        } else {
+            if (state != JSP_ZERO_STATE) { if (!quiet) std::printf("%zu inter raised %s\n", f.index, jsp_last_error()); return; }
+            if (shown_ptr && shown_ptr == f.prev && f.prev_slot >= 0) shown = f.prev_slot;
+            else if (!shown_ptr) shown = -1;
+        }
+        ++done;
+        if (quiet) return;
+        uint32_t crc = 0;
+        if (shown >= 0 && jsp_download(jsp_pool_buffer(pool, shown), host.data(), npx) == 0)
+            crc = crc32(reinterpret_cast<const uint8_t*>(host.data()), npx * 4);
+        std::printf("%zu %s %d %d %08x\n", f.index, f.key ? "key" : "inter", shown, signif, crc);
+    };
+    for (int rep = 0; rep < repeat && !failed; ++rep) {
+        bool last_was_key = false;
+        for (size_t i = 0; i < clip.frames.size(); ++i) {
+            if ((int)flying.size() == depth) collect();
+            const uint8_t* src = clip.bytes.data() + clip.frames[i].first;
+            const size_t len = clip.frames[i].second;
+            const bool key = frame_is_key(clip, dec, i);
+            int32_t* prev = jsp_previous_frame(dec);          // as of the last submitted frame
+            int prev_slot = -1, slot = -1;
+            for (int k = 0; k < nbuf; ++k) if (prev && jsp_pool_buffer(pool, k) == prev) prev_slot = k;
+            const long gi = (long)(rep * clip.frames.size() + i);
+            const long horizon = flying.empty() ? gi : flying.front().gindex - 1;   // what may still be looked at
+            {
+                long oldest = 1L << 60;
+                int victim = -1;
+                for (int k = 0; k < nbuf && slot < 0; ++k) {
+                    bool busy = k == prev_slot;
+                    for (const Flight& f : flying) busy |= f.slot == k || f.prev_slot == k;
+                    if (busy) continue;
+                    if (first[k] < 0) slot = k;
+                    else if (last[k] < horizon && first[k] < oldest) { oldest = first[k]; victim = k; }
+                }
+                if (slot < 0) { slot = victim; if (slot >= 0) first[slot] = last[slot] = -1; }
+            }
+            if (slot < 0) { std::fprintf(stderr, "no free frame buffer\n"); failed = true; break; }
+            uint64_t ticket = 0;
+            int32_t* dst = jsp_pool_buffer(pool, slot);
+            const int rc = key ? jsp_decompress_i_async(dec, src, len, dst, &ticket) : jsp_decompress_p_async(dec, src, len, dst, &ticket);
+            if (rc != 0) { std::fprintf(stderr, "submit: %s\n", jsp_last_error()); failed = true; break; }
+            // which slot shows this frame is decided by the host stage: the previous frame after submission
+            int32_t* now = jsp_previous_frame(dec);
+            if (now == dst) first[slot] = last[slot] = gi;
+            else if (now && now == prev && prev_slot >= 0) last[prev_slot] = gi;
+            flying.push_back({ticket, i, gi, key, slot, prev_slot, prev, key && last_was_key && i > 0, rep == 0 && i == 0});
+            last_was_key = key;
+        }
+        while (!flying.empty()) collect();
+    }
+    jsp_pool_destroy(pool);
+    jsp_codec_destroy(dec);
+    return failed ? -1 : done;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R]]]\n", argv[0]); return 2; }
     Clip clip;
     if (!load(argv[1], clip)) { std::fprintf(stderr, "%s: not a RIFF/AVI file this player understands\n", argv[1]); return 2; }
+    bool pipelined = false, quiet = false;
+    int depth = 4, streams = 1, repeat = 1;
+    for (int a = 2; a < argc; ++a) {
+        const std::string o = argv[a];
+        if (o == "--pipelined") pipelined = true;
+        else if (o == "--quiet") quiet = true;
+        else if (o == "--depth" && a + 1 < argc) depth = std::atoi(argv[++a]);
+        else if (o == "--streams" && a + 1 < argc) streams = std::atoi(argv[++a]);
+        else if (o == "--repeat" && a + 1 < argc) repeat = std::atoi(argv[++a]);
+        else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
+    }
+    if (pipelined) {
+        depth = depth < 1 ? 1 : (depth > 16 ? 16 : depth);
+        if (!quiet) return play_pipelined(clip, depth, 1, false) < 0 ? 1 : 0;
+        streams = streams < 1 ? 1 : streams;
+        std::vector<long> done(streams, 0);
+        std::vector<std::thread> pool;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int s = 0; s < streams; ++s) pool.emplace_back([&, s] { done[s] = play_pipelined(clip, depth, repeat, true); });
+        for (auto& t : pool) t.join();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        long frames = 0;
+        for (long d : done) { if (d < 0) return 1; frames += d; }
+        std::printf("{\"streams\": %d, \"depth\": %d, \"frames\": %ld, \"seconds\": %.6f, \"mpixels_per_s\": %.1f}\n", streams, depth, frames,
+                    sec, frames * (double)clip.X * clip.Y / sec / 1e6);
+        return 0;
+    }
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
                                       (int)clip.palette.size(), 0);
     if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return 1; }
@@ -114,7 +264,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < clip.frames.size(); ++i) {
         const uint8_t* src = clip.bytes.data() + clip.frames[i].first;
         const size_t len = clip.frames[i].second;
-        const bool key = i == 0 || jsp_is_key_frame(dec, src, len);          // DataLoaderAVISeq.hx:45
+        const bool key = frame_is_key(clip, dec, i);
         int32_t* prev = jsp_previous_frame(dec);
         int prev_slot = -1, slot = -1;
         for (int k = 0; k < nbuf; ++k) if (prev && jsp_pool_buffer(pool, k) == prev) prev_slot = k;

@@ -80,6 +80,14 @@ struct FrameOut {
     uint64_t motion_pixels = 0;      // Inter: part of prev_pixels that is motion-compensated
     uint64_t stream_bytes = 0;
     const char* error = nullptr;
+    // Back to the empty state WITHOUT giving the tables' memory back: a stream's frames need about the same room one
+    // after the other, and megabyte-sized allocations per frame (page faults, allocator locks shared by the host
+    // threads of other streams) were a measurable part of the host stage.
+    void reset() {
+        kind = FrameKind::None; status = 0; adopted = prev_cleared = significant = false; flat_colour = 0;
+        runs.clear(); stream_runs = 0; row_run.clear(); seeds.clear(); band_rows = 0; span_px = 0; tile_idx.clear(); left.clear();
+        blocks.clear(); payload.clear(); prev_pixels = data_pixels = motion_pixels = stream_bytes = 0; error = nullptr;
+    }
 };
 
 // Host entropy stage for one stream (one codec instance): ScreenPressor.hx state + shadow frames.
@@ -120,6 +128,8 @@ private:
     std::vector<int32_t> bts_;
     int stall_ = 0;
     int band_rows_ = 0, span_px_ = 0;
+    std::vector<IRun> tiled_;        // scratch of the tile regrouping (kept: no per-frame allocation)
+    std::vector<uint32_t> cursor_;
 };
 
 // ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------

@@ -26,6 +26,13 @@ struct SpStaged : jsp_staged {
     std::vector<Op> ops;
     DeviceBuffer d_runs, d_rows, d_seeds, d_tileidx, d_left, d_iargs, d_blocks, d_payload, d_gframes;
     PinnedBuffer h_pack;   // every table of the batch, back to back: the uploads read from here, nobody waits for them
+    // the batch's tables while the host stage builds them (kept from use to use of this object: no per-frame allocation)
+    std::vector<IRun> runs;
+    std::vector<uint32_t> rows, seeds, tileidx, left, payload;
+    std::vector<IFrameArgs> iargs;
+    std::vector<size_t> iarg_run_off, iarg_row_off, iarg_seed_off, iarg_tile_off, iarg_left_off;
+    std::vector<PBlock> blocks;
+    std::vector<PGroupFrame> gframes;
 
     void decode(hipStream_t stream) override {
         for (const Op& op : ops) {
@@ -48,6 +55,7 @@ struct SpStaged : jsp_staged {
 
 struct SpCodec : jsp_codec {
     HostDecoder host;
+    FrameOut frame_out;   // what the host stage says about the frame in hand (its tables keep their memory)
     SpCodec(int w, int h, int bpp) : host(w, h, bpp) {
         kind = JSP_CODEC_SCREENPRESSOR;
         X = w;
@@ -97,25 +105,28 @@ struct SpCodec : jsp_codec {
         st->cleared.assign(nf, 0);
         st->info = jsp_staged_info{};
 
-        std::vector<IRun> runs;
-        std::vector<uint32_t> rows, seeds, tileidx, left;
-        std::vector<IFrameArgs> iargs;
-        std::vector<size_t> iarg_run_off, iarg_row_off, iarg_seed_off, iarg_tile_off, iarg_left_off;
+        auto &runs = st->runs;
+        auto &rows = st->rows, &seeds = st->seeds, &tileidx = st->tileidx, &left = st->left, &payload = st->payload;
+        auto &iargs = st->iargs;
+        auto &iarg_run_off = st->iarg_run_off, &iarg_row_off = st->iarg_row_off, &iarg_seed_off = st->iarg_seed_off,
+             &iarg_tile_off = st->iarg_tile_off, &iarg_left_off = st->iarg_left_off;
+        auto &blocks = st->blocks;
+        auto &gframes = st->gframes;
+        runs.clear(); rows.clear(); seeds.clear(); tileidx.clear(); left.clear(); payload.clear(); iargs.clear();
+        iarg_run_off.clear(); iarg_row_off.clear(); iarg_seed_off.clear(); iarg_tile_off.clear(); iarg_left_off.clear();
+        blocks.clear(); gframes.clear();
         int nkey = 0;
         for (const auto& f : frames) nkey += f.key ? 1 : 0;
         int band_rows = opt_band_rows >= 0 ? opt_band_rows : choose_band_rows(g, nkey);   // one cut for the whole batch
         const bool tiles = iframe_tiles_ok(st->geo);   // key frames as independent tiles (needs aligned buffers)
         if (tiles && g.Y > 4096 && (band_rows <= 0 || band_rows > 4096)) band_rows = 4096;   // a tile's row index lives in LDS
         host.set_iframe_layout(band_rows, tiles ? iframe_tile_span(st->geo) : 0);
-        std::vector<PBlock> blocks;
-        std::vector<uint32_t> payload;
-        std::vector<PGroupFrame> gframes;
         // Inter frames are fused per launch when the batch has several of them; a frame that moves more
         // than a quarter of its pixels keeps its motion blocks (literal pixels for them would rival the
         // frame in size) and gets a launch of its own.
         const bool fuse_inter = opt_inter_fusion && nf - nkey >= 2;
         std::unordered_set<const void*> group_dsts;
-        FrameOut fo;
+        FrameOut& fo = frame_out;
         for (int i = 0; i < nf; ++i) {
             const jsp_frame_in& f = frames[i];
             if (f.key) host.decode_i(f.src, f.n, fo);

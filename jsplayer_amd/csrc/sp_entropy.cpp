@@ -125,8 +125,7 @@ private:
 
 class RansDecoder final : public EntropyDecoder {
 public:
-    explicit RansDecoder(int f0) : clr_(3 * 4096) {
-        sc_.f0 = f0;
+    explicit RansDecoder(int f0) : clr_(f0) {
         for (auto& m : ntab_) m.init(256);
         for (auto& m : ptab_) m.init(6);
         xx_.init(256); bn_.init(256); bt_.init(5);
@@ -134,7 +133,7 @@ public:
         for (auto& m : mv_) m.init(512);
     }
     void renewI() override {
-        for (auto& c : clr_) c.renew();
+        clr_.renew();
         for (auto& m : ntab_) m.renew();
         for (auto& m : ptab_) m.renew();
         xx_.renew(); bn_.renew(); bt_.renew();
@@ -143,15 +142,14 @@ public:
     }
     void begin(const uint8_t* src, size_t n, size_t pos0) override { bits_.begin(src, n, pos0); ndec_ = 0; }
     int clr(int ctx) override {
-        ColourContext& cc = clr_[ctx];
         int c;
-        if (cc.coded()) {
-            const Interval iv = cc.take(bits_.slot(), sc_);
+        if (clr_.coded(ctx)) {
+            const Interval iv = clr_.take(ctx, bits_.slot());
             bits_.advance(iv.cum, iv.freq);
             c = iv.sym;
         } else {
             c = bits_.raw();
-            cc.learn(c, sc_);
+            clr_.learn(ctx, c);
         }
         tick();
         return c;
@@ -183,8 +181,7 @@ private:
     }
     RansBits bits_;
     int ndec_ = 0;
-    AnsScratch sc_;
-    std::vector<ColourContext> clr_;
+    ColourModels clr_;
     FixedModel ntab_[6], ptab_[6], xx_, bn_, bt_, sxy_[4], mv_[2];
 };
 

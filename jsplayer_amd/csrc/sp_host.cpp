@@ -63,7 +63,7 @@ int32_t HostDecoder::literal() {  // ScreenPressor.hx:173-189 / 224-235 / 419-43
 }
 
 void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
-    out = FrameOut{};
+    out.reset();
     const long X = g_.X, end = (long)g_.X * g_.Y;
     int32_t* dst = shadow_[cur_].data();
     const int head = n ? src[0] : 0;
@@ -208,8 +208,10 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             };
             for (const IRun& r : runs) ++idx[slot(r.start) + 1];
             for (size_t i = 1; i < idx.size(); ++i) idx[i] += idx[i - 1];
-            std::vector<IRun> tiled(runs.size());
-            std::vector<uint32_t> cursor(idx.begin(), idx.end() - 1);
+            std::vector<IRun>& tiled = tiled_;
+            tiled.resize(runs.size());
+            std::vector<uint32_t>& cursor = cursor_;
+            cursor.assign(idx.begin(), idx.end() - 1);
             for (const IRun& r : runs) tiled[cursor[slot(r.start)]++] = r;   // stable: row-major order survives inside a tile
             runs.swap(tiled);
             idx.pop_back();                               // ntiles * stride entries: the slot after a tile's last row is its end
@@ -239,7 +241,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
         decoded_i_ = true;
         cur_ ^= 1;
     } catch (const DecodeAbort& a) {
-        out = FrameOut{};
+        out.reset();
         out.status = 2;
         out.error = a.why;
         out.prev_cleared = had_prev && !has_prev_;  // RenewI nulled prevFrame and it stays null
@@ -247,7 +249,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
 }
 
 void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
-    out = FrameOut{};
+    out.reset();
     last_flat_ = false;
     if (n == 0 || !decoded_i_) return;  // :308-309
     if (src[0] == 0) return;            // :311-313 "no changes"
@@ -389,7 +391,7 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
         has_prev_ = true;
         cur_ ^= 1;
     } catch (const DecodeAbort& a) {
-        out = FrameOut{};
+        out.reset();
         out.status = 2;
         out.error = a.why;
     }

@@ -5,9 +5,9 @@
 //   v2  range-coder tables : RangeCoder.hx:51-130 (DecodeVal / DecodeValUni), EntroCoders.hx:81-130
 //   v3/4 rANS models       : ANS.hx:54-145 (FixedSizeRansCtx), :155-392 (Cx1..Cx5), :394-704 (Cx6),
 //                            :706-772 (Cx7), :785-860 (Context)
-// The stream encoder used to synthesise test/bench input drives the same objects through
-// `locate(symbol)` (a slot inside the symbol's current interval) followed by the decoder's own
-// lookup, so encoder and decoder cannot drift apart.
+// The stream encoder used to synthesise test/bench input (jsplayer_amd/gen, built with JSP_MODEL_TOOLS) drives the same
+// objects through `locate(symbol)` (a slot inside the symbol's current interval) followed by the decoder's own lookup,
+// so encoder and decoder cannot drift apart; the decoder's build carries none of those helpers.
 #pragma once
 #include <algorithm>
 #include <array>
@@ -32,7 +32,9 @@ struct RcTable {
     void init(int nsym, uint32_t st) { n = nsym; step = st; cnt.assign(nsym + 1, 0); }
     void reset() { std::fill(cnt.begin(), cnt.begin() + n, 1u); cnt[n] = (uint32_t)n; }
     uint32_t total() const { return cnt[n]; }
+#ifdef JSP_MODEL_TOOLS
     uint32_t cum_of(int c) const { uint32_t s = 0; for (int i = 0; i < c; ++i) s += cnt[i]; return s; }
+#endif
     // symbol owning `value`, then the adaptive update.  No symbol owns value >= total: the scan
     // then ends at c == n with the last count read, as the reference's loop does.
     Interval take(uint32_t value) {
@@ -72,6 +74,7 @@ struct RcColourTables {
         }
     }
     uint32_t total(int row) const { return w[(size_t)row * ROW + 16]; }
+#ifdef JSP_MODEL_TOOLS
     uint32_t cum_of(int row, int c) const {
         const uint32_t* p = &w[(size_t)row * ROW];
         uint32_t s = 0;
@@ -79,6 +82,7 @@ struct RcColourTables {
         for (int i = (c >> 4) << 4; i < c; ++i) s += p[17 + i];
         return s;
     }
+#endif
     Interval take(int row, uint32_t value) {
         uint32_t* p = &w[(size_t)row * ROW];
         uint32_t cum = 0, fg = 0, f = 0;
@@ -115,19 +119,21 @@ struct RcColourTables {
 // ------------------------------------------------------------------ v3/v4 models -------------
 constexpr int kProbBits = 12, kProbScale = 1 << kProbBits;
 
-// Fixed alphabet, counts folded into the live intervals only when they fill the code space
-// (deferred adaptation).  ANS.hx:54-145.  Also the last stage (Cx7) of a colour context.
-class FixedModel {
+// Fixed alphabet of up to CAP symbols, counts folded into the live intervals only when they fill the code space
+// (deferred adaptation).  ANS.hx:54-145.  Also the last stage (Cx7) of a colour context.  Plain arrays: a model is one
+// contiguous block, a pool of them a plain vector.
+template <int CAP>
+class FixedModelT {
 public:
-    explicit FixedModel(int nsym = 0) { if (nsym) init(nsym); }
-    void init(int nsym) { n_ = nsym; fc_.assign(nsym, {0, 0}); cnt_.assign(nsym, 0); std::memset(start_, 0, sizeof start_); sum_ = 0; }
+    struct FC { uint16_t freq, cum; };
+    explicit FixedModelT(int nsym = 0) { init(nsym); }
+    void init(int nsym) { n_ = nsym; sum_ = 0; std::memset(fc_, 0, sizeof fc_); std::memset(cnt_, 0, sizeof cnt_); std::memset(start_, 0, sizeof start_); }
     void renew() {
         const int fr = kProbScale / n_, c0 = fr - (fr >> 1);
         sum_ = c0 * n_;
         int cf = 0;
         for (int i = 0; i < n_; ++i) { fc_[i] = {(uint16_t)fr, (uint16_t)cf}; cnt_[i] = (uint16_t)c0; mark(cf, fr, i); cf += fr; }
     }
-    int locate(int c) const { return fc_[c].cum; }
     Interval take(int slot) {
         int j = start_[slot >> 7];
         while (j < n_ - 1 && fc_[j + 1].cum <= slot) ++j;
@@ -137,14 +143,16 @@ public:
     }
     int size() const { return n_; }
     // builders used by the colour-context upgrades (ANS.hx:711-771)
-    struct FC { uint16_t freq, cum; };
-    std::vector<FC>& fc() { return fc_; }
-    std::vector<uint16_t>& cnt() { return cnt_; }
+    FC* fc() { return fc_; }
+    uint16_t* cnt() { return cnt_; }
     int& sum() { return sum_; }
     void mark(int cf, int fr, int sym) {
         const int k0 = (cf + 127) >> 7, k1 = ((cf + fr - 1) >> 7) + 1;
         for (int k = std::max(k0, 0); k < k1 && k < 32; ++k) start_[k] = (uint8_t)sym;
     }
+#ifdef JSP_MODEL_TOOLS   // stream generator only: a slot inside c's current interval
+    int locate(int c) const { return fc_[c].cum; }
+#endif
 private:
     void bump(int c) {
         cnt_[c] = (uint16_t)(cnt_[c] + 16);
@@ -163,44 +171,83 @@ private:
         }
     }
     int n_ = 0, sum_ = 0;
-    std::vector<FC> fc_;
-    std::vector<uint16_t> cnt_;
+    FC fc_[CAP];
+    uint16_t cnt_[CAP];
     uint8_t start_[32];
 };
+using FixedModel = FixedModelT<512>;   // run lengths, predictor types, block types, motion vectors, ...: up to 512 symbols
 
-// State shared by the colour contexts of ONE coder (statics in the reference: ANS.hx:217,401-402,409).
-struct AnsScratch {
-    int tot = 0;   // SmallContext.totFr
-    int f0 = 32;   // Cx6.f0: 64 for v3, 32 for v4
-    uint16_t c256[256];
-    uint16_t f512[512];
-};
-
-// Census of stage entries (how often a colour context reached each Stage) — lets the stream
-// generator's tests prove that every model kind is exercised.  Not used by the decoder.
-extern uint64_t g_stage_census[8];
-
-// One colour context = a growing model (ANS.hx:785-860):
+// The 3 x 4096 colour contexts of ONE coder, each a growing model (ANS.hx:785-860):
 //   Empty -> List14 -> (repeat) Sparse4 / Sparse16 -> Table40 -> Full
 //                   -> (15th new) List64 -> (repeat) Table40 | (65th new) List256 -> (repeat) Full
-class ColourContext {
+// Layout (this library's own): one 64-byte record per context — enough for the stages screen content lives in
+// (List14, Sparse4, Sparse16), so the whole hot set is 768 KB — and pools for the big stages (long lists, 40-entry
+// tables with their entries interleaved, full 256-symbol models), addressed by index and emptied at every key frame.
+// The statics of the reference (ANS.hx:217,401-402,409) are members: coders of different streams run side by side.
+class ColourModels {
 public:
     enum Stage : uint8_t { Empty, List14, List64, List256, Sparse4, Sparse16, Table40, Full };
-    Stage stage() const { return stage_; }
-    void renew() { stage_ = Empty; p_.reset(); }
-    bool coded() const { return stage_ >= Sparse4; }  // false: the next symbol travels as a raw byte
-
+    explicit ColourModels(int f0);
+    void renew();                                             // every context back to Empty (a coded key frame begins)
+    Stage stage(int ctx) const { return (Stage)small_[ctx].stage; }
+    bool coded(int ctx) const { return small_[ctx].stage >= Sparse4; }   // false: the next symbol travels as a raw byte
     // Coded stages: interval of the symbol owning `slot`, then adapt (may upgrade the stage).
-    Interval take(int slot, AnsScratch& sc);
-    // Raw stages: learn symbol c (c < 0 = the reference's `undefined`: never equal to anything).
-    void learn(int c, AnsScratch& sc);
-    // Encoder side: a slot inside c's current interval (coded stages only).
-    int locate(int c, const AnsScratch& sc) const;
+    Interval take(int ctx, int slot);
+    // Raw stages: learn symbol c (c < 0 = the reference's `undefined`: stored as 0, never found by itself).
+    void learn(int ctx, int c);
+#ifdef JSP_MODEL_TOOLS   // stream generator only
+    int locate(int ctx, int c) const;                         // a slot inside c's current interval (coded stages)
+    uint64_t census[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // how often a context entered each Stage
+#endif
 
 private:
-    struct Payload;
-    Stage stage_ = Empty;
-    std::shared_ptr<Payload> p_;
+    struct Small {            // 64 bytes
+        uint8_t stage, n, cap, maxpos;   // n: List14 symbols seen / sparse symbols held
+        uint16_t cached_tot, pad;
+        uint32_t big;                    // List64/List256 -> lists_, Table40 -> tables_, Full -> fulls_
+        uint8_t sym[16];                 // List14: symbols in arrival order; sparse: sorted symbols
+        uint16_t freq[16];               // sparse frequencies
+        uint8_t pad2[4];
+    };
+    struct ListBig { uint16_t ld; uint8_t list[256]; uint64_t seen[4]; };
+    struct Table {            // Cx6: up to 40 explicit intervals inside the full 256-symbol cumulative space
+        struct E { uint16_t cum, freq, cnt; uint8_t sym, pad; };
+        int tcap, td, fshift;
+        uint16_t tsum;   // a 16-bit slot in the reference's typed array: it wraps
+        E e[64];
+    };
+    using Full256 = FixedModelT<256>;
+    static_assert(sizeof(Small) == 64, "one cache line per context");
+
+    void enter(Small& s, Stage st);
+    // sparse (SmallContext / Cx4 / Cx5, ANS.hx:210-392)
+    static int sparse_total(const Small& s);
+    void sparse_halve(Small& s);
+    bool sparse_insert(Small& s, int pos, int c);
+    bool sparse_take(Small& s, int slot, int tot0, Interval& iv);
+    void sparse_from_list14(Small& s, int capacity, int c);
+    void sparse16_from_sparse4(Small& s, int c);
+    // table (Cx6, ANS.hx:394-704)
+    static void table_swap(Table& t, int a, int b) { std::swap(t.e[a], t.e[b]); }
+    static void table_calc_sum(Table& t);
+    void table_rebuild(Table& t);
+    void table_bump(Table& t, int pos);
+    static int table_add(Table& t, int c, int freq, int cum);
+    static int table_unseen_cum(const Table& t, int c);
+    uint32_t table_from_sparse16(const Small& s, int c);
+    uint32_t table_from_list(ListBig& l, int c);
+    bool table_take(Table& t, int slot, Interval& iv);
+    // full (Cx7, ANS.hx:706-772)
+    uint32_t full_from_list(const ListBig& l, int c);
+    uint32_t full_from_table(const Table& t);
+
+    std::vector<Small> small_;
+    std::vector<ListBig> lists_;
+    std::vector<Table> tables_;
+    std::vector<Full256> fulls_;
+    int tot_ = 0;              // SmallContext.totFr
+    int f0_;                   // Cx6.f0: 64 for v3, 32 for v4
+    uint16_t c256_[256], f512_[512];   // Cx6._cnts / _freqs
 };
 
 }  // namespace jsp::sp

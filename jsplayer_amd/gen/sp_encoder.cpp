@@ -10,6 +10,7 @@
 //         below 2^24, first byte = the carry cache the decoder skips, RangeCoder.hx:29-33)
 //   v3/v4 byte-wise rANS, 12-bit probabilities, state in [2^23, 2^31), encoded backwards per block of
 //         131072 symbols with raw bytes interleaved in decode order (ANS.hx:5-49, EntroCoders.hx:249-253)
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -20,6 +21,7 @@
 
 namespace {
 using namespace jsp::sp;
+std::atomic<uint64_t> g_census[8];   // how often colour contexts entered each model stage (all encoders of the process)
 
 // ---------------------------------------------------------------- bit-level coders ------------
 class RangeEncoder {
@@ -149,8 +151,7 @@ private:
 
 class RansSymbolEncoder final : public SymbolEncoder {
 public:
-    explicit RansSymbolEncoder(int f0) : clr_(3 * 4096) {
-        sc_.f0 = f0;
+    explicit RansSymbolEncoder(int f0) : clr_(f0) {
         for (auto& m : ntab_) m.init(256);
         for (auto& m : ptab_) m.init(6);
         xx_.init(256); bn_.init(256); bt_.init(5);
@@ -158,7 +159,7 @@ public:
         for (auto& m : mv_) m.init(512);
     }
     void renewI() override {
-        for (auto& c : clr_) c.renew();
+        clr_.renew();
         for (auto& m : ntab_) m.renew();
         for (auto& m : ptab_) m.renew();
         xx_.renew(); bn_.renew(); bt_.renew();
@@ -168,15 +169,15 @@ public:
     void begin(std::vector<uint8_t>* out) override { out_ = out; ev_.clear(); }
     void finish() override { rans_flush(ev_, *out_); }
     void clr(int ctx, int c) override {
-        ColourContext& cc = clr_[ctx];
-        if (cc.coded()) {
-            const Interval iv = cc.take(cc.locate(c, sc_), sc_);
+        if (clr_.coded(ctx)) {
+            const Interval iv = clr_.take(ctx, clr_.locate(ctx, c));
             if (iv.sym != c) throw std::logic_error("encoder/model disagreement (colour context)");
             push(iv);
         } else {
             ev_.push_back({0, 0, (uint8_t)c});
-            cc.learn(c, sc_);
+            clr_.learn(ctx, c);
         }
+        for (int k = 0; k < 8; ++k) { g_census[k] += clr_.census[k]; clr_.census[k] = 0; }
     }
     void run(int ptype, int n) override { fixed(ntab_[ptype], n); }
     void ptype(int prev, int pt) override { fixed(ptab_[prev], pt); }
@@ -208,8 +209,7 @@ private:
     }
     std::vector<uint8_t>* out_ = nullptr;
     std::vector<RansEvent> ev_;
-    AnsScratch sc_;
-    std::vector<ColourContext> clr_;
+    ColourModels clr_;
     FixedModel ntab_[6], ptab_[6], xx_, bn_, bt_, sxy_[4], mv_[2];
 };
 
@@ -490,8 +490,8 @@ long jspgen_sp_encode_p(void* p, const uint32_t* frame, const int16_t* hints, ui
     return guarded(h, out, cap, [&] { h->enc.encode_p(frame, hints, h->out); });
 }
 // How often colour contexts entered each model stage since the library was loaded
-// (index = ColourContext::Stage): test coverage evidence.
-void jspgen_stage_census(uint64_t* out) { std::memcpy(out, jsp::sp::g_stage_census, sizeof jsp::sp::g_stage_census); }
+// (index = ColourModels::Stage): test coverage evidence.
+void jspgen_stage_census(uint64_t* out) { for (int k = 0; k < 8; ++k) out[k] = g_census[k].load(); }
 // The frame a decoder holds after the last encoded frame (for flat frames the colour is derived
 // from the emitted bytes).
 void jspgen_sp_current(void* p, uint32_t* out) {

@@ -193,11 +193,13 @@ def test_cpp_player_over_the_c_abi(what, tmp_path):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
     if what == "screenpressor":
         chunks, keys, _ = sg.sp_clip(31, 320, 240, 12, version=4, key_every=5, unchanged_at=(2, 7))
-        blob = avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24)
+        blob = avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys)   # the player takes the index's flags
     else:
         bits = 16 if what == "msvc16" else 8
         frames, pal = config0_clip(bits, 30)
-        blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=bits, palette=pal)
+        probe = ORACLE_CLASSES[0](320, 240) if bits == 16 else ORACLE_CLASSES[1](320, 240, pal)
+        blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=bits, palette=pal,
+                             key_flags=[i == 0 or probe.IsKeyFrame(f) for i, f in enumerate(frames)])
     path = tmp_path / "clip.avi"
     path.write_bytes(blob)
     res = subprocess.run([exe, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
@@ -213,6 +215,45 @@ def test_cpp_player_over_the_c_abi(what, tmp_path):
         assert int(ln[2]) == d.buffer_index, ln
         assert int(ln[3]) == int(bool(d.significant_changes)), ln
         assert int(ln[4], 16) == crc, ln
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["msvc16", "msvc8", "screenpressor"])
+def test_cpp_player_pipelined_shows_the_same_pictures(what, tmp_path):
+    """examples/jsp_play --pipelined: the same loop over jsp_decompress_*_async / jsp_wait with three frames in flight and
+    the file's bytes in pinned memory shows, frame for frame, what the synchronous loop shows (the pool is larger, so slot
+    numbers may differ); its --quiet form plays several streams at once and reports a rate."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "jsp_play")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    if what == "screenpressor":
+        chunks, keys, _ = sg.sp_clip(31, 320, 240, 12, version=4, key_every=5, unchanged_at=(2, 7))
+        blob = avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys)   # the player takes the index's flags
+    else:
+        bits = 16 if what == "msvc16" else 8
+        frames, pal = config0_clip(bits, 30)
+        probe = ORACLE_CLASSES[0](320, 240) if bits == 16 else ORACLE_CLASSES[1](320, 240, pal)
+        blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=bits, palette=pal,
+                             key_flags=[i == 0 or probe.IsKeyFrame(f) for i, f in enumerate(frames)])
+    path = tmp_path / "clip.avi"
+    path.write_bytes(blob)
+    outs = []
+    for extra in ([], ["--pipelined", "--depth", "3"]):
+        res = subprocess.run([exe, str(path)] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert res.returncode == 0, res.stderr.decode()
+        outs.append([l.split() for l in res.stdout.decode().splitlines()])
+    assert len(outs[0]) == len(outs[1]) > 0
+    for a, b in zip(*outs):
+        assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3] and a[4] == b[4], (a, b)
+    res = subprocess.run([exe, str(path), "--pipelined", "--quiet", "--streams", "3", "--repeat", "2", "--depth", "4"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode == 0, res.stderr.decode()
+    rate = json.loads(res.stdout.decode())
+    assert rate["streams"] == 3 and rate["frames"] == 3 * 2 * len(outs[0]) and rate["mpixels_per_s"] > 0
 
 
 @pytest.mark.parametrize("per_ix", [0, 4])
