@@ -191,7 +191,9 @@ struct Msv1Codec : jsp_codec {
         // remainders outside the block grid are never written; an 8-bit end marker or an abort
         // can leave more.  Cheap to be conservative: only exact multiples of 4 with a 16-bit
         // stream are guaranteed to be fully written.
-        return (X & 3) || (Y & 3) || geo.bits == 8;
+        // ... and while there is no previous frame a skip code aborts the frame (the reference raises), leaving
+        // every block after it as the caller had it
+        return (X & 3) || (Y & 3) || geo.bits == 8 || !prev_dev;
     }
     int set_option(const char* key, const char* value) override {
         if (std::strcmp(key, "msv1_parse") == 0) {

@@ -31,6 +31,7 @@ enum RunKind : uint32_t {   // bit 0: the pixel starts from the row above; bit 1
                          // telescopes inside a run: p[i]-p[i-X] = p[i0-1]-p[i0-1-X]
     RUN_ABOVE_LEFT = 3,  // pixel i takes pixel i-X-1 (addend 0)
 };
+constexpr uint32_t kRowRepeats = 0x80000000u;   // tile layout: flag in a row's index entry — same words as the row above, no records stored
 constexpr long kRunSplit = 256;  // row-major layout: records never cross a multiple of this many columns (= one wave x 4 pixels)
 struct IRun {
     uint32_t start;  // linear pixel index of the first pixel
@@ -71,7 +72,7 @@ struct FrameOut {
     // Intra, tile layout (set_iframe_layout with a span): `runs` is then ordered tile by tile (band-major,
     // then column span, then row, then column; no sentinel) and these two tables describe the tiles
     int span_px = 0;
-    std::vector<uint32_t> tile_idx;  // per tile band_rows+1 offsets into runs: first record of each of its rows, then the end
+    std::vector<uint32_t> tile_idx;  // per tile band_rows+1 offsets into runs: first record of each of its rows (| kRowRepeats), then the end
     std::vector<uint32_t> left;      // per tile band_rows words: the pixel left of the span's first pixel, one row up
     std::vector<PBlock> blocks;      // Inter
     std::vector<uint32_t> payload;   // Inter: literal pixels of the data rectangles

@@ -213,8 +213,25 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             std::vector<uint32_t>& cursor = cursor_;
             cursor.assign(idx.begin(), idx.end() - 1);
             for (const IRun& r : runs) tiled[cursor[slot(r.start)]++] = r;   // stable: row-major order survives inside a tile
-            runs.swap(tiled);
             idx.pop_back();                               // ntiles * stride entries: the slot after a tile's last row is its end
+            // Screen content repeats itself from row to row: a row of a tile whose records equal, column for column, those
+            // of the row above it in the same tile is not stored at all — bit 31 of its index entry (kRowRepeats) says "the
+            // same words as the row above", and the wave keeps using the words it has in registers.
+            runs.clear();
+            cursor.assign(idx.begin(), idx.end());        // the index into `tiled`; idx is rewritten to index the packed records
+            for (size_t t = 0; t < ntiles; ++t) {
+                const size_t base = t * stride;
+                for (int r = 0; r < rows_per; ++r) {
+                    const uint32_t lo = cursor[base + r], hi = cursor[base + r + 1];
+                    bool same = r > 0 && hi > lo && hi - lo == lo - cursor[base + r - 1];
+                    const uint32_t plo = same ? cursor[base + r - 1] : 0;
+                    for (uint32_t k = 0; same && k < hi - lo; ++k)
+                        same = tiled[lo + k].word == tiled[plo + k].word && tiled[lo + k].start - tiled[plo + k].start == (uint32_t)X;
+                    idx[base + r] = (uint32_t)runs.size() | (same ? kRowRepeats : 0u);
+                    if (!same) runs.insert(runs.end(), tiled.begin() + lo, tiled.begin() + hi);
+                }
+                idx[base + rows_per] = (uint32_t)runs.size();   // the tile's end
+            }
             out.left.assign(ntiles * rows_per, 0);
             for (int b = 0; b < nbands; ++b)
                 for (int sp = 0; sp < nspans; ++sp)

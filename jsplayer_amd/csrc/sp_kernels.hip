@@ -235,19 +235,26 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     __builtin_amdgcn_wave_barrier();
 
     const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
+    constexpr uint32_t OFF = ~kRowRepeats;            // an index entry = record offset | kRowRepeats ("same words as the row above")
+    // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the 24-bit colour / addend, its
+    // low 7 bits per byte, and the two masks that pick the pixel's starting value — the pixel to the upper left, the pixel
+    // above, or nothing (a constant).  A row that repeats the layout of the row above keeps all of it.
+    uint32_t d24[PPL], dlo[PPL], m_left[PPL], m_above[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) d24[j] = dlo[j] = m_left[j] = m_above[j] = 0;
     int y = yb;
     while (y < ye) {
         // window: rows y .. y_end-1 whose records fit in win_cap.  A single row with more records than that
         // (more than one run every other pixel) is scattered straight from global memory.
-        const uint32_t w0 = idx[y - yb];
+        const uint32_t w0 = idx[y - yb] & OFF;
         int y_end = y + 1;
-        while (y_end < ye && (int)(idx[y_end + 1 - yb] - w0) <= win_cap) ++y_end;
-        int wn = (int)(idx[y_end - yb] - w0);
+        while (y_end < ye && (int)((idx[y_end + 1 - yb] & OFF) - w0) <= win_cap) ++y_end;
+        int wn = (int)((idx[y_end - yb] & OFF) - w0);
         const bool direct = wn > win_cap;             // only possible with y_end == y + 1
         if (direct) wn = 0;
         for (int k = lane; k < wn; k += 64) win[k] = load2_global(gruns + w0 + k);
         {
-            const uint32_t r0 = w0, r1 = idx[y + 1 - yb], origin = (uint32_t)((size_t)y * X + xs);
+            const uint32_t r0 = w0, r1 = idx[y + 1 - yb] & OFF, origin = (uint32_t)((size_t)y * X + xs);
             if (direct) {
                 for (int r = lane; r < (int)(r1 - r0); r += 64) {
                     const uint2 q = load2_global(gruns + r0 + r);
@@ -262,16 +269,19 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
                     head[q.x - origin] = q.y | HEAD_PRESENT;
                 }
         }
-        uint32_t r1 = idx[y + 1 - yb];
-        uint32_t r2 = y + 1 < y_end ? idx[y + 2 - yb] : r1;
+        uint32_t e0 = idx[y - yb];                                        // this row's entry (its flag matters)
+        uint32_t e1 = idx[y + 1 - yb];
+        uint32_t e2 = y + 1 < y_end ? idx[y + 2 - yb] : e1;
         for (; y < y_end; ++y) {
             const bool more = y + 1 < y_end;
-            const uint32_t r3 = y + 2 < y_end ? idx[y + 3 - yb] : r2;     // a row ahead, off the critical path
+            const uint32_t e3 = y + 2 < y_end ? idx[y + 3 - yb] : e2;     // a row ahead, off the critical path
+            const uint32_t r1 = e1 & OFF, r2 = e2 & OFF;
+            const bool repeat = (e0 & kRowRepeats) != 0u;                  // (uniform) no records: the words of the row above stay
             const uint32_t eg = left[y - yb];
             uint4 hv[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) hv[v] = make_uint4(0, 0, 0, 0);
-            if (active) {
+            if (active && !repeat) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) hv[v] = *reinterpret_cast<const uint4*>(head + lane * PPL + 4 * v);
             }
@@ -282,28 +292,36 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             uint32_t u0 = lane_to_the_left(p[PPL - 1]);
             if (lane == 0) u0 = eg;
             if (active) {
+                if (!repeat) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + lane * PPL + 4 * v) = make_uint4(0, 0, 0, 0);
-                uint32_t h[PPL];
+                    for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + lane * PPL + 4 * v) = make_uint4(0, 0, 0, 0);
+                    uint32_t h[PPL];
 #pragma unroll
-                for (int v = 0; v < V; ++v) { h[4 * v] = hv[v].x; h[4 * v + 1] = hv[v].y; h[4 * v + 2] = hv[v].z; h[4 * v + 3] = hv[v].w; }
-                uint32_t last = h[0];
+                    for (int v = 0; v < V; ++v) { h[4 * v] = hv[v].x; h[4 * v + 1] = hv[v].y; h[4 * v + 2] = hv[v].z; h[4 * v + 3] = hv[v].w; }
+                    uint32_t last = h[0];
 #pragma unroll
-                for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
-                const unsigned long long seen = __ballot(last != 0u);
-                const unsigned long long lower = seen & ((1ull << lane) - 1ull);
-                const int src = lower ? 63 - __clzll((long long)lower) : lane;
-                uint32_t w = (uint32_t)__shfl((int)last, src);   // lane 0 always has h[0] != 0: a record starts every span
-                auto predict = [](uint32_t word, uint32_t lft, uint32_t above) -> uint32_t {
-                    const uint32_t use_above = (uint32_t)((int32_t)(word << 7) >> 31), use_left = (uint32_t)((int32_t)(word << 6) >> 31);
-                    const uint32_t base = ((lft & use_left) | (above & ~use_left)) & use_above;
-                    return add_bytes(base, word);
-                };
+                    for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
+                    const unsigned long long seen = __ballot(last != 0u);
+                    const unsigned long long lower = seen & ((1ull << lane) - 1ull);
+                    const int src = lower ? 63 - __clzll((long long)lower) : lane;
+                    uint32_t w = (uint32_t)__shfl((int)last, src);   // lane 0 always has h[0] != 0: a record starts every span
+#pragma unroll
+                    for (int j = 0; j < PPL; ++j) {
+                        w = h[j] ? h[j] : w;
+                        const uint32_t use_above = (uint32_t)((int32_t)(w << 7) >> 31), use_left = (uint32_t)((int32_t)(w << 6) >> 31);
+                        d24[j] = w & 0x00FFFFFFu;
+                        dlo[j] = w & 0x007F7F7Fu;
+                        m_left[j] = use_left & use_above;
+                        m_above[j] = ~use_left & use_above;
+                    }
+                }
+                // pixel = start value + addend, byte by byte (bytes 0..2; byte 3 stays 0): the low 7 bits of every byte
+                // are added in one go (no carry can cross a byte), bit 7 of each byte is put right with an exclusive or
                 uint32_t q[PPL];
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) {
-                    w = h[j] ? h[j] : w;
-                    q[j] = predict(w, j ? p[j - 1] : u0, p[j]);
+                    const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
+                    q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
                 }
 #pragma unroll
                 for (int v = 0; v < V; ++v)
@@ -318,8 +336,9 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
                 head[q2.x - origin_next] = q2.y | HEAD_PRESENT;
             }
             __builtin_amdgcn_wave_barrier();
-            r1 = r2;
-            r2 = r3;
+            e0 = e1;
+            e1 = e2;
+            e2 = e3;
         }
     }
 }

@@ -730,6 +730,23 @@ int rans_trace(const uint8_t* src, size_t n, long pos0, const int32_t* ops, int 
     return k;
 }
 
+// Test hook (tests/test_js_semantics.py): decodeClr over a list of colour-context indices on an arbitrary byte stream,
+// so that the whole model ladder (Context, Cx1..Cx7) can be held against a JS engine's typed arrays.
+// out_syms[k] = symbol k (-1 = undefined); *out_pos = stream position afterwards; returns the calls done (stops at a hang)
+int ans_clr_trace(int f0, const uint8_t* src, size_t n, long pos0, const int32_t* ctxs, int nctx, int32_t* out_syms, int64_t* out_pos) {
+    EntroANS ec(f0);
+    ec.renewI();
+    ec.decodeBegin(ByteView{src, (long)n}, pos0);
+    int k = 0;
+    for (; k < nctx; ++k) {
+        const int c = ec.decodeClr(ctxs[k]);
+        if (ec.failed()) break;
+        out_syms[k] = c;
+    }
+    *out_pos = ec.rans.pos;
+    return k;
+}
+
 }  // namespace
 
 std::unique_ptr<EntroCoder> make_entro_rc() { return std::make_unique<EntroRC>(); }
@@ -737,6 +754,9 @@ std::unique_ptr<EntroCoder> make_entro_ans(int f0) { return std::make_unique<Ent
 
 }  // namespace orc
 
+extern "C" int orc_ans_clr_trace(int f0, const uint8_t* src, size_t n, long pos0, const int32_t* ctxs, int nctx, int32_t* out_syms, int64_t* out_pos) {
+    return orc::ans_clr_trace(f0, src, n, pos0, ctxs, nctx, out_syms, out_pos);
+}
 extern "C" int orc_rans_trace(const uint8_t* src, size_t n, long pos0, const int32_t* ops, int nops, int64_t* out) {
     return orc::rans_trace(src, n, pos0, ops, nops, out);
 }

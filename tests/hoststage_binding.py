@@ -164,10 +164,14 @@ def expand_iframe_tiles(desc, X, Y):
             up = seeds[(b - 1) * (X + 1) + 1 + xs:(b - 1) * (X + 1) + 1 + xe].copy() if b > 0 else np.zeros(xe - xs, np.uint32)
             for r in range(min(rows_per, Y - b * rows_per)):
                 y = b * rows_per + r
-                lo, hi = int(idx[t * (rows_per + 1) + r]), int(idx[t * (rows_per + 1) + r + 1])
-                rec = runs[lo:hi]
-                covered[lo:hi] = True
-                cols = rec[:, 0].astype(np.int64) - y * X - xs
+                e = int(idx[t * (rows_per + 1) + r])
+                lo, hi = e & 0x7FFFFFFF, int(idx[t * (rows_per + 1) + r + 1]) & 0x7FFFFFFF
+                if e >> 31:        # kRowRepeats: no records of its own, the words of the row above stay in force
+                    assert r > 0 and lo == hi, (b, s, r)
+                else:
+                    rec = runs[lo:hi]
+                    covered[lo:hi] = True
+                    cols = rec[:, 0].astype(np.int64) - y * X - xs
                 assert len(rec) and cols[0] == 0 and np.all(np.diff(cols) > 0) and cols[-1] < xe - xs, (b, s, r)
                 k = np.searchsorted(cols, np.arange(xe - xs), side="right") - 1
                 w = rec[k, 1]

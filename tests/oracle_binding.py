@@ -144,3 +144,22 @@ class OracleScreenPressor:
 
     def __del__(self):
         self.close()
+
+
+def orc_display_convert(frame: np.ndarray, width: int, height: int, mode: int, flip_rows: bool) -> np.ndarray:
+    """oracle/manager_oracle.cpp: Manager.fill_bitmap_data (Manager.hx:325-390) on a host frame."""
+    L = lib()
+    L.orc_display_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    src = np.ascontiguousarray(frame, dtype=np.int32)
+    out = np.empty(width * height, dtype=np.int32)
+    L.orc_display_convert(C.c_void_p(src.ctypes.data), C.c_void_p(out.ctypes.data), width, height, mode, 1 if flip_rows else 0)
+    return out
+
+
+def orc_frames_differ(a: np.ndarray, b: np.ndarray, first_pixel: int, npixels: int) -> bool:
+    """oracle/manager_oracle.cpp: the pixel loop of Manager.frames_differ_significantly (Manager.hx:413-419)."""
+    L = lib()
+    L.orc_frames_differ.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    return bool(L.orc_frames_differ(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), first_pixel, npixels))

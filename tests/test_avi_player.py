@@ -103,33 +103,45 @@ def test_avi_clip_gpu_matches_cpu_reference_path(bits):
 
 @pytest.mark.gpu
 def test_display_convert_and_frames_differ_kernels():
-    """Manager.fill_bitmap_data / frames_differ_significantly restated in numpy vs the HIP kernels."""
+    """jsp_display_convert / jsp_frames_differ against the oracle's restatement of Manager.fill_bitmap_data
+    (Manager.hx:325-390, all four conversions, with and without the row flip) and of the pixel loop of
+    frames_differ_significantly (Manager.hx:413-419); pixel values cover all 32 bits (the shifts drop high bits)."""
     import torch
     from jsplayer_amd import codec as cm
+    from oracle_binding import orc_display_convert, orc_frames_differ
     rng = np.random.default_rng(3)
     for (w, h) in [(1920, 1080), (321, 7), (64, 48)]:
-        src = rng.integers(0, 1 << 24, size=w * h, dtype=np.uint32)
-        t = torch.from_numpy(src.view(np.int32)).cuda()
+        src = rng.integers(0, 1 << 32, size=w * h, dtype=np.uint64).astype(np.uint32).view(np.int32)
+        t = torch.from_numpy(src).cuda()
         out = torch.empty_like(t)
-        for mode, fn in [(cm.DISPLAY_CANVAS, lambda c: 0xFF000000 | ((c & 0xFF) << 16) | (c & 0xFF00) | ((c >> 16) & 0xFF)),
-                         (cm.DISPLAY_CANVAS_RGB15, lambda c: 0xFF000000 | ((c << 3) & 0xFFFFFFFF)),
-                         (cm.DISPLAY_SETPIXELS, lambda c: 0xFF000000 | c),
-                         (cm.DISPLAY_SETPIXELS_RGB15, lambda c: (c << 11) & 0xFFFFFFFF)]:
+        for mode in (cm.DISPLAY_CANVAS, cm.DISPLAY_CANVAS_RGB15, cm.DISPLAY_SETPIXELS, cm.DISPLAY_SETPIXELS_RGB15):
             for flip in (False, True):
                 cm.display_convert(t, out, w, h, mode, flip)
                 torch.cuda.synchronize()
-                exp = fn(src.astype(np.uint64)).astype(np.uint32).reshape(h, w)
-                if flip:
-                    exp = exp[::-1]
-                assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), exp), (w, h, mode, flip)
+                assert np.array_equal(out.cpu().numpy(), orc_display_convert(src, w, h, mode, flip)), (w, h, mode, flip)
         b = t.clone()
-        assert cm.frames_differ(t, b, 0, w * h) is False
-        b[w * h - 1] += 1
-        assert cm.frames_differ(t, b, 0, w * h) is True
-        assert cm.frames_differ(t, b, w * h - 1, w * h) is True
-        b[w * h - 1] -= 1
-        b[5] += 1
-        assert cm.frames_differ(t, b, 6, w * h) is False and cm.frames_differ(t, b, 5, w * h) is True
+        for first, poke in [(0, None), (0, w * h - 1), (w * h - 1, w * h - 1), (6, 5), (5, 5), (36 * w if 36 * w < w * h else 0, w * h // 2)]:
+            if poke is not None:
+                b[poke] += 1
+            torch.cuda.synchronize()
+            assert cm.frames_differ(t, b, first, w * h) == orc_frames_differ(src, b.cpu().numpy(), first, w * h), (w, h, first, poke)
+            if poke is not None:
+                b[poke] -= 1
+
+
+def test_oracle_display_and_differ_known_answers():
+    """The oracle's own restatement against hand-worked values of the four formulas (Manager.hx:340,351,370,379)."""
+    from oracle_binding import orc_display_convert, orc_frames_differ
+    px = np.array([0x00112233, 0x00FFEEDD, 0x12345678, 0x0000001F], dtype=np.uint32).view(np.int32)
+    u = lambda a: a.view(np.uint32).tolist()
+    assert u(orc_display_convert(px, 4, 1, 0, False)) == [0xFF332211, 0xFFDDEEFF, 0xFF785634, 0xFF1F0000]
+    assert u(orc_display_convert(px, 4, 1, 1, False)) == [0xFF891198, 0xFFFF76E8, 0xFFA2B3C0, 0xFF0000F8]
+    assert u(orc_display_convert(px, 4, 1, 2, False)) == [0xFF112233, 0xFFFFEEDD, 0xFF345678, 0xFF00001F]
+    assert u(orc_display_convert(px, 4, 1, 3, False)) == [0x89119800, 0xFF76E800, 0xA2B3C000, 0x0000F800]
+    assert u(orc_display_convert(px, 2, 2, 2, True)) == [0xFF345678, 0xFF00001F, 0xFF112233, 0xFFFFEEDD]
+    other = px.copy()
+    other[1] ^= 1
+    assert not orc_frames_differ(px, px.copy(), 0, 4) and orc_frames_differ(px, other, 0, 4) and not orc_frames_differ(px, other, 2, 4)
 
 
 @pytest.mark.parametrize("per_ix", [0, 7, 1000])

@@ -186,3 +186,55 @@ def test_rans_state_machine_agrees_with_a_real_js_engine():
         hangs += done < len(cs["ops"])
         steps += done
     assert steps > 4000 and hangs > 0
+
+
+# ---- ScreenPressor versions 3 / 4: the colour-context model ladder -------------------------------------------------
+def test_colour_context_ladder_agrees_with_a_real_js_engine():
+    """oracle/sp_entropy_oracle.cpp's Context / Cx1..Cx7 / FixedSizeRansCtx behind EntroANS.decodeClr against the same
+    models kept in JS typed arrays under node (tests/js/ans_models_js_semantics.js): arbitrary byte streams — small and
+    large raw alphabets, so that every stage of the ladder is entered — decoded through a handful of contexts, symbol
+    for symbol and position for position, both f0 settings (64: version 3, whose table can outgrow the code space)."""
+    import ctypes as C
+    import oracle_binding
+    L = oracle_binding.lib()
+    L.orc_ans_clr_trace.restype = C.c_int
+    L.orc_ans_clr_trace.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(83)
+    cases = []
+    for k in range(160):
+        alphabet = rng.choice(256, size=int(rng.choice([2, 5, 12, 30, 70, 256])), replace=False)
+        nbytes = int(rng.integers(40, 9000))
+        data = alphabet[rng.integers(0, alphabet.size, size=nbytes)].astype(np.uint8)
+        if k % 4 == 0:                                      # bursts of anything in between
+            at = rng.integers(0, nbytes, size=nbytes // 6)
+            data[at] = rng.integers(0, 256, size=at.size, dtype=np.uint8)
+        nctx = int(rng.choice([1, 2, 3, 6, 12]))
+        ids = rng.choice(3 * 4096, size=nctx, replace=False)
+        ctxs = ids[rng.integers(0, nctx, size=int(rng.integers(50, 7000)))]
+        cases.append(dict(f0=int(rng.choice([32, 64])), bytes=data.tolist(), pos=1, ctxs=ctxs.tolist()))
+    for k in range(12):   # 65+ distinct raw bytes before the first repeat: the 256-entry list, then the full model built from it
+        perm = rng.permutation(256).astype(np.uint8)
+        data = np.concatenate([rng.integers(0, 256, 5, dtype=np.uint8), perm[:int(rng.integers(66, 257))], perm[::-1],
+                               rng.integers(0, 256, 3000, dtype=np.uint8)])
+        cases.append(dict(f0=32 if k % 2 else 64, bytes=data.tolist(), pos=1, ctxs=[int(rng.integers(0, 3 * 4096))] * int(rng.integers(300, 3000))))
+    res = subprocess.run([NODE, os.path.join(HERE, "js", "ans_models_js_semantics.js")], input=json.dumps(cases).encode(),
+                         stdout=subprocess.PIPE, check=True, timeout=300)
+    js = json.loads(res.stdout)
+    total = past_end = hangs = big = 0
+    census = np.zeros(8, dtype=np.int64)
+    for cs, jr in zip(cases, js):
+        ctxs = np.array(cs["ctxs"], dtype=np.int32)
+        out = np.zeros(ctxs.size, dtype=np.int32)
+        pos = C.c_int64(0)
+        src = bytes(cs["bytes"])
+        done = L.orc_ans_clr_trace(cs["f0"], src, len(src), cs["pos"], ctxs.ctypes.data, ctxs.size, out.ctypes.data, C.byref(pos))
+        assert done == len(jr["syms"]), (done, len(jr["syms"]))
+        assert out[:done].tolist() == jr["syms"]
+        assert pos.value == jr["pos"]
+        total += done
+        past_end += pos.value > len(src)
+        hangs += done < ctxs.size
+        big += int((out[:done] > 255).sum())
+        census += np.array(jr["census"])
+    assert total > 100000 and past_end > 0
+    assert (census[1:] > 0).all(), census     # every stage was entered: lists 14 / 64 / 256, sparse 4 / 16, table, full
