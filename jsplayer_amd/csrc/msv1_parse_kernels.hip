@@ -453,6 +453,50 @@ __device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail
         }
 }
 
+// 16-bit frames, lane wholly inside the frame's data, no skip code among its 32 slots (the wave checks): everything the
+// table pass and the replay need is three bit masks over the slots — S: solid (bit 15 of the code word set), E: 8-colour
+// (pattern word followed by a word with bit 15 set), T: 2-colour (the other pattern words); every code is one block.
+struct LaneMasks { uint32_t S, T, E; };
+__device__ __forceinline__ LaneMasks lane_masks16(const uint32_t (&w)[17], bool& has_skip) {
+    uint32_t notp = 0, z = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t d = w[i];
+        notp |= ((d >> 15) & 1u) << (2 * i);
+        notp |= (d >> 31) << (2 * i + 1);
+        const uint32_t t = (d & 0xFC00FC00u) ^ 0x84008400u;           // a zero half = a skip code (high byte 0x84..0x87)
+        z |= (t - 0x00010001u) & ~t & 0x80008000u;                     // (a borrow out of a zero low half can only add a hit)
+    }
+    has_skip = z != 0u;
+    const uint32_t next_set = (notp >> 1) | (((w[16] >> 15) & 1u) << 31);   // bit 15 of the word after the slot's
+    LaneMasks m;
+    m.S = notp;
+    m.E = ~notp & next_set;
+    m.T = ~notp & ~next_set;
+    return m;
+}
+// the 9-entry table from the masks: the reverse pass of lane_table_fast with the slot's two predicates read off the masks
+__device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&tab)[9]) {
+    uint32_t dw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dw[k] = pack(k, 0);
+    const uint32_t P = ~m.S;
+#pragma unroll
+    for (int s = LSLOTS - 1; s >= 0; --s) {
+        uint32_t mp, me;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mp) : "v"(P), "n"(s));       // 0 / ~0: pattern code
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(me) : "v"(m.E), "n"(s));     // 0 / ~0: ... with 8 colours
+        uint32_t nx = (dw[8] & me) | (dw[2] & ~me);
+        nx = (nx & mp) | (dw[0] & ~mp);
+        const uint32_t v = nx + 16u;                                       // one block per code: no saturation in 32 slots
+#pragma unroll
+        for (int k = 8; k > 0; --k) dw[k] = dw[k - 1];
+        dw[0] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tab[e] = dw[e];
+}
+
 // One launch: grid = tiles, in stream order.
 // Measured and dropped (profiles/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
 // prefetched into registers, 2-bit packed slot kinds instead of 32 classification registers) hid the tile load but ran
@@ -541,16 +585,28 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         *reinterpret_cast<uint4*>(lds_bytes + o) = v;
     }
     __syncthreads();
-    uint32_t cls[LSLOTS];
     const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
     const bool inside = tile_byte0 + TILE_BYTES + 4u <= r.frame_end;   // every tile of a frame but the last: no end-of-data tests
+    LaneMasks masks{0, 0, 0};
+    bool fast = false;        // (wave-uniform) the mask form serves: 16-bit, inside the frame, no skip code in this wave's slots
     {
         uint32_t w[17], tab[9];
         const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
 #pragma unroll
         for (int i = 0; i < 17; ++i) w[i] = mine_w[i];
-        if (inside) lane_table_fast<BITS>(w, cls, tab);
-        else lane_table<BITS>(w, p0, r.frame_end, cls, tab);
+#ifndef JSP_FUSED_MASKS
+#define JSP_FUSED_MASKS 1
+#endif
+        if (JSP_FUSED_MASKS && BITS == 16 && inside) {
+            bool has_skip;
+            masks = lane_masks16(w, has_skip);
+            fast = __ballot(has_skip) == 0ull;
+        }
+        if (fast) lane_table_masks(masks, tab);
+        else {
+            uint32_t cls[LSLOTS];
+            lane_table<BITS>(w, p0, r.frame_end, cls, tab);
+        }
 #pragma unroll
         for (int e = 0; e < 9; ++e) tree[tid][e] = tab[e];
     }
@@ -673,8 +729,40 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG) reinterpret_cast<uint32_t*>(stage)[i] = 0xFFFFFFFFu;
             __syncthreads();
         }
-        {
-            // replay the lane's slots: the chain visits slot `pos`; a coded block leaves the offset of its code
+        if (fast) {
+            // The slots the chain visits, as a bit mask: from the entry slot, every visited code marks the slot its length
+            // further on, until nothing changes (a wave needs as many rounds as its longest lane has codes).
+            const uint32_t entry_slot = mine & 15u, blk0 = mine >> 4;
+            uint32_t V = 1u << entry_slot;                      // (entry_slot <= 8)
+            for (;;) {
+                const uint32_t V2 = V | ((V & masks.S) << 1) | ((V & masks.T) << 3) | ((V & masks.E) << 9);
+                const bool grew = V2 != V;
+                V = V2;
+                if (!__any(grew)) break;
+            }
+            if (INFO && w0 == tb0) {                            // a coded block in a significant block row?
+                const uint32_t cnt = (uint32_t)__popc(V), lo = blk0 > s1_first_block ? blk0 : s1_first_block;
+                const uint32_t hi = blk0 + cnt < nblocks ? blk0 + cnt : nblocks;
+                if (lo < hi) seen |= MSV1_ASYNC_S1;
+            }
+            if (MODE != 1) {
+                uint32_t idx = blk0 - w0;                       // position in the window of the lane's next block
+                for (uint32_t left = V; left; left &= left - 1u) {
+                    const uint32_t sl = (uint32_t)__ffs((int)left) - 1u;
+                    if (idx < wn) stage[idx] = (uint16_t)(tid * (LSLOTS * 2) + 2u * sl);
+                    ++idx;
+                }
+            }
+        } else {
+            // replay the lane's slots one by one: the chain visits slot `pos`; a coded block leaves the offset of its code
+            uint32_t w[17], cls[LSLOTS];
+            const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
+#pragma unroll
+            for (int i = 0; i < 17; ++i) w[i] = mine_w[i];
+            {
+                uint32_t tab[9];
+                lane_table<BITS>(w, p0, r.frame_end, cls, tab);   // (for its classification; the table is not used again)
+            }
             uint32_t pos = mine & 15u, blk = mine >> 4;
 #pragma unroll
             for (int s = 0; s < LSLOTS; ++s) {
