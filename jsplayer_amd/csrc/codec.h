@@ -1,6 +1,7 @@
 // Internal C++ shape of the C ABI objects (include/jsplayer_amd.h).
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "../../include/jsplayer_amd.h"
@@ -33,6 +34,7 @@ struct jsp_staged {
     jsp::DeviceBuffer d_signif;
     jsp::PinnedBuffer h_signif;
     bool decoded = false;
+    bool verdict_pending = false;   // asynchronous staging whose results are final only after async_finish()
     void finish_results();  // after the stream has been synchronised
     virtual void after_sync() {}   // codec-specific checks of what the kernels reported (called by finish_results)
 };
@@ -47,7 +49,9 @@ struct jsp_async_job {
     int32_t* prev_dev_before = nullptr;
     int32_t* prev_caller_after = nullptr;    // PreviousFrame() once this frame is done
     bool redone = false;                 // results already final (the frame was re-run through the synchronous path)
+    bool settled = false;                // results already final (its kernels were waited for ahead of its jsp_wait)
     int status = 0, significant = 0;
+    std::string why;                     // error text of a final non-zero status
 };
 
 struct jsp_codec {
@@ -90,6 +94,10 @@ struct jsp_codec {
         return stage(std::vector<jsp_frame_in>{f}, reuse);
     }
     virtual bool async_finish(jsp_staged*) { return true; }
+    // True when stage_async() would stage this frame with kernels that cannot be vetoed afterwards (the synchronous
+    // staging): every earlier frame still in flight is then settled first — re-run, if the GPU could not settle it —
+    // because the caller may already have handed this frame a buffer an earlier frame's re-run still reads.
+    virtual bool async_settle_first(const jsp_frame_in&) { return false; }
     // Called (stream idle) before frames are re-run through the synchronous path: undo whatever made the frames in
     // flight behind the failed one stand still.
     virtual void async_reset() {}

@@ -264,32 +264,6 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
 
 namespace {
 
-int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool key, uint64_t* ticket) {
-    if (!c || !dst || !ticket || (!src && n)) throw std::runtime_error("null argument");
-    c->activate();
-    if (classify_pointer(dst) != 1) throw std::runtime_error("asynchronous calls take device frame buffers only");
-    if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
-    c->ptr_mode = 1;
-    if ((int)(c->next_ticket - c->oldest_ticket) >= c->async_depth) throw std::runtime_error("too many frames in flight: jsp_wait for the oldest first");
-    if ((int)c->jobs.size() != c->async_depth) c->jobs.resize(c->async_depth);
-    jsp_async_job& j = c->jobs[c->next_ticket % c->async_depth];
-    if (!j.done) JSP_HIP(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
-    j.frame = jsp_frame_in{src, n, key, dst};
-    j.prev_caller_before = c->prev_caller;
-    j.prev_dev_before = c->prev_dev;
-    j.redone = false;
-    jsp_staged* st = c->stage_async(j.frame, j.st.get());
-    if (st != j.st.get()) j.st.reset(st);
-    st->decode(c->stream);
-    JSP_HIP(hipEventRecord(j.done, c->stream));
-    if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
-    if (st->adopted[0]) c->prev_caller = dst;
-    j.prev_caller_after = c->prev_caller;
-    j.ticket = c->next_ticket++;
-    *ticket = j.ticket;
-    return JSP_ZERO_STATE;
-}
-
 // The frame of job `from` could not be settled by the GPU alone: everything from it on is re-run, in order, through
 // the synchronous path (the codec's state is put back to what it was before that frame).
 void redo_from(jsp_codec* c, uint64_t from) {
@@ -304,9 +278,55 @@ void redo_from(jsp_codec* c, uint64_t from) {
         int sig = 0;
         j.status = decompress_one(c, j.frame.src, j.frame.n, j.frame.dst, j.frame.key, &data, &sig);
         j.significant = sig;
+        if (j.status != JSP_ZERO_STATE) j.why = last_error_slot();
         j.prev_caller_after = c->prev_caller;
         j.redone = true;
     }
+}
+
+// Makes the results of job `t` final: waits for its kernels, reads the verdict of the scout, and re-runs everything from
+// it on when the GPU alone could not settle the frame.
+void settle(jsp_codec* c, uint64_t t) {
+    jsp_async_job& j = c->jobs[t % c->async_depth];
+    if (j.redone || j.settled) return;
+    JSP_HIP(hipEventSynchronize(j.done));
+    j.st->finish_results();
+    if (!c->async_finish(j.st.get())) { redo_from(c, t); return; }
+    j.status = j.st->status[0];
+    j.significant = j.st->significant[0] < 0 ? 0 : j.st->significant[0];
+    if (j.status != JSP_ZERO_STATE) j.why = j.st->why.empty() ? "decode aborted: the reference raises on this stream" : j.st->why;
+    j.settled = true;
+}
+
+
+int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool key, uint64_t* ticket) {
+    if (!c || !dst || !ticket || (!src && n)) throw std::runtime_error("null argument");
+    c->activate();
+    if (classify_pointer(dst) != 1) throw std::runtime_error("asynchronous calls take device frame buffers only");
+    if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
+    c->ptr_mode = 1;
+    if ((int)(c->next_ticket - c->oldest_ticket) >= c->async_depth) throw std::runtime_error("too many frames in flight: jsp_wait for the oldest first");
+    if ((int)c->jobs.size() != c->async_depth) c->jobs.resize(c->async_depth);
+    jsp_async_job& j = c->jobs[c->next_ticket % c->async_depth];
+    if (!j.done) JSP_HIP(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+    j.frame = jsp_frame_in{src, n, key, dst};
+    if (c->async_settle_first(j.frame))
+        for (uint64_t t = c->oldest_ticket; t < c->next_ticket; ++t)
+            if (c->jobs[t % c->async_depth].st->verdict_pending) settle(c, t);   // the others were settled when they were staged
+    j.prev_caller_before = c->prev_caller;
+    j.prev_dev_before = c->prev_dev;
+    j.redone = j.settled = false;
+    j.why.clear();
+    jsp_staged* st = c->stage_async(j.frame, j.st.get());
+    if (st != j.st.get()) j.st.reset(st);
+    st->decode(c->stream);
+    JSP_HIP(hipEventRecord(j.done, c->stream));
+    if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
+    if (st->adopted[0]) c->prev_caller = dst;
+    j.prev_caller_after = c->prev_caller;
+    j.ticket = c->next_ticket++;
+    *ticket = j.ticket;
+    return JSP_ZERO_STATE;
 }
 
 }  // namespace
@@ -325,17 +345,8 @@ extern "C" int jsp_wait(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* 
         if (ticket != c->oldest_ticket || ticket >= c->next_ticket) throw std::runtime_error("tickets are waited for in submission order");
         c->activate();
         jsp_async_job& j = c->jobs[ticket % c->async_depth];
-        if (!j.redone) {
-            JSP_HIP(hipEventSynchronize(j.done));
-            j.st->finish_results();
-            if (!c->async_finish(j.st.get())) redo_from(c, ticket);
-            else {
-                j.status = j.st->status[0];
-                j.significant = j.st->significant[0] < 0 ? 0 : j.st->significant[0];
-                if (j.status != JSP_ZERO_STATE)
-                    set_error("%s", j.st->why.empty() ? "decode aborted: the reference raises on this stream" : j.st->why.c_str());
-            }
-        }
+        settle(c, ticket);
+        if (j.status != JSP_ZERO_STATE) set_error("%s", j.why.c_str());
         ++c->oldest_ticket;
         j.ticket = 0;
         if (data_pnt) *data_pnt = j.prev_caller_after;

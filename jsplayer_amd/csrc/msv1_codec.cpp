@@ -99,6 +99,7 @@ struct Msv1Staged : jsp_staged {
 // waits for the GPU; what the host could not know (stage-1 / stage-2 significance, a stream the host parser has to
 // settle) is read from the report once the frame's event has fired (Msv1Codec::async_finish).
 struct Msv1AsyncStaged : jsp_staged {
+    Msv1AsyncStaged() { verdict_pending = true; }
     Msv1Geometry geo{};
     const int32_t* d_palette = nullptr;
     int ntiles = 0, insignificant_blocks = 0;
@@ -240,13 +241,19 @@ struct Msv1Codec : jsp_codec {
         return {covered < geo.nblocks, false};   // all skip codes: nothing coded; too short = host parser
     }
 
+    // frames the scout + vetoable decode pair cannot take: they go through the synchronous staging
+    bool sync_staging(const jsp_frame_in& f, const Prescan& ps) const {
+        const bool aligned = (X & 3) == 0 && !(reinterpret_cast<uintptr_t>(f.dst) & 15) && !(reinterpret_cast<uintptr_t>(prev_dev) & 15);
+        return !opt_gpu_parse || !aligned || (Y & 3) || ps.sync_path || geo.nblocks <= 0 || geo.nblocks >= (1 << 20) ||
+               f.n + msv1_parse_tile_bytes() > 0xFFFFFFF0u || (geo.bits == 8 && !d_palette.p);
+    }
+    bool async_settle_first(const jsp_frame_in& f) override { return sync_staging(f, prescan(f.src, f.n)); }
+
     jsp_staged* stage_async(const jsp_frame_in& f, jsp_staged* reuse) override {
         activate();
-        const bool aligned = (X & 3) == 0 && !(reinterpret_cast<uintptr_t>(f.dst) & 15) && !(reinterpret_cast<uintptr_t>(prev_dev) & 15);
         const size_t tile_bytes = msv1_parse_tile_bytes();
         const Prescan ps = prescan(f.src, f.n);
-        if (!opt_gpu_parse || !aligned || (Y & 3) || ps.sync_path || geo.nblocks <= 0 || geo.nblocks >= (1 << 20) ||
-            f.n + tile_bytes > 0xFFFFFFF0u || (geo.bits == 8 && !d_palette.p)) {
+        if (sync_staging(f, ps)) {
             // the synchronous staging (it may wait for the GPU: tiny, odd or pre-parsed frames only)
             return stage(std::vector<jsp_frame_in>{f}, dynamic_cast<Msv1Staged*>(reuse));
         }

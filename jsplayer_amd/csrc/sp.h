@@ -131,6 +131,9 @@ private:
     int band_rows_ = 0, span_px_ = 0;
     std::vector<IRun> tiled_;        // scratch of the tile regrouping (kept: no per-frame allocation)
     std::vector<uint32_t> cursor_;
+    std::vector<uint32_t> slot_of_;  // tile slot of every record, in emission order
+    std::vector<uint32_t> row_slot_; // tile slot of (row, span 0) for the current layout
+    int row_slot_rows_ = 0, row_slot_span_ = 0;
 };
 
 // ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------

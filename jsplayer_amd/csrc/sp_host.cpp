@@ -105,43 +105,84 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
         };
         auto& runs = out.runs;
         runs.clear();
-        // One record per piece of a run: runs are cut at row starts and at every kRunSplit-th column, so a
+        const bool tile_layout = span_px_ > 0;
+        const long split = tile_layout ? span_px_ : kRunSplit;
+        const int split_shift = (split & (split - 1)) == 0 ? __builtin_ctzl((unsigned long)split) : -1;
+        const int rows_per = band_rows_ > 0 && band_rows_ < g_.Y ? band_rows_ : g_.Y;
+        const int nspans = tile_layout ? (int)((X + split - 1) / split) : 0;
+        const size_t stride = (size_t)rows_per + 1;   // index entries per tile: its rows, then its end
+        if (tile_layout && (row_slot_.size() != (size_t)g_.Y || row_slot_rows_ != rows_per || row_slot_span_ != span_px_)) {
+            row_slot_.resize(g_.Y);   // tile slot of (row y, span 0): ((band * nspans) * stride + row inside the band)
+            for (int y = 0; y < g_.Y; ++y) row_slot_[y] = (uint32_t)(((size_t)(y / rows_per) * nspans) * stride + (size_t)(y % rows_per));
+            row_slot_rows_ = rows_per;
+            row_slot_span_ = span_px_;
+        }
+        slot_of_.clear();
+        long di = 0;
+        int row = 0, col = 0;   // di == row * X + col, kept without dividing
+        // One record per piece of a run: runs are cut at row starts and at every `split`-th column, so a
         // row's records are exactly those that start inside it and none crosses the span of one wave of
-        // the row kernel (which then scatters each record with a single store, no clamping, no loop).
-        auto emit = [&](long start, int cnt, uint32_t kind, uint32_t payload) {
-            if (cnt <= 0 || start >= end) return;
+        // the row kernel (which then scatters each record with a single store, no clamping, no loop).  In the
+        // tile layout the tile slot of every piece is noted on the way: the regrouping below never divides.
+        auto emit = [&](int cnt, uint32_t kind, uint32_t payload) {   // the run starts at di
+            if (cnt <= 0 || di >= end) return;
             ++out.stream_runs;
             const uint32_t word = (payload & 0xFFFFFFu) | (kind << 24);
-            const long stop = start + cnt < end ? start + cnt : end;
-            const long split = span_px_ > 0 ? span_px_ : kRunSplit;
-            long col = start % X;
-            for (long i = start; i < stop;) {
+            long left = di + cnt < end ? cnt : end - di;
+            long i = di;
+            int y = row, c = col;
+            long sp = split_shift >= 0 ? c >> split_shift : c / split;
+            while (left > 0) {
                 runs.push_back({(uint32_t)i, word});
-                const long next_col = (col / split + 1) * split;
-                const long step = (next_col < X ? next_col : X) - col;
+                if (tile_layout) slot_of_.push_back(row_slot_[y] + (uint32_t)(sp * stride));
+                const long next_col = (sp + 1) * split < X ? (sp + 1) * split : X;
+                const long step = next_col - c;
                 i += step;
-                col = next_col < X ? next_col : 0;
+                left -= step;
+                c = (int)next_col;
+                ++sp;
+                if (c >= X) { c = 0; sp = 0; ++y; }
             }
         };
-        auto rd = [&](long i) -> int32_t { return (i >= 0 && i < end) ? dst[i] : 0; };
-        auto fill = [&](long at, int cnt, int32_t v) {
-            for (long i = at; i < at + cnt && i < end; ++i) dst[i] = v;
+        auto advance = [&](int cnt) {
+            di += cnt;
+            col += cnt;
+            while (col >= X) { col -= (int)X; ++row; }
         };
-        long di = 0, k = 0;
+        auto rd = [&](long i) -> int32_t { return (i >= 0 && i < end) ? dst[i] : 0; };
+        auto inside = [&](int cnt) -> long { return di >= end ? 0 : (di + cnt < end ? cnt : end - di); };
+        auto fill = [&](int cnt, int32_t v) { std::fill_n(dst + di, inside(cnt), v); };
+        // pixel i takes pixel i - back (+ the byte-wise addend d): forward order matters only when the run is longer
+        // than `back`, so it goes in pieces of at most X pixels, each of them a plain non-overlapping copy
+        auto from_above = [&](int cnt, long back, uint32_t d) {
+            const long n = inside(cnt);
+            for (long off = 0; off < n; off += X) {
+                const long len = n - off < X ? n - off : X;
+                int32_t* to = dst + di + off;
+                const int32_t* from = to - back;
+                if (d == 0) std::memcpy(to, from, (size_t)len * 4);
+                else
+                    for (long j = 0; j < len; ++j) {
+                        const uint32_t u = (uint32_t)from[j];
+                        to[j] = (int32_t)((((u & 0x7F7F7Fu) + (d & 0x7F7F7Fu)) ^ ((u ^ d) & 0x808080u)) & 0xFFFFFFu);
+                    }
+            }
+        };
+        long k = 0;
         int32_t clr = 0;
         while (k < X + 1) {  // phase 1: literal runs until a full row + 1 exists, :170-197
             clr = literal();
             const int cnt = ec_->run(0);
             k += cnt;
             progress(cnt > 0);
-            emit(di, cnt, RUN_CONST, (uint32_t)clr);
-            fill(di, cnt, clr);
-            di += cnt;
+            emit(cnt, RUN_CONST, (uint32_t)clr);
+            fill(cnt, clr);
+            advance(cnt);
         }
         int mask1 = 0xFC00, shift1 = 4, shiftc = 18;
         if (g_.bpp == 16 && ec_->rc_16bpp_constants()) { mask1 = 0xFF00; shift1 = 2; shiftc = 16; }
         int pt = 0;
-        while (di < end) {  // phase 2, :218-286
+        while (di < end) {  // phase 2, :218-286.  di >= X + 1 here: the row above and its left neighbour exist
             pt = ec_->ptype(pt);
             if (pt >= 6) throw DecodeAbort{"predictor type outside its tables"};
             if (pt == 0) clr = literal();
@@ -149,36 +190,38 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             progress(cnt > 0 && pt != 3);
             switch (pt) {
                 case 0:
-                    emit(di, cnt, RUN_CONST, (uint32_t)clr);
-                    fill(di, cnt, clr);
-                    di += cnt;
+                    emit(cnt, RUN_CONST, (uint32_t)clr);
+                    fill(cnt, clr);
+                    advance(cnt);
                     break;
                 case 1:  // repeat the pixel before the run
                     clr = rd(di - 1);
-                    emit(di, cnt, RUN_CONST, (uint32_t)clr);
-                    fill(di, cnt, clr);
-                    di += cnt;
+                    emit(cnt, RUN_CONST, (uint32_t)clr);
+                    fill(cnt, clr);
+                    advance(cnt);
                     break;
                 case 2:
-                    emit(di, cnt, RUN_ABOVE, 0);
-                    for (int c = 0; c < cnt; ++c, ++di) { clr = rd(di - X); if (di < end) dst[di] = clr; }
+                case 5: {
+                    const long back = pt == 2 ? X : X + 1;
+                    emit(cnt, pt == 2 ? RUN_ABOVE : RUN_ABOVE_LEFT, 0);
+                    if (cnt > 0) {
+                        from_above(cnt, back, 0);
+                        clr = rd(di + cnt - 1 - back);   // the last pixel of the run, also when the run overshoots the frame
+                        advance(cnt);
+                    }
                     break;
-                case 5:
-                    emit(di, cnt, RUN_ABOVE_LEFT, 0);
-                    for (int c = 0; c < cnt; ++c, ++di) { clr = rd(di - X - 1); if (di < end) dst[di] = clr; }
-                    break;
+                }
                 case 4: {  // left + above - aboveleft per byte; constant offset from the row above
                     if (cnt > 0) {
                         const uint32_t a = (uint32_t)rd(di - 1), b = (uint32_t)rd(di - 1 - X);
                         const uint32_t d = (((a & 0xFF) - (b & 0xFF)) & 0xFF) | (((a & 0xFF00) - (b & 0xFF00)) & 0xFF00) |
                                            (((a & 0xFF0000) - (b & 0xFF0000)) & 0xFF0000);
-                        emit(di, cnt, RUN_ABOVE, d);
-                        for (int c = 0; c < cnt; ++c, ++di) {
-                            const uint32_t u = (uint32_t)rd(di - X);
-                            clr = (int32_t)((((u & 0xFF) + (d & 0xFF)) & 0xFF) | (((u & 0xFF00) + (d & 0xFF00)) & 0xFF00) |
-                                            (((u & 0xFF0000) + (d & 0xFF0000)) & 0xFF0000));
-                            if (di < end) dst[di] = clr;
-                        }
+                        emit(cnt, RUN_ABOVE, d);
+                        from_above(cnt, X, d);
+                        const uint32_t u = (uint32_t)rd(di + cnt - 1 - X);
+                        clr = (int32_t)((((u & 0xFF) + (d & 0xFF)) & 0xFF) | (((u & 0xFF00) + (d & 0xFF00)) & 0xFF00) |
+                                        (((u & 0xFF0000) + (d & 0xFF0000)) & 0xFF0000));
+                        advance(cnt);
                     }
                     break;
                 }
@@ -195,24 +238,21 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             while (r + 1 < runs.size() && runs[r + 1].start <= first) ++r;
             out.row_run[y] = (uint32_t)r;
         }
-        if (span_px_ > 0) {  // tile layout: records regrouped tile by tile, plus what each tile needs from its left
-            const int rows_per = band_rows_ > 0 && band_rows_ < g_.Y ? band_rows_ : g_.Y;
-            const int nbands = (g_.Y + rows_per - 1) / rows_per, nspans = (g_.X + span_px_ - 1) / span_px_;
-            const size_t ntiles = (size_t)nbands * nspans, stride = (size_t)rows_per + 1;
+        if (tile_layout) {  // records regrouped tile by tile, plus what each tile needs from its left
+            const int nbands = (g_.Y + rows_per - 1) / rows_per;
+            const size_t ntiles = (size_t)nbands * nspans;
             runs.pop_back();                              // the sentinel has no place in a tile
             std::vector<uint32_t>& idx = out.tile_idx;
             idx.assign(ntiles * stride + 1, 0);           // counts first (shifted by one), then prefix sums
-            auto slot = [&](uint32_t start) -> size_t {
-                const long y = start / X, x = start - y * X;
-                return ((size_t)(y / rows_per) * nspans + (size_t)(x / span_px_)) * stride + (size_t)(y % rows_per);
-            };
-            for (const IRun& r : runs) ++idx[slot(r.start) + 1];
+            const uint32_t* slot_of = slot_of_.data();    // per record, noted when it was emitted
+            const size_t nrec = runs.size();
+            for (size_t i = 0; i < nrec; ++i) ++idx[slot_of[i] + 1];
             for (size_t i = 1; i < idx.size(); ++i) idx[i] += idx[i - 1];
             std::vector<IRun>& tiled = tiled_;
             tiled.resize(runs.size());
             std::vector<uint32_t>& cursor = cursor_;
             cursor.assign(idx.begin(), idx.end() - 1);
-            for (const IRun& r : runs) tiled[cursor[slot(r.start)]++] = r;   // stable: row-major order survives inside a tile
+            for (size_t i = 0; i < nrec; ++i) tiled[cursor[slot_of[i]]++] = runs[i];   // stable: row-major order survives inside a tile
             idx.pop_back();                               // ntiles * stride entries: the slot after a tile's last row is its end
             // Screen content repeats itself from row to row: a row of a tile whose records equal, column for column, those
             // of the row above it in the same tile is not stored at all — bit 31 of its index entry (kRowRepeats) says "the

@@ -25,8 +25,8 @@ def main():
     rng = np.random.default_rng(seed)
     t0, clips, nframes = time.time(), 0, 0
     while time.time() - t0 < budget:
-        w = int(rng.choice([int(rng.integers(1, 120)) * 4, int(rng.integers(4, 500))]))
-        h = int(rng.choice([int(rng.integers(1, 70)) * 4, int(rng.integers(4, 300))]))
+        w = int(rng.choice([int(rng.integers(1, 120)) * 4, int(rng.integers(4, 500)), int(rng.integers(100, 481)) * 4]))
+        h = int(rng.choice([int(rng.integers(1, 70)) * 4, int(rng.integers(4, 300)), int(rng.integers(60, 271)) * 4]))   # up to 1920x1080: dozens of 16 KiB tiles per frame
         bits = int(rng.choice([16, 8]))
         n = int(rng.integers(2, 12))
         p_mix = sg.msv1_p_mix(float(rng.choice([0.0, 0.3, 0.7, 0.95, 1.0])), float(rng.choice([1.5, 8.0, 40.0, 300.0])))
@@ -46,12 +46,20 @@ def main():
             elif r < 0.30:
                 b = b + b"\x07"
             frames[i] = bytes(b)
-        mode = str(rng.choice(["host", "gpu"]))
+        mode = str(rng.choice(["host", "gpu", "gpu", "async"]))   # async: jsp_decompress_*_async / jsp_wait with the on-GPU parse
         host_buffers, misalign = rng.random() < 0.15, rng.random() < 0.15
         lines = int(rng.integers(0, 60))
-        tag = f"{w}x{h} {bits}bit n={n} key_every={key_every} parse={mode} host={host_buffers} misalign={misalign} lines={lines} cfg={cfg}"
+        depth = int(rng.choice([1, 2, 4, 8]))
+        tag = f"{w}x{h} {bits}bit n={n} key_every={key_every} parse={mode} host={host_buffers} misalign={misalign} lines={lines} cfg={cfg}" + (f" depth={depth}" if mode == "async" else "")
         try:
-            drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
+            if mode == "async":
+                import test_async_gpu as A
+                from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit
+                gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
+                gpu.set_option("msv1_parse", "gpu")
+                A.drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=bool(rng.random() < 0.5), lines=lines)
+            else:
+                drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
         except AssertionError as e:
             print("BAD", tag, e, flush=True)
             return 1

@@ -112,6 +112,20 @@ def test_msvideo1_async_hands_unsettled_frames_to_the_synchronous_path(depth):
     drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, depth=depth)
 
 
+@pytest.mark.parametrize("size", [(320, 240), (1224, 752)], ids=["320x240", "1224x752"])
+def test_msvideo1_async_synchronously_staged_frame_waits_for_open_verdicts(size):
+    """Found by tests/fuzz_msvideo1.py: a truncated inter frame (its verdict is open until the scout has run), then a
+    tiny frame that can only be staged synchronously, handed the buffer the truncated frame's re-run still reads as its
+    previous frame (the caller may: it is not PreviousFrame() any more).  The tiny frame must not run ahead."""
+    w, h = size
+    frames, keys, _ = sg.msv1_clip(57, w, h, 4, p_mix=sg.msv1_p_mix(0.7, 8.0), key_every=0)
+    rng = np.random.default_rng(6)
+    frames = [frames[0], frames[1][:len(frames[1]) * 3 // 4], rng.integers(0, 256, 92, dtype=np.uint8).tobytes(), frames[3]]
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, [True, False, False, False], depth=2, lines=57)
+
+
 def test_msvideo1_8bit_end_marker_and_first_frame_skip_code():
     w, h = 64, 32
     frames, keys, pal = sg.msv1_clip(53, w, h, 6, bits=8, p_mix=sg.msv1_p_mix(0.5, 6.0))
