@@ -127,6 +127,7 @@ private:
     bool use_bool_ = false;
     int insignificant_blocks_ = 0;
     std::vector<int32_t> bts_;
+    std::vector<uint8_t> stale_;     // per 16x16 block: shadow_[cur_] may differ from shadow_[1-cur_] there
     int stall_ = 0;
     int band_rows_ = 0, span_px_ = 0;
     std::vector<IRun> tiled_;        // scratch of the tile regrouping (kept: no per-frame allocation)

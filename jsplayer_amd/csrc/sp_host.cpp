@@ -19,6 +19,7 @@ HostDecoder::HostDecoder(int width, int height, int bpp) {
     g_.nby = (height + 15) / 16;
     cxshift_ = bpp == 16 ? 0 : 2;  // ScreenPressor.hx:59
     bts_.assign((size_t)g_.nbx * g_.nby, 0);
+    stale_.assign(bts_.size(), 1);
     for (auto& s : shadow_) s.assign((size_t)width * height, 0);
 }
 
@@ -90,6 +91,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             last_flat_ = true;
             decoded_i_ = true;
             cur_ ^= 1;
+            std::fill(stale_.begin(), stale_.end(), 1);
             return;
         }
         last_flat_ = false;
@@ -297,11 +299,13 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
         has_prev_ = true;
         decoded_i_ = true;
         cur_ ^= 1;
+        std::fill(stale_.begin(), stale_.end(), 1);
     } catch (const DecodeAbort& a) {
         out.reset();
         out.status = 2;
         out.error = a.why;
         out.prev_cleared = had_prev && !has_prev_;  // RenewI nulled prevFrame and it stays null
+        std::fill(stale_.begin(), stale_.end(), 1);
     }
 }
 
@@ -356,9 +360,13 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
                 const size_t bi = (size_t)by * g_.nbx + bx;
                 const int bt = bts_[bi];
                 PBlock& pb = out.blocks[bi];
+                // The two shadow frames differ only where the frame before this one changed something (stale_): the rest of
+                // an unchanged block is already in place.
                 auto copy_block = [&] {
                     need_prev();
+                    if (!stale_[bi]) return;
                     for (int y = y1; y < y2; ++y) std::memcpy(dst + (long)y * X + x1, prev + (long)y * X + x1, sizeof(int32_t) * bw);
+                    stale_[bi] = 0;
                 };
                 if (bt <= 0) {  // unchanged, :468-474
                     copy_block();
@@ -447,10 +455,12 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
         out.stream_bytes = ec_->consumed();
         has_prev_ = true;
         cur_ ^= 1;
+        for (size_t i = 0; i < stale_.size(); ++i) stale_[i] = bts_[i] > 0;   // what the other shadow frame lacks now
     } catch (const DecodeAbort& a) {
         out.reset();
         out.status = 2;
         out.error = a.why;
+        std::fill(stale_.begin(), stale_.end(), 1);   // the frame being written is in an unknown state
     }
 }
 

@@ -130,44 +130,43 @@ void ColourModels::sparse16_from_sparse4(Small& s, int c) {  // Cx5.createFrom4
 void ColourModels::table_calc_sum(Table& t) {
     const int sh = t.fshift > 0 ? t.fshift - 1 : 0;
     int sum = (256 - t.td) << sh;
-    for (int i = 0; i < t.tcap; ++i) sum += t.e[i].cnt;
+    for (int i = 0; i < t.tcap; ++i) sum += t.cnt[i];
     t.tsum = (uint16_t)sum;
 }
 void ColourModels::table_rebuild(Table& t) {  // Cx6.rescaleDec
     const int sh = t.fshift > 0 ? t.fshift - 1 : 0;
     for (int i = 0; i < 256; ++i) c256_[i] = (uint16_t)(1 << sh);
-    for (int i = 0; i < t.td; ++i) c256_[t.e[i].sym] = t.e[i].cnt;
+    for (int i = 0; i < t.td; ++i) c256_[t.sym[i]] = t.cnt[i];
     int cum = 0;
     for (int i = 0; i < 256; ++i) { f512_[2 * i] = c256_[i]; f512_[2 * i + 1] = (uint16_t)cum; cum += c256_[i]; }
     if (t.fshift > 0) --t.fshift;
     const int sh2 = t.fshift > 0 ? t.fshift - 1 : 0;
     int sum = (256 - t.td) << sh2;
     for (int i = 0; i < t.td; ++i) {
-        Table::E& e = t.e[i];
-        e.cnt = (uint16_t)(e.cnt - (e.cnt >> 1));
-        sum += e.cnt;
-        e.freq = f512_[2 * e.sym];
-        e.cum = f512_[2 * e.sym + 1];
+        t.cnt[i] = (uint16_t)(t.cnt[i] - (t.cnt[i] >> 1));
+        sum += t.cnt[i];
+        t.freq[i] = f512_[2 * t.sym[i]];
+        t.cum[i] = f512_[2 * t.sym[i] + 1];
     }
     t.tsum = (uint16_t)sum;
 }
 void ColourModels::table_bump(Table& t, int pos) {  // Cx6.incrCntDec
     const int step = kTableStep << t.fshift;
-    t.e[pos].cnt = (uint16_t)(t.e[pos].cnt + step);
+    t.cnt[pos] = (uint16_t)(t.cnt[pos] + step);
     t.tsum = (uint16_t)(t.tsum + step);
-    if (pos > 0 && t.e[pos].cnt > t.e[pos - 1].cnt) table_swap(t, pos, pos - 1);
+    if (pos > 0 && t.cnt[pos] > t.cnt[pos - 1]) table_swap(t, pos, pos - 1);
     if (t.tsum + step > kProbScale) table_rebuild(t);
 }
 int ColourModels::table_add(Table& t, int c, int freq, int cum) {
     if (t.td >= 40 || t.td >= t.tcap) return -1;
-    t.e[t.td] = {(uint16_t)cum, (uint16_t)freq, (uint16_t)(freq - (freq >> 1)), (uint8_t)c, 0};
+    t.set(t.td, cum, freq, freq - (freq >> 1), c);
     return t.td++;
 }
 // interval an unseen symbol c would get right now
 int ColourModels::table_unseen_cum(const Table& t, int c) {
     int lower = -1, lfreq = 0, lcum = 0;
     for (int i = 0; i < t.td; ++i)
-        if (t.e[i].sym > lower && t.e[i].sym < c) { lower = t.e[i].sym; lfreq = t.e[i].freq; lcum = t.e[i].cum; }
+        if (t.sym[i] > lower && t.sym[i] < c) { lower = t.sym[i]; lfreq = t.freq[i]; lcum = t.cum[i]; }
     return lfreq > 0 ? lcum + lfreq + ((c - lower - 1) << t.fshift) : c << t.fshift;
 }
 uint32_t ColourModels::table_from_sparse16(const Small& s, int c) {  // Cx6.createFrom5
@@ -182,7 +181,7 @@ uint32_t ColourModels::table_from_sparse16(const Small& s, int c) {  // Cx6.crea
         const int sy = s.sym[pos];
         cum += sy - last;
         const int fr = s.freq[pos] << shift;
-        t.e[pos] = {(uint16_t)(cum << shift), (uint16_t)fr, (uint16_t)(fr - (fr >> 1)), (uint8_t)sy, 0};
+        t.set(pos, cum << shift, fr, fr - (fr >> 1), sy);
         cum += s.freq[pos];
         last = sy + 1;
     }
@@ -190,16 +189,16 @@ uint32_t ColourModels::table_from_sparse16(const Small& s, int c) {  // Cx6.crea
     t.fshift = shift;
     const int f = 1 << t.fshift;
     const int cf = c > 0 ? table_unseen_cum(t, c) : 0;
-    t.e[oldd] = {(uint16_t)cf, (uint16_t)f, (uint16_t)(f - (f >> 1)), (uint8_t)c, 0};
+    t.set(oldd, cf, f, f - (f >> 1), c);
     t.td = oldd + 1;
     const int step = kTableStep << t.fshift;
-    t.e[oldd].cnt = (uint16_t)(t.e[oldd].cnt + step);
+    t.cnt[oldd] = (uint16_t)(t.cnt[oldd] + step);
     t.tsum = (uint16_t)(t.tsum + step);
     if (t.tsum + step > kProbScale) table_rebuild(t);
     table_calc_sum(t);
     for (int i = 0; i < t.td - 1; ++i)  // most frequent first (exchange sort, as the reference)
         for (int j = i + 1; j < t.td; ++j)
-            if (t.e[j].freq > t.e[i].freq) table_swap(t, i, j);
+            if (t.freq[j] > t.freq[i]) table_swap(t, i, j);
     return (uint32_t)(tables_.size() - 1);
 }
 uint32_t ColourModels::table_from_list(ListBig& l, int c) {  // Cx6.createFrom2
@@ -209,7 +208,14 @@ uint32_t ColourModels::table_from_list(ListBig& l, int c) {  // Cx6.createFrom2
     const int oldd = l.ld;
     t.tcap = oldd <= 32 ? 32 : 64;
     const int shift = shift_for(256 - oldd + oldd * f0_ + f0_);
-    sort_bytes(l.list, oldd);
+    // ascending symbols: read off the membership bits when the list holds each symbol once (always, but for the 0 a read
+    // past the end of the stream stores), else sorted as the reference does
+    if (__builtin_popcountll(l.seen[0]) + __builtin_popcountll(l.seen[1]) + __builtin_popcountll(l.seen[2]) + __builtin_popcountll(l.seen[3]) == oldd) {
+        int k = 0;
+        for (int w = 0; w < 4; ++w)
+            for (uint64_t m = l.seen[w]; m; m &= m - 1) l.list[k++] = (uint8_t)(w * 64 + __builtin_ctzll(m));
+    } else
+        sort_bytes(l.list, oldd);
     int cum = 0, last = 0, at = 0;
     for (int pos = 0; pos < oldd; ++pos) {
         const int sy = l.list[pos];
@@ -217,7 +223,7 @@ uint32_t ColourModels::table_from_list(ListBig& l, int c) {  // Cx6.createFrom2
         int cfr = f0_;
         if (sy == c) { at = pos; cfr = 2 * f0_; }
         const int fr = cfr << shift;
-        t.e[pos] = {(uint16_t)(cum << shift), (uint16_t)fr, (uint16_t)(fr - (fr >> 1)), (uint8_t)sy, 0};
+        t.set(pos, cum << shift, fr, fr - (fr >> 1), sy);
         cum += cfr;
         last = sy + 1;
     }
@@ -228,18 +234,39 @@ uint32_t ColourModels::table_from_list(ListBig& l, int c) {  // Cx6.createFrom2
     return (uint32_t)(tables_.size() - 1);
 }
 bool ColourModels::table_take(Table& t, int slot, Interval& iv) {  // Cx6.decode
-    int lfreq = 0, lcum = 0, lower = 0;
-    for (int i = 0; i < t.td; ++i) {
-        const int cf = t.e[i].cum;
-        if (cf <= slot) {
-            const int fr = t.e[i].freq;
-            if (cf + fr > slot) {
-                iv = {t.e[i].sym, (uint32_t)cf, (uint32_t)fr};
-                table_bump(t, i);
-                return true;
-            }
-            if (cf >= lcum) { lfreq = fr; lcum = cf; lower = t.e[i].sym; }
+    // The reference walks the entries in order: the first whose interval holds the slot wins; if none does, the entry
+    // with the highest start at or below the slot (the later one on a tie) is the seen symbol below the new one.  Here:
+    // eight entries per compare, one bit per entry, the two questions answered from the bit sets.
+    uint64_t below = 0, holds = 0;   // bit i: cum[i] <= slot / ... and slot < cum[i] + freq[i]
+    {
+        const __m128i bias = _mm_set1_epi16((short)0x8000);
+        const __m128i sl = _mm_set1_epi16((short)slot), sv = _mm_xor_si128(sl, bias);
+        for (int v = 0; v * 8 < t.td; ++v) {
+            const __m128i cu = _mm_load_si128(reinterpret_cast<const __m128i*>(t.cum + v * 8));
+            const __m128i fr = _mm_load_si128(reinterpret_cast<const __m128i*>(t.freq + v * 8));
+            const __m128i le = _mm_xor_si128(_mm_cmpgt_epi16(_mm_xor_si128(cu, bias), sv), _mm_set1_epi16(-1));   // cum <= slot (unsigned)
+            const __m128i room = _mm_sub_epi16(sl, cu);                                                            // slot - cum, exact where le
+            const __m128i in = _mm_cmpgt_epi16(_mm_xor_si128(fr, bias), _mm_xor_si128(room, bias));               // freq > slot - cum
+            const uint32_t mle = (uint32_t)_mm_movemask_epi8(_mm_packs_epi16(le, _mm_setzero_si128()));
+            const uint32_t min_ = (uint32_t)_mm_movemask_epi8(_mm_packs_epi16(_mm_and_si128(le, in), _mm_setzero_si128()));
+            below |= (uint64_t)mle << (v * 8);
+            holds |= (uint64_t)min_ << (v * 8);
         }
+        const uint64_t live = t.td >= 64 ? ~0ull : (1ull << t.td) - 1;
+        below &= live;
+        holds &= live;
+    }
+    if (holds) {
+        const int i = __builtin_ctzll(holds);
+        iv = {t.sym[i], t.cum[i], t.freq[i]};
+        table_bump(t, i);
+        return true;
+    }
+    int lfreq = 0, lcum = 0, lower = 0;
+    for (uint64_t m = below; m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        const int cf = t.cum[i];
+        if (cf >= lcum) { lfreq = t.freq[i]; lcum = cf; lower = t.sym[i]; }
     }
     const int f = 1 << t.fshift;
     int c, cf;
@@ -266,41 +293,49 @@ bool ColourModels::table_take(Table& t, int slot, Interval& iv) {  // Cx6.decode
 uint32_t ColourModels::full_from_list(const ListBig& l, int c) {  // Cx7.createFrom3
     fulls_.emplace_back(256);
     Full256& m = fulls_.back();
-    auto* fc = m.fc();
-    auto* cnt = m.cnt();
-    for (int i = 0; i < 256; ++i) { fc[i].freq = 1; cnt[i] = 1; }
+    uint16_t* cnt = m.cnt();
+    uint16_t* cum = m.cum();
+    uint16_t freq[256];
+    for (int i = 0; i < 256; ++i) { freq[i] = 1; cnt[i] = 1; }
     const int d = l.ld;
     const int f0 = (kProbScale - (256 - d)) / (d + 1), c0 = f0 - (f0 >> 1);
-    for (int i = 0; i < d; ++i) { fc[l.list[i]].freq = (uint16_t)f0; cnt[l.list[i]] = (uint16_t)c0; }
-    fc[c].freq = (uint16_t)(fc[c].freq + f0);
+    for (int i = 0; i < d; ++i) { freq[l.list[i]] = (uint16_t)f0; cnt[l.list[i]] = (uint16_t)c0; }
+    freq[c] = (uint16_t)(freq[c] + f0);
     cnt[c] = (uint16_t)(cnt[c] + 16);
     int sum = 0, cf = 0;
     for (int i = 0; i < 256; ++i) {
         sum += cnt[i];
-        fc[i].cum = (uint16_t)cf;
-        m.mark(cf, fc[i].freq, i);
-        cf += fc[i].freq;
+        cum[i] = (uint16_t)cf;
+        cf += freq[i];
     }
+    cum[256] = (uint16_t)cf;
     m.sum() = sum;
+    m.reindex();
     return (uint32_t)(fulls_.size() - 1);
 }
 uint32_t ColourModels::full_from_table(const Table& t) {  // Cx7.createFrom6
     fulls_.emplace_back(256);
     Full256& m = fulls_.back();
-    auto* fc = m.fc();
-    auto* cnt = m.cnt();
+    uint16_t* cnt = m.cnt();
+    uint16_t* cum = m.cum();
     m.sum() = t.tsum;
+    uint16_t freq[256];
+    std::memset(freq, 0, sizeof freq);
     for (int i = 0; i < t.tcap; ++i)
-        if (t.e[i].cnt > 0) { fc[t.e[i].sym] = {t.e[i].freq, t.e[i].cum}; cnt[t.e[i].sym] = t.e[i].cnt; }
+        if (t.cnt[i] > 0) { freq[t.sym[i]] = t.freq[i]; cnt[t.sym[i]] = t.cnt[i]; }
+    // (a seen symbol keeps the start the table gave it — the same running sum: the table tiles the code space with its own
+    // intervals and one of width f per unseen symbol)
     const int f = 1 << t.fshift, cu = f - (f >> 1);
     int cf = 0;
     for (int i = 0; i < 256; ++i) {
         int fr;
-        if (fc[i].freq > 0) fr = fc[i].freq;
-        else { fc[i] = {(uint16_t)f, (uint16_t)cf}; cnt[i] = (uint16_t)cu; fr = f; }
-        m.mark(cf, fr, i);
+        if (freq[i] > 0) fr = freq[i];
+        else { cnt[i] = (uint16_t)cu; fr = f; }
+        cum[i] = (uint16_t)cf;
         cf += fr;
     }
+    cum[256] = (uint16_t)cf;
+    m.reindex();
     return (uint32_t)(fulls_.size() - 1);
 }
 
@@ -320,8 +355,8 @@ void ColourModels::learn(int ctx, int c) {
             enter(s, List14);
             break;
         case List14: {
-            bool found = false;
-            for (int i = 0; i < s.n && !found; ++i) found = c >= 0 && s.sym[i] == c;
+            const unsigned same = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(s.sym)), _mm_set1_epi8((char)byte)));
+            const bool found = c >= 0 && (same & ((1u << s.n) - 1u));
             if (found) {
                 if (s.n <= 4) { sparse_from_list14(s, 4, c); enter(s, Sparse4); }
                 else { sparse_from_list14(s, 16, c); s.cached_tot = (uint16_t)sparse_total(s); enter(s, Sparse16); }
@@ -378,7 +413,12 @@ Interval ColourModels::take(int ctx, int slot) {
         case Table40:
             if (!table_take(tables_[s.big], slot, iv)) { s.big = full_from_table(tables_[s.big]); enter(s, Full); }
             break;
-        case Full: iv = fulls_[s.big].take(slot); break;
+        case Full: {
+            Full256& m = fulls_[s.big];
+            m.prefetch();   // hint and starts together: the second read does not wait for the first
+            iv = m.take(slot);
+            break;
+        }
         default: break;
     }
     return iv;
@@ -406,7 +446,7 @@ int ColourModels::locate(int ctx, int c) const {
         case Table40: {
             const Table& t = tables_[s.big];
             for (int i = 0; i < t.td; ++i)
-                if (t.e[i].sym == c) return t.e[i].cum;
+                if (t.sym[i] == c) return t.cum[i];
             return c > 0 ? table_unseen_cum(t, c) : 0;
         }
         case Full: return fulls_[s.big].locate(c);

@@ -14,7 +14,10 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 #include <vector>
+
+#include <emmintrin.h>   // SSE2: part of every x86-64
 
 namespace jsp::sp {
 
@@ -83,18 +86,54 @@ struct RcColourTables {
         return s;
     }
 #endif
+    // running sums of 16 counts on top of `before` into run[]; returns bit k set where run[k] > value
+    static unsigned scan16(const uint32_t* q, uint32_t before, uint32_t* run, __m128i vv) {
+        auto sums4 = [](__m128i v) { v = _mm_add_epi32(v, _mm_slli_si128(v, 4)); return _mm_add_epi32(v, _mm_slli_si128(v, 8)); };
+        __m128i a = _mm_add_epi32(sums4(_mm_loadu_si128(reinterpret_cast<const __m128i*>(q))), _mm_set1_epi32((int)before));
+        __m128i b = _mm_add_epi32(sums4(_mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 4))), _mm_shuffle_epi32(a, 0xFF));
+        __m128i c = _mm_add_epi32(sums4(_mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 8))), _mm_shuffle_epi32(b, 0xFF));
+        __m128i d = _mm_add_epi32(sums4(_mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 12))), _mm_shuffle_epi32(c, 0xFF));
+        _mm_store_si128(reinterpret_cast<__m128i*>(run), a);
+        _mm_store_si128(reinterpret_cast<__m128i*>(run + 4), b);
+        _mm_store_si128(reinterpret_cast<__m128i*>(run + 8), c);
+        _mm_store_si128(reinterpret_cast<__m128i*>(run + 12), d);
+        return (unsigned)_mm_movemask_ps(_mm_castsi128_ps(_mm_cmpgt_epi32(a, vv))) | (unsigned)_mm_movemask_ps(_mm_castsi128_ps(_mm_cmpgt_epi32(b, vv))) << 4 |
+               (unsigned)_mm_movemask_ps(_mm_castsi128_ps(_mm_cmpgt_epi32(c, vv))) << 8 | (unsigned)_mm_movemask_ps(_mm_castsi128_ps(_mm_cmpgt_epi32(d, vv))) << 12;
+    }
     Interval take(int row, uint32_t value) {
         uint32_t* p = &w[(size_t)row * ROW];
+        // The reference scans the 16 group sums, then the symbols of the group it stopped in (and on into the next ones
+        // when the sums do not add up — never on streams an encoder wrote).  Same answer from running sums built four
+        // at a time: the group / symbol is the first whose running sum exceeds the value.
         uint32_t cum = 0, fg = 0, f = 0;
-        int g = 0;
-        for (; g < 16; ++g) {
-            fg = p[g];
-            if (value >= cum + fg) cum += fg; else break;
+        int g = 16, c = 256;
+        if (value < 0x7FFFFFFFu) {
+            alignas(16) uint32_t run[16];
+            const __m128i vv = _mm_set1_epi32((int)value);
+            unsigned above = scan16(p, 0, run, vv);
+            if (above) {
+                g = __builtin_ctz(above);
+                fg = p[g];
+                const uint32_t before = g ? run[g - 1] : 0;
+                above = scan16(p + 17 + g * 16, before, run, vv);
+                if (above) {
+                    const int k = __builtin_ctz(above);
+                    c = g * 16 + k;
+                    f = p[17 + c];
+                    cum = k ? run[k - 1] : before;
+                }
+            }
         }
-        int c = g * 16;
-        for (; c < 256; ++c) {
-            f = p[17 + c];
-            if (value >= cum + f) cum += f; else break;
+        if (c == 256) {   // off the common path: walk as the reference does
+            cum = 0; fg = 0; f = 0;
+            for (g = 0; g < 16; ++g) {
+                fg = p[g];
+                if (value >= cum + fg) cum += fg; else break;
+            }
+            for (c = g * 16; c < 256; ++c) {
+                f = p[17 + c];
+                if (value >= cum + f) cum += f; else break;
+            }
         }
         uint32_t tot = p[16];
         // c == 256 lands on the next row's first word (dropped past the end of the whole table),
@@ -120,38 +159,65 @@ struct RcColourTables {
 constexpr int kProbBits = 12, kProbScale = 1 << kProbBits;
 
 // Fixed alphabet of up to CAP symbols, counts folded into the live intervals only when they fill the code space
-// (deferred adaptation).  ANS.hx:54-145.  Also the last stage (Cx7) of a colour context.  Plain arrays: a model is one
-// contiguous block, a pool of them a plain vector.
+// (deferred adaptation).  ANS.hx:54-145.  Also the last stage (Cx7) of a colour context.
+// The symbol owning a slot is the first j whose successor starts above the slot (ANS.hx:105-126: a scan from a hint that
+// never lies above the answer — the reference keeps 32 hints, this model 128, the answer is the same).  Layout for that
+// scan: only the interval STARTS are kept (the intervals tile the code space, so a frequency is the distance to the next
+// start; the end of the last interval closes the array), with eight 0xFFFF sentinels behind, so eight candidates are
+// compared at once and the scan needs no bound.  A lookup then depends on two cache lines in a row (hint, starts) — the
+// models of a stream are tens of megabytes, every lookup misses — and the count it bumps is off that path.
 template <int CAP>
 class FixedModelT {
 public:
-    struct FC { uint16_t freq, cum; };
+    using Hint = typename std::conditional<(CAP > 256), uint16_t, uint8_t>::type;
     explicit FixedModelT(int nsym = 0) { init(nsym); }
-    void init(int nsym) { n_ = nsym; sum_ = 0; std::memset(fc_, 0, sizeof fc_); std::memset(cnt_, 0, sizeof cnt_); std::memset(start_, 0, sizeof start_); }
+    void init(int nsym) {
+        n_ = nsym; sum_ = 0;
+        std::memset(hint_, 0, sizeof hint_); std::memset(cum_, 0, sizeof cum_); std::memset(cnt_, 0, sizeof cnt_);
+        for (int i = nsym + 1; i < CAP + 9; ++i) cum_[i] = 0xFFFF;
+    }
     void renew() {
         const int fr = kProbScale / n_, c0 = fr - (fr >> 1);
         sum_ = c0 * n_;
         int cf = 0;
-        for (int i = 0; i < n_; ++i) { fc_[i] = {(uint16_t)fr, (uint16_t)cf}; cnt_[i] = (uint16_t)c0; mark(cf, fr, i); cf += fr; }
+        for (int i = 0; i < n_; ++i) { cnt_[i] = (uint16_t)c0; cum_[i] = (uint16_t)cf; cf += fr; }
+        cum_[n_] = (uint16_t)cf;
+        reindex();
+    }
+    void prefetch() const {   // every line a lookup may read first
+        const char* p = reinterpret_cast<const char*>(hint_);
+        for (size_t o = 0; o < sizeof hint_ + sizeof cum_; o += 64) __builtin_prefetch(p + o);
     }
     Interval take(int slot) {
-        int j = start_[slot >> 7];
-        while (j < n_ - 1 && fc_[j + 1].cum <= slot) ++j;
-        Interval iv{j, fc_[j].cum, fc_[j].freq};
+        int j = hint_[slot >> 5];
+        const __m128i bias = _mm_set1_epi16((short)0x8000);
+        const __m128i sv = _mm_set1_epi16((short)(slot ^ 0x8000));
+        for (;;) {   // first of cum_[j+1 ..] above the slot (unsigned compare); the sentinels end it
+            const __m128i c = _mm_xor_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(cum_ + j + 1)), bias);
+            const int above = _mm_movemask_epi8(_mm_cmpgt_epi16(c, sv));
+            if (above) { j += __builtin_ctz((unsigned)above) >> 1; break; }
+            j += 8;
+        }
+        if (j > n_ - 1) j = n_ - 1;   // a slot past the last interval belongs to the last symbol
+        Interval iv{j, cum_[j], (uint32_t)(uint16_t)(cum_[j + 1] - cum_[j])};
         bump(j);
         return iv;
     }
     int size() const { return n_; }
-    // builders used by the colour-context upgrades (ANS.hx:711-771)
-    FC* fc() { return fc_; }
+    // builders used by the colour-context upgrades (ANS.hx:711-771): fill cum()[0..n] / cnt() / sum(), then reindex()
+    uint16_t* cum() { return cum_; }
     uint16_t* cnt() { return cnt_; }
     int& sum() { return sum_; }
-    void mark(int cf, int fr, int sym) {
-        const int k0 = (cf + 127) >> 7, k1 = ((cf + fr - 1) >> 7) + 1;
-        for (int k = std::max(k0, 0); k < k1 && k < 32; ++k) start_[k] = (uint8_t)sym;
+    void reindex() {   // hint of bucket k: the symbol owning slot 32 k
+        int j = 0;
+        for (int k = 0; k < 128; ++k) {
+            const int s = k << 5;
+            while (j < n_ - 1 && cum_[j + 1] <= s) ++j;
+            hint_[k] = (Hint)j;
+        }
     }
 #ifdef JSP_MODEL_TOOLS   // stream generator only: a slot inside c's current interval
-    int locate(int c) const { return fc_[c].cum; }
+    int locate(int c) const { return cum_[c]; }
 #endif
 private:
     void bump(int c) {
@@ -162,18 +228,19 @@ private:
             int cf = 0;
             for (int j = 0; j < n_; ++j) {
                 const int fr = cnt_[j];
-                fc_[j] = {(uint16_t)fr, (uint16_t)cf};
-                mark(cf, fr, j);
+                cum_[j] = (uint16_t)cf;
                 cf += fr;
                 cnt_[j] = (uint16_t)(fr - (fr >> 1));
                 sum_ += cnt_[j];
             }
+            cum_[n_] = (uint16_t)cf;
+            reindex();
         }
     }
     int n_ = 0, sum_ = 0;
-    FC fc_[CAP];
+    alignas(64) Hint hint_[128];
+    uint16_t cum_[CAP + 9];   // starts of the n intervals, the end of the last one, sentinels
     uint16_t cnt_[CAP];
-    uint8_t start_[32];
 };
 using FixedModel = FixedModelT<512>;   // run lengths, predictor types, block types, motion vectors, ...: up to 512 symbols
 
@@ -211,10 +278,14 @@ private:
     };
     struct ListBig { uint16_t ld; uint8_t list[256]; uint64_t seen[4]; };
     struct Table {            // Cx6: up to 40 explicit intervals inside the full 256-symbol cumulative space
-        struct E { uint16_t cum, freq, cnt; uint8_t sym, pad; };
         int tcap, td, fshift;
         uint16_t tsum;   // a 16-bit slot in the reference's typed array: it wraps
-        E e[64];
+        // entry i = (cum[i], freq[i], cnt[i], sym[i]); one array per field: the lookup compares eight starts at once
+        alignas(16) uint16_t cum[64];
+        alignas(16) uint16_t freq[64];
+        uint16_t cnt[64];
+        uint8_t sym[64];
+        void set(int i, int c, int f, int n, int sy) { cum[i] = (uint16_t)c; freq[i] = (uint16_t)f; cnt[i] = (uint16_t)n; sym[i] = (uint8_t)sy; }
     };
     using Full256 = FixedModelT<256>;
     static_assert(sizeof(Small) == 64, "one cache line per context");
@@ -228,7 +299,9 @@ private:
     void sparse_from_list14(Small& s, int capacity, int c);
     void sparse16_from_sparse4(Small& s, int c);
     // table (Cx6, ANS.hx:394-704)
-    static void table_swap(Table& t, int a, int b) { std::swap(t.e[a], t.e[b]); }
+    static void table_swap(Table& t, int a, int b) {
+        std::swap(t.cum[a], t.cum[b]); std::swap(t.freq[a], t.freq[b]); std::swap(t.cnt[a], t.cnt[b]); std::swap(t.sym[a], t.sym[b]);
+    }
     static void table_calc_sum(Table& t);
     void table_rebuild(Table& t);
     void table_bump(Table& t, int pos);

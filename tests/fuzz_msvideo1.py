@@ -23,7 +23,7 @@ def main():
     from jsplayer_amd import streamgen as sg
     from oracle_binding import OracleMSVideo1
     rng = np.random.default_rng(seed)
-    t0, clips, nframes = time.time(), 0, 0
+    t0, clips, nframes, bad = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         w = int(rng.choice([int(rng.integers(1, 120)) * 4, int(rng.integers(4, 500)), int(rng.integers(100, 481)) * 4]))
         h = int(rng.choice([int(rng.integers(1, 70)) * 4, int(rng.integers(4, 300)), int(rng.integers(60, 271)) * 4]))   # up to 1920x1080: dozens of 16 KiB tiles per frame
@@ -62,12 +62,15 @@ def main():
                 drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
         except AssertionError as e:
             print("BAD", tag, e, flush=True)
-            return 1
+            bad += 1
+            if bad >= 10:
+                return 1
+            continue
         print("ok ", tag, flush=True)
         clips += 1
         nframes += n
-    print(f"fuzz finished: {clips} clips, {nframes} frames, {time.time() - t0:.0f} s, seed {seed}")
-    return 0
+    print(f"fuzz finished: {clips} clips, {nframes} frames, {bad} BAD, {time.time() - t0:.0f} s, seed {seed}")
+    return 1 if bad else 0
 
 
 def drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign):
