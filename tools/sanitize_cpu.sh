@@ -12,6 +12,6 @@ C="$ROOT/jsplayer_amd/csrc"
 g++ $SAN -o "$OUT/liboracle.so" "$ROOT"/oracle/*.cpp
 g++ $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wno-deprecated-declarations -o "$OUT/libhoststage.so" \
     "$ROOT/tests/hoststage/shim.cpp" "$C/msv1_host.cpp" "$C/sp_host.cpp" "$C/sp_entropy.cpp" "$C/sp_models.cpp"
-g++ $SAN -o "$OUT/libjspgen.so" "$ROOT/jsplayer_amd/gen/sp_encoder.cpp" "$C/sp_models.cpp"
+g++ $SAN -DJSP_MODEL_TOOLS -o "$OUT/libjspgen.so" "$ROOT/jsplayer_amd/gen/sp_encoder.cpp" "$C/sp_models.cpp"
 LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" \
     ASAN_OPTIONS=detect_leaks=0 python3 "$ROOT/tools/sanitize_cpu.py"
