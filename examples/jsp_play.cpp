@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <string>
@@ -123,12 +124,20 @@ bool frame_is_key(const Clip& c, jsp_codec* dec, size_t i) {
 // The same loop with up to `depth` frames in flight.  A slot is handed out when it is neither the previous frame of the
 // last submitted frame, nor a destination in flight, nor showing a frame the oldest frame in flight may still be compared
 // with.  Returns frames decoded, or -1.
-long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet) {
+// Throughput runs (--quiet): `warmup` untimed passes over the clip (the codec's buffers reach their size, the clocks ramp up), then every
+// stream waits at `gate` and the timed passes begin together; *t0 / *t1 bracket this stream's timed passes.
+struct Gate { std::atomic<int> waiting{0}; int parties = 1; };
+using Clock = std::chrono::steady_clock;
+long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int warmup = 0, Gate* gate = nullptr, Clock::time_point* t0 = nullptr,
+                    Clock::time_point* t1 = nullptr) {
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
                                       (int)clip.palette.size(), 0);
     if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return -1; }
     jsp_preinit(dec, kInsignificantLines);
-    if (clip.kind != JSP_CODEC_SCREENPRESSOR) jsp_set_option(dec, "msv1_parse", "gpu");
+    if (clip.kind != JSP_CODEC_SCREENPRESSOR) {
+        jsp_set_option(dec, "msv1_parse", "gpu");
+        if (const char* form = std::getenv("JSP_PLAY_MSV1_ASYNC")) jsp_set_option(dec, "msv1_async", form);   // measurements: "two_launches"
+    }
     char dbuf[16];
     std::snprintf(dbuf, sizeof dbuf, "%d", depth);
     jsp_set_option(dec, "async_depth", dbuf);
@@ -173,7 +182,12 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet) {
             crc = crc32(reinterpret_cast<const uint8_t*>(host.data()), npx * 4);
         std::printf("%zu %s %d %d %08x\n", f.index, f.key ? "key" : "inter", shown, signif, crc);
     };
-    for (int rep = 0; rep < repeat && !failed; ++rep) {
+    for (int rep = -warmup; rep < repeat && !failed; ++rep) {
+        if (rep == 0) {
+            if (gate) { gate->waiting.fetch_add(1); while (gate->waiting.load() < gate->parties) std::this_thread::yield(); }
+            if (t0) *t0 = Clock::now();
+            done = 0;
+        }
         bool last_was_key = false;
         for (size_t i = 0; i < clip.frames.size(); ++i) {
             if ((int)flying.size() == depth) collect();
@@ -183,7 +197,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet) {
             int32_t* prev = jsp_previous_frame(dec);          // as of the last submitted frame
             int prev_slot = -1, slot = -1;
             for (int k = 0; k < nbuf; ++k) if (prev && jsp_pool_buffer(pool, k) == prev) prev_slot = k;
-            const long gi = (long)(rep * clip.frames.size() + i);
+            const long gi = (long)((rep + warmup) * (long)clip.frames.size() + (long)i);
             const long horizon = flying.empty() ? gi : flying.front().gindex - 1;   // what may still be looked at
             {
                 long oldest = 1L << 60;
@@ -206,22 +220,23 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet) {
             int32_t* now = jsp_previous_frame(dec);
             if (now == dst) first[slot] = last[slot] = gi;
             else if (now && now == prev && prev_slot >= 0) last[prev_slot] = gi;
-            flying.push_back({ticket, i, gi, key, slot, prev_slot, prev, key && last_was_key && i > 0, rep == 0 && i == 0});
+            flying.push_back({ticket, i, gi, key, slot, prev_slot, prev, key && last_was_key && i > 0, rep == -warmup && i == 0});
             last_was_key = key;
         }
         while (!flying.empty()) collect();
     }
+    if (t1) *t1 = Clock::now();
     jsp_pool_destroy(pool);
     jsp_codec_destroy(dec);
     return failed ? -1 : done;
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R]]]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R] [--warmup W]]]\n", argv[0]); return 2; }
     Clip clip;
     if (!load(argv[1], clip)) { std::fprintf(stderr, "%s: not a RIFF/AVI file this player understands\n", argv[1]); return 2; }
     bool pipelined = false, quiet = false;
-    int depth = 4, streams = 1, repeat = 1;
+    int depth = 4, streams = 1, repeat = 1, warmup = 1;
     for (int a = 2; a < argc; ++a) {
         const std::string o = argv[a];
         if (o == "--pipelined") pipelined = true;
@@ -229,6 +244,7 @@ int main(int argc, char** argv) {
         else if (o == "--depth" && a + 1 < argc) depth = std::atoi(argv[++a]);
         else if (o == "--streams" && a + 1 < argc) streams = std::atoi(argv[++a]);
         else if (o == "--repeat" && a + 1 < argc) repeat = std::atoi(argv[++a]);
+        else if (o == "--warmup" && a + 1 < argc) warmup = std::atoi(argv[++a]);
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
     }
     if (pipelined) {
@@ -236,15 +252,19 @@ int main(int argc, char** argv) {
         if (!quiet) return play_pipelined(clip, depth, 1, false) < 0 ? 1 : 0;
         streams = streams < 1 ? 1 : streams;
         std::vector<long> done(streams, 0);
+        std::vector<Clock::time_point> begin(streams), end(streams);
         std::vector<std::thread> pool;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int s = 0; s < streams; ++s) pool.emplace_back([&, s] { done[s] = play_pipelined(clip, depth, repeat, true); });
+        Gate gate;
+        gate.parties = streams;
+        for (int s = 0; s < streams; ++s) pool.emplace_back([&, s] { done[s] = play_pipelined(clip, depth, repeat, true, warmup, &gate, &begin[s], &end[s]); });
         for (auto& t : pool) t.join();
-        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        Clock::time_point first = begin[0], last = end[0];
+        for (int s = 1; s < streams; ++s) { if (begin[s] < first) first = begin[s]; if (end[s] > last) last = end[s]; }
+        const double sec = std::chrono::duration<double>(last - first).count();
         long frames = 0;
         for (long d : done) { if (d < 0) return 1; frames += d; }
-        std::printf("{\"streams\": %d, \"depth\": %d, \"frames\": %ld, \"seconds\": %.6f, \"mpixels_per_s\": %.1f}\n", streams, depth, frames,
-                    sec, frames * (double)clip.X * clip.Y / sec / 1e6);
+        std::printf("{\"streams\": %d, \"depth\": %d, \"frames\": %ld, \"warmup_passes\": %d, \"seconds\": %.6f, \"mpixels_per_s\": %.1f}\n", streams, depth, frames,
+                    warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6);
         return 0;
     }
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),

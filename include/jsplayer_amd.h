@@ -120,6 +120,13 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
  *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its
  *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame. */
+/*   "msv1_async" = "one_launch_dma" (default) | "one_launch" | "two_launches" : MSVideo1 with "msv1_parse" = "gpu", asynchronous
+ *       calls only; frames of up to 128 parse tiles (2 MiB).  one_launch_dma: the copy engine brings the frame's bytes up on a
+ *       stream of its own (next to the previous frame's kernel), ONE launch parses, waits until every tile of the frame
+ *       has reported what the host parser would have found, and rebuilds the frame — or leaves `dst` untouched for the
+ *       synchronous re-run.  one_launch: the same launch reads the bytes from the caller's pinned memory itself (no copy
+ *       queued at all; the bus transfer then sits inside the kernel).  two_launches: a scout launch, then the decode
+ *       launch it may veto (what larger frames always get).  Results do not depend on it. */
 /*   "async_depth" = "1".."16" (default "4") : any codec.  Frames that may be in flight between jsp_decompress_*_async and
  *       jsp_wait. */
 int jsp_set_option(jsp_codec* c, const char* key, const char* value);

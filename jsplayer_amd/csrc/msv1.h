@@ -107,16 +107,28 @@ constexpr uint32_t MSV1_ASYNC_SHORT = 1u;     // the stream does not cover every
 constexpr uint32_t MSV1_ASYNC_S1 = 2u;        // a coded block lies in a significant block row (MSVideo1.hx:187-194)
 constexpr uint32_t MSV1_ASYNC_END = 4u;       // an 8-bit end-of-data marker sits on the code chain
 constexpr uint32_t MSV1_ASYNC_SKIPCODE = 8u;  // a skip code sits on the code chain
+constexpr uint32_t MSV1_ASYNC_STUCK = 16u;    // mode 3: the frame's tiles did not all report in time (the GPU is shared with something that
+                                              // keeps them from being resident together): the host path settles the frame
 struct Msv1AsyncInfo {
     uint32_t flags;
     uint32_t signif;   // stage-2 significance word (OR-ed with 1 when a compared pixel differs)
     uint32_t fault;    // look-back gave up
-    uint32_t pad;
+    uint32_t arrived;  // mode 3: workgroups whose findings are in `flags` / that have written their last pixel; both run
+    uint32_t finished; //         on from launch to launch (see `want`)
+    uint32_t pad[3];
 };
+// mode 3 (one frame per launch, at most MSV1_MERGED_MAX_TILES tiles): scout and decode in ONE launch — every tile parses
+// and reports, waits until all `ntiles` reports are in (`want` = the value of d_info->arrived / finished once this launch is
+// through), and only then writes, or does not.  All tiles share `*one_rec` (k = the tile's index); the last workgroup copies
+// flags / signif / fault to `h_info` (pinned host memory) and clears them in d_info.  `d_stream` may be pinned HOST memory
+// (any alignment, nothing read past the frame's last byte): each tile reads its bytes once, over the bus, and leaves a copy
+// in `d_keep` (HBM, the frame's size rounded up to 16 bytes).
+constexpr int MSV1_MERGED_MAX_TILES = 128;
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
                        hipStream_t stream, Msv1AsyncInfo* d_info = nullptr, int insignificant_blocks = 0, int mode = 0,
-                       uint32_t bad_mask = 0, uint32_t* d_poison = nullptr);
+                       uint32_t bad_mask = 0, uint32_t* d_poison = nullptr, const Msv1TileRec* one_rec = nullptr,
+                       Msv1AsyncInfo* h_info = nullptr, uint32_t want = 0, uint8_t* d_keep = nullptr);
 
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,

@@ -106,15 +106,39 @@ struct Msv1AsyncStaged : jsp_staged {
     size_t nbytes = 0;
     bool have_prev = false, compare = false, key = false;
     uint32_t* d_poison = nullptr;             // the codec's veto word (see msv1_launch_fused)
-    DeviceBuffer d_stream, d_meta, d_agg;     // d_meta = [tile records | Msv1AsyncInfo]
+    DeviceBuffer d_stream, d_meta, d_agg;     // d_meta = [tile records | Msv1AsyncInfo] (two-launch form)
     PinnedBuffer h_stream, h_meta, h_info;
     uint32_t epoch = 0;                        // never reset: d_agg is zeroed only when it is (re)allocated
     size_t agg_tiles = 0;
+    // one-launch form (frames of at most MSV1_MERGED_MAX_TILES tiles): the record all tiles share travels as a kernel
+    // argument, the report comes back through pinned memory, and the kernel reads the frame's bytes from pinned host
+    // memory itself (the caller's, or h_stream), leaving a copy in d_stream: no copy is queued at all
+    bool merged = false;
+    Msv1TileRec rec{};
+    DeviceBuffer d_report;                    // one Msv1AsyncInfo, allocated (and zeroed) once: its counters run on
+    uint32_t want = 0;                        // ... to this value once every launch so far is through
+    const uint8_t* src_dev = nullptr;         // device-side address of the frame's bytes in pinned host memory
+    hipEvent_t uploaded = nullptr;            // (copy-engine form) the frame's bytes are in d_stream
+    bool dma = false;
+    ~Msv1AsyncStaged() override { if (uploaded) (void)hipEventDestroy(uploaded); }
 
-    Msv1AsyncInfo* d_info() const { return reinterpret_cast<Msv1AsyncInfo*>(static_cast<uint8_t*>(d_meta.p) + sizeof(Msv1TileRec) * (size_t)ntiles); }
+    Msv1AsyncInfo* d_info() const {
+        if (merged) return static_cast<Msv1AsyncInfo*>(d_report.p);
+        return reinterpret_cast<Msv1AsyncInfo*>(static_cast<uint8_t*>(d_meta.p) + sizeof(Msv1TileRec) * (size_t)ntiles);
+    }
     void decode(hipStream_t stream) override {
         auto* info_dev = d_info();
         const uint32_t bad = MSV1_ASYNC_SHORT | MSV1_ASYNC_END | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE);
+        if (merged) {
+            want += (uint32_t)ntiles;
+            if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
+            msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
+                              ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad, d_poison, &rec,
+                              static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p));
+            JSP_HIP(hipGetLastError());
+            decoded = true;
+            return;
+        }
         for (int mode = 1; mode <= 2; ++mode)   // scout, then the decode it may veto
             msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_meta.p), d_palette,
                               static_cast<unsigned long long*>(d_agg.p), ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev,
@@ -136,6 +160,9 @@ struct Msv1Codec : jsp_codec {
     int32_t palette[256];
     DeviceBuffer d_palette;
     bool opt_gpu_parse = false;
+    bool opt_async_merged = true, opt_async_dma = true;
+    hipStream_t up_stream = nullptr;
+    ~Msv1Codec() override { if (up_stream) (void)hipStreamDestroy(up_stream); }
     // block_changes is only maintained by the host parser; after frames parsed on the GPU it is
     // rebuilt on demand from the bytes of the last fully parsed frame
     bool block_changes_stale = false;
@@ -200,6 +227,11 @@ struct Msv1Codec : jsp_codec {
         if (std::strcmp(key, "msv1_parse") == 0) {
             if (std::strcmp(value, "gpu") == 0) { opt_gpu_parse = true; return 0; }
             if (std::strcmp(value, "host") == 0) { opt_gpu_parse = false; return 0; }
+        }
+        if (std::strcmp(key, "msv1_async") == 0) {   // frames of up to MSV1_MERGED_MAX_TILES tiles: one launch, or scout + decode
+            if (std::strcmp(value, "one_launch") == 0) { opt_async_merged = true; opt_async_dma = false; return 0; }
+            if (std::strcmp(value, "one_launch_dma") == 0) { opt_async_merged = true; opt_async_dma = true; return 0; }
+            if (std::strcmp(value, "two_launches") == 0) { opt_async_merged = false; return 0; }
         }
         return -1;
     }
@@ -284,21 +316,27 @@ struct Msv1Codec : jsp_codec {
         const size_t n_even = f.n & ~size_t(1);
         const int nt = (int)((f.n + tile_bytes - 1) / tile_bytes);
         st->ntiles = nt;
+        st->merged = opt_async_merged && nt <= MSV1_MERGED_MAX_TILES;
         const size_t slot = (size_t)nt * tile_bytes;
         st->d_stream.reserve(slot + 64);
-        const size_t meta_bytes = sizeof(Msv1TileRec) * (size_t)nt + sizeof(Msv1AsyncInfo);
-        st->d_meta.reserve(meta_bytes);
-        st->h_meta.reserve(meta_bytes);
         st->h_info.reserve(sizeof(Msv1AsyncInfo));
         if ((size_t)nt > st->agg_tiles) {   // published tile tables carry the launch epoch: fresh memory must read as epoch 0
             st->d_agg.reserve(sizeof(unsigned long long) * 9 * (size_t)nt);
             st->agg_tiles = st->d_agg.cap / (sizeof(unsigned long long) * 9);
             JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, st->d_agg.cap, stream));
         }
-        auto* recs = static_cast<Msv1TileRec*>(st->h_meta.p);
+        if (st->merged && !st->d_report.p) {
+            st->d_report.reserve(sizeof(Msv1AsyncInfo));
+            JSP_HIP(hipMemsetAsync(st->d_report.p, 0, sizeof(Msv1AsyncInfo), stream));
+            st->want = 0;
+        }
+        const size_t meta_bytes = sizeof(Msv1TileRec) * (size_t)nt + sizeof(Msv1AsyncInfo);
+        if (!st->merged) {
+            st->d_meta.reserve(meta_bytes);
+            st->h_meta.reserve(meta_bytes);
+        }
         auto* info_dev = st->d_info();
-        for (int k = 0; k < nt; ++k) {
-            Msv1TileRec& r = recs[k];
+        auto fill = [&](Msv1TileRec& r, int k) {
             r.byte0 = (uint32_t)(k * tile_bytes);
             r.frame_end = (uint32_t)n_even;
             r.data_end = geo.bits == 16 ? (uint32_t)n_even : (uint32_t)f.n;
@@ -311,19 +349,38 @@ struct Msv1Codec : jsp_codec {
             r.prev = prev_dev;
             r.signif = &info_dev->signif;
             r.pad = 0;
-        }
-        std::memset(recs + nt, 0, sizeof(Msv1AsyncInfo));
+        };
         // the frame's bytes: from where they are when the caller keeps them in pinned memory, else through our own
         const void* up = f.src;
+        const uint8_t* up_dev = nullptr;
         hipPointerAttribute_t attr{};
-        if (hipPointerGetAttributes(&attr, f.src) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        if (hipPointerGetAttributes(&attr, f.src) == hipSuccess && attr.type == hipMemoryTypeHost) {
+            up_dev = static_cast<const uint8_t*>(attr.devicePointer ? attr.devicePointer : f.src);
+        } else {
             (void)hipGetLastError();
             st->h_stream.reserve(f.n + 16);
             std::memcpy(st->h_stream.p, f.src, f.n);
             up = st->h_stream.p;
+            up_dev = static_cast<const uint8_t*>(st->h_stream.p);
         }
-        JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, stream));
-        JSP_HIP(hipMemcpyAsync(st->d_meta.p, recs, meta_bytes, hipMemcpyHostToDevice, stream));
+        if (st->merged) {
+            fill(st->rec, 0);
+            st->src_dev = up_dev;
+            st->dma = opt_async_dma;
+            if (st->dma) {   // the copy engine brings the bytes up on a stream of its own, next to the previous frame's kernel
+                if (!up_stream) JSP_HIP(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
+                if (!st->uploaded) JSP_HIP(hipEventCreateWithFlags(&st->uploaded, hipEventDisableTiming));
+                JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, up_stream));
+                JSP_HIP(hipEventRecord(st->uploaded, up_stream));
+                st->src_dev = static_cast<const uint8_t*>(st->d_stream.p);
+            }
+        } else {
+            auto* recs = static_cast<Msv1TileRec*>(st->h_meta.p);
+            for (int k = 0; k < nt; ++k) fill(recs[k], k);
+            std::memset(recs + nt, 0, sizeof(Msv1AsyncInfo));
+            JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, stream));
+            JSP_HIP(hipMemcpyAsync(st->d_meta.p, recs, meta_bytes, hipMemcpyHostToDevice, stream));
+        }
         // codec state, as the synchronous path leaves it
         if (ps.changes) prev_dev = f.dst;
         block_changes_stale = true;
@@ -333,7 +390,7 @@ struct Msv1Codec : jsp_codec {
         st->info.frames = 1;
         st->info.pixels = (uint64_t)X * Y;
         st->info.stream_bytes = f.n;
-        st->info.kernel_launches = 1;
+        st->info.kernel_launches = st->merged ? 1 : 2;
         st->info.host_stage_ms = now_ms() - t0;
         st->kernels = "msv1_fused_kernel";
         guard.release();
@@ -345,7 +402,7 @@ struct Msv1Codec : jsp_codec {
         if (!st) return true;                                    // went through the synchronous staging: already settled
         const Msv1AsyncInfo& in = *static_cast<const Msv1AsyncInfo*>(st->h_info.p);
         if (in.fault) { st->status[0] = JSP_ERROR_OCCURED; st->why = "msv1_fused_kernel: look-back timed out"; return true; }
-        if ((in.flags & (MSV1_ASYNC_SHORT | MSV1_ASYNC_END)) || ((in.flags & MSV1_ASYNC_SKIPCODE) && !st->have_prev))
+        if ((in.flags & (MSV1_ASYNC_SHORT | MSV1_ASYNC_END | MSV1_ASYNC_STUCK)) || ((in.flags & MSV1_ASYNC_SKIPCODE) && !st->have_prev))
             return false;                                        // the host parser has to settle this stream
         // significance, MSVideo1.hx:187-204 / 372-388 (key frames report none)
         const bool s1 = st->adopted[0] && (in.flags & MSV1_ASYNC_S1);

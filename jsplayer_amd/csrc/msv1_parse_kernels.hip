@@ -354,6 +354,7 @@ constexpr uint32_t TILE_BYTES = TSLOTS * 2;
 constexpr int LOOKBACK_BATCH = 3 * PWG / 9;    // 85 earlier tiles per poll (3 words per lane)
 constexpr int LOOKBACK_SEGS = 7;               // the chain through a batch is walked in 7 segments side by side
 constexpr int LOOKBACK_SPIN_LIMIT = 1 << 18;   // polls before the tile gives up and raises the fault word
+constexpr int VERDICT_SPIN_LIMIT = 1 << 15;    // MODE 3: polls for the frame's other tiles before the frame goes to the host path
 
 typedef uint32_t fu32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) fu32x4 fgu32x4;
@@ -516,8 +517,10 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                                                             uint32_t tile0, uint32_t* __restrict__ fault,
                                                             uint32_t nblocks, int nbx, int X,
                                                             Msv1AsyncInfo* __restrict__ info, uint32_t s1_first_block,
-                                                            uint32_t bad_mask, uint32_t* __restrict__ poison) {
-    constexpr bool INFO = MODE == 1;
+                                                            uint32_t bad_mask, uint32_t* __restrict__ poison,
+                                                            Msv1TileRec one_rec, Msv1AsyncInfo* __restrict__ host_info, uint32_t want,
+                                                            uint8_t* __restrict__ keep) {
+    constexpr bool INFO = MODE == 1 || MODE == 3;
     // one LDS arena: [tile bytes | composition tree | per-node entry]; the tree's space becomes the staging
     // window once every lane knows where the chain enters its slots; `enter` doubles as the look-back scratch
     constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = LOOKBACK_BATCH * 9 + 4;
@@ -538,8 +541,33 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     // stream loads do not wait for the record: under a saturated write stream every dependent global round trip
     // costs microseconds.
     const uint32_t t = tile0 + blockIdx.x;
-    const Msv1TileRec r = recs[t];
-    if (r.flags & MSV1_TILE_SKIP) return;
+    Msv1TileRec r = MODE == 3 ? one_rec : recs[t];             // MODE 3: one frame per launch, the record is a kernel argument
+    if (MODE == 3) r.k = blockIdx.x;
+    if (MODE != 3 && (r.flags & MSV1_TILE_SKIP)) return;
+    // MODE 3 bookkeeping (thread 0): `arrived` counts the workgroups whose findings are in info->flags, `finished` those
+    // that have written their last pixel; both run on from launch to launch (`want` = their value once this launch is
+    // through), so nothing has to be zeroed between frames.  The last workgroup to finish hands the report to the host
+    // (pinned memory) and clears the words for the next launch.
+    auto arrive = [&] { __threadfence(); atomicAdd(&info->arrived, 1u); };
+    auto finish = [&] {
+        __threadfence();
+        if (atomicAdd(&info->finished, 1u) + 1u == want) {
+            __threadfence();
+            host_info->flags = __hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_info->signif = __hip_atomic_load(&info->signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_info->fault = __hip_atomic_load(&info->fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&info->flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&info->signif, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&info->fault, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (MODE == 3) {
+        // (uniform over the launch: only earlier launches on this stream, or this one after its verdict, set the word)
+        if (__hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (threadIdx.x == 0) { arrive(); finish(); }
+            return;
+        }
+    }
     if (MODE == 2) {
         // (uniform) the scout handed this frame — or an earlier one still in flight — to the host path: nothing may be
         // written from here on (later frames reuse, as destination, buffers the re-run still needs to read), until the
@@ -571,8 +599,13 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         uint4 v = make_uint4(0, 0, 0, 0);
         const uint32_t at = tile_byte0 + o;
         if (at < data_end) {
-            v = *reinterpret_cast<const uint4*>(stream + at);  // buffers are padded
             const uint32_t nvalid = data_end - at;
+            if (MODE == 3 && nvalid < 16u) {                   // the caller's own memory: not a byte past the frame is touched
+                uint32_t wds[4] = {0, 0, 0, 0};
+                for (uint32_t i = 0; i < nvalid; ++i) wds[i >> 2] |= (uint32_t)stream[at + i] << (8u * (i & 3u));
+                v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+            } else
+                v = *reinterpret_cast<const uint4*>(stream + at);  // buffers are padded
             if (nvalid < 16u) {
                 auto keep = [&](uint32_t word, uint32_t first) -> uint32_t {
                     if (nvalid >= first + 4u) return word;
@@ -583,6 +616,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             }
         }
         *reinterpret_cast<uint4*>(lds_bytes + o) = v;
+        if (MODE == 3 && keep && o < TILE_BYTES && at < data_end) *reinterpret_cast<uint4*>(keep + at) = v;   // the frame's bytes stay in HBM
     }
     __syncthreads();
     const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
@@ -650,7 +684,10 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             }
             for (int spin = 0; !__syncthreads_and(have); ++spin) {
                 if (spin > LOOKBACK_SPIN_LIMIT) {              // uniform: every lane counts the same rounds
-                    if (tid == 0) atomicOr(fault, 1u);         // reported by jsp_staged_results / the call as an error
+                    if (tid == 0) {
+                        atomicOr(fault, 1u);                   // reported by jsp_staged_results / the call as an error
+                        if (MODE == 3) { arrive(); finish(); }
+                    }
                     return;
                 }
                 __builtin_amdgcn_s_sleep(8);
@@ -721,6 +758,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     __syncthreads();                                           // tree and enter are dead: the staging window takes their place
 
     uint32_t seen = 0;                                         // INFO: what this lane's codes on the chain were
+    bool arrived = false;                                      // MODE 3 (uniform): this workgroup has been through the verdict
     const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(r.prev);
     uint32_t* __restrict__ dstf = reinterpret_cast<uint32_t*>(r.dst);
     for (uint32_t w0 = tb0; w0 < span_end; w0 += FSTAGE) {     // more than one window only behind long skip runs
@@ -780,6 +818,30 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             }
         }
         if (MODE == 1) break;                                  // the scout only needed the replay of the first window
+        if (MODE == 3 && w0 == tb0) {
+            // ---- the frame's verdict: every tile's findings are in before any tile writes a pixel (all tiles of a
+            //      frame this small are resident together: the launcher only takes frames of a few hundred tiles) ----
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
+            if (lane == 0 && seen) atomicOr(&info->flags, seen);
+            __syncthreads();
+            if (tid == 0) {
+                arrive();
+                bool all = false;
+                for (int spin = 0; spin < VERDICT_SPIN_LIMIT; ++spin) {
+                    all = (int32_t)(__hip_atomic_load(&info->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
+                    if (all) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (!all) atomicOr(&info->flags, MSV1_ASYNC_STUCK);    // the host re-runs the frame synchronously
+                const uint32_t fl = __hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (all ? 0u : MSV1_ASYNC_STUCK);
+                s_entry = fl & (bad_mask | MSV1_ASYNC_STUCK);
+                if (s_entry) atomicOr(poison, 1u);             // ... and every later frame in flight with it
+            }
+            arrived = true;
+            __syncthreads();
+            if (s_entry) break;                                // vetoed: `dst` stays exactly as the caller left it
+        }
         __syncthreads();
         // ---- 5. reconstruction: lane = block, raster order; block coordinates advance by PWG blocks per round ----
         uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
@@ -818,10 +880,17 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         }
         if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
     }
-    if (INFO) {
+    if (MODE == 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
         if (lane == 0 && seen) atomicOr(&info->flags, seen);
+    }
+    if (MODE == 3) {
+        __syncthreads();                                       // every lane's stores and significance reports are out
+        if (tid == 0) {
+            if (!arrived) arrive();                            // a tile behind the last block: nothing to report, nothing to write
+            finish();
+        }
     }
 }
 
@@ -855,14 +924,17 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
                        hipStream_t stream, Msv1AsyncInfo* d_info, int insignificant_blocks, int mode, uint32_t bad_mask,
-                       uint32_t* d_poison) {
+                       uint32_t* d_poison, const Msv1TileRec* one_rec, Msv1AsyncInfo* h_info, uint32_t want, uint8_t* d_keep) {
     if (ntiles <= 0) return;
     const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
+    const Msv1TileRec rec = one_rec ? *one_rec : Msv1TileRec{};
 #define JSP_FUSED(BITS, MODE)                                                                                            \
     hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
-                       d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison)
-    if (geo.bits == 16) { if (mode == 1) JSP_FUSED(16, 1); else if (mode == 2) JSP_FUSED(16, 2); else JSP_FUSED(16, 0); }
-    else { if (mode == 1) JSP_FUSED(8, 1); else if (mode == 2) JSP_FUSED(8, 2); else JSP_FUSED(8, 0); }
+                       d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep)
+#define JSP_FUSED_MODES(BITS)                                                                                            \
+    switch (mode) { case 1: JSP_FUSED(BITS, 1); break; case 2: JSP_FUSED(BITS, 2); break; case 3: JSP_FUSED(BITS, 3); break; default: JSP_FUSED(BITS, 0); }
+    if (geo.bits == 16) { JSP_FUSED_MODES(16) } else { JSP_FUSED_MODES(8) }
+#undef JSP_FUSED_MODES
 #undef JSP_FUSED
 }
 

@@ -50,13 +50,15 @@ def main():
         host_buffers, misalign = rng.random() < 0.15, rng.random() < 0.15
         lines = int(rng.integers(0, 60))
         depth = int(rng.choice([1, 2, 4, 8]))
-        tag = f"{w}x{h} {bits}bit n={n} key_every={key_every} parse={mode} host={host_buffers} misalign={misalign} lines={lines} cfg={cfg}" + (f" depth={depth}" if mode == "async" else "")
+        form = str(rng.choice(["one_launch_dma", "one_launch", "two_launches"]))   # how the asynchronous path runs a frame
+        tag = f"{w}x{h} {bits}bit n={n} key_every={key_every} parse={mode} host={host_buffers} misalign={misalign} lines={lines} cfg={cfg}" + (f" depth={depth} form={form}" if mode == "async" else "")
         try:
             if mode == "async":
                 import test_async_gpu as A
                 from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit
                 gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
                 gpu.set_option("msv1_parse", "gpu")
+                gpu.set_option("msv1_async", form)
                 A.drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=bool(rng.random() < 0.5), lines=lines)
             else:
                 drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)

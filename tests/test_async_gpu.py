@@ -95,6 +95,21 @@ def test_msvideo1_async_matches_oracle(bits, size, pinned):
     drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, pinned=pinned)
 
 
+@pytest.mark.parametrize("form", ["one_launch_dma", "one_launch", "two_launches"])
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
+def test_msvideo1_async_forms_match_oracle(form, pinned):
+    """The three ways a frame runs on the asynchronous path (option msv1_async): one launch fed by the copy engine
+    (default), one launch reading the caller's pinned memory itself, scout + decode launches."""
+    w, h = 1920, 1080
+    frames, keys, _ = sg.msv1_clip(58, w, h, 8, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=5)
+    frames = list(frames)
+    frames[3] = frames[3][:len(frames[3]) - 7]                    # ends inside a code, at an odd length
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    gpu.set_option("msv1_async", form)
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, depth=4, pinned=pinned)
+
+
 @pytest.mark.parametrize("depth", [1, 2, 8])
 def test_msvideo1_async_hands_unsettled_frames_to_the_synchronous_path(depth):
     """Truncated streams, an all-skip frame, a skip count of zero ("the rest"), random bytes — in the middle of a clip,
