@@ -120,8 +120,9 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
  *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its
  *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame. */
-/*   "msv1_async" = "one_launch_dma" (default) | "one_launch" | "two_launches" : MSVideo1 with "msv1_parse" = "gpu", asynchronous
- *       calls only; frames of up to 128 parse tiles (2 MiB).  one_launch_dma: the copy engine brings the frame's bytes up on a
+/*   "msv1_async" = "auto" (default) | "one_launch_dma" | "one_launch" | "two_launches" : MSVideo1 with "msv1_parse" = "gpu",
+ *       asynchronous calls only; frames of up to 128 parse tiles (2 MiB).  auto: one_launch_dma while at most 3 codec instances
+ *       of the process use this path, one_launch beyond (many streams: the copy queues are the bottleneck).  one_launch_dma: the copy engine brings the frame's bytes up on a
  *       stream of its own (next to the previous frame's kernel), ONE launch parses, waits until every tile of the frame
  *       has reported what the host parser would have found, and rebuilds the frame — or leaves `dst` untouched for the
  *       synchronous re-run.  one_launch: the same launch reads the bytes from the caller's pinned memory itself (no copy

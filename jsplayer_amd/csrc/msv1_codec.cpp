@@ -4,6 +4,7 @@
 // built either by the sequential host parser (msv1_host.cpp) or on the GPU
 // (msv1_parse_kernels.hip, option "msv1_parse" = "gpu").
 #include <algorithm>
+#include <atomic>
 #include <unordered_set>
 
 #include "codec.h"
@@ -149,6 +150,10 @@ struct Msv1AsyncStaged : jsp_staged {
     }
 };
 
+// MSVideo1 codec instances of this process that have used the asynchronous one-launch path (see "msv1_async" = "auto")
+std::atomic<int> g_async_streams{0};
+constexpr int kDmaStreams = 3;
+
 struct Msv1Codec : jsp_codec {
     Msv1Geometry geo{};
     size_t size_of_just_skips = 0;
@@ -160,9 +165,13 @@ struct Msv1Codec : jsp_codec {
     int32_t palette[256];
     DeviceBuffer d_palette;
     bool opt_gpu_parse = false;
-    bool opt_async_merged = true, opt_async_dma = true;
+    bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
+    bool counted_async = false;   // this instance is in g_async_streams
     hipStream_t up_stream = nullptr;
-    ~Msv1Codec() override { if (up_stream) (void)hipStreamDestroy(up_stream); }
+    ~Msv1Codec() override {
+        if (up_stream) (void)hipStreamDestroy(up_stream);
+        if (counted_async) g_async_streams.fetch_sub(1);
+    }
     // block_changes is only maintained by the host parser; after frames parsed on the GPU it is
     // rebuilt on demand from the bytes of the last fully parsed frame
     bool block_changes_stale = false;
@@ -229,8 +238,9 @@ struct Msv1Codec : jsp_codec {
             if (std::strcmp(value, "host") == 0) { opt_gpu_parse = false; return 0; }
         }
         if (std::strcmp(key, "msv1_async") == 0) {   // frames of up to MSV1_MERGED_MAX_TILES tiles: one launch, or scout + decode
-            if (std::strcmp(value, "one_launch") == 0) { opt_async_merged = true; opt_async_dma = false; return 0; }
-            if (std::strcmp(value, "one_launch_dma") == 0) { opt_async_merged = true; opt_async_dma = true; return 0; }
+            if (std::strcmp(value, "auto") == 0) { opt_async_merged = true; opt_async_auto = true; return 0; }
+            if (std::strcmp(value, "one_launch") == 0) { opt_async_merged = true; opt_async_auto = false; opt_async_dma = false; return 0; }
+            if (std::strcmp(value, "one_launch_dma") == 0) { opt_async_merged = true; opt_async_auto = false; opt_async_dma = true; return 0; }
             if (std::strcmp(value, "two_launches") == 0) { opt_async_merged = false; return 0; }
         }
         return -1;
@@ -366,7 +376,10 @@ struct Msv1Codec : jsp_codec {
         if (st->merged) {
             fill(st->rec, 0);
             st->src_dev = up_dev;
-            st->dma = opt_async_dma;
+            if (!counted_async) { counted_async = true; g_async_streams.fetch_add(1); }
+            // a few streams: the copy engine works next to the kernels; many: its queues become the bottleneck (16 streams on one
+            // GPU: 57 against 68 Gpixels/s), the kernels then fetch the bytes themselves
+            st->dma = opt_async_auto ? g_async_streams.load() <= kDmaStreams : opt_async_dma;
             if (st->dma) {   // the copy engine brings the bytes up on a stream of its own, next to the previous frame's kernel
                 if (!up_stream) JSP_HIP(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
                 if (!st->uploaded) JSP_HIP(hipEventCreateWithFlags(&st->uploaded, hipEventDisableTiming));

@@ -595,28 +595,42 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     }
 
     // ---- 1. tile bytes -> LDS (zero past the end of the frame's data), lane tables, composition tree ----
-    for (uint32_t o = tid * 16u; o < (uint32_t)BYTES_W * 4u; o += PWG * 16u) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        const uint32_t at = tile_byte0 + o;
-        if (at < data_end) {
-            const uint32_t nvalid = data_end - at;
-            if (MODE == 3 && nvalid < 16u) {                   // the caller's own memory: not a byte past the frame is touched
-                uint32_t wds[4] = {0, 0, 0, 0};
-                for (uint32_t i = 0; i < nvalid; ++i) wds[i >> 2] |= (uint32_t)stream[at + i] << (8u * (i & 3u));
-                v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-            } else
-                v = *reinterpret_cast<const uint4*>(stream + at);  // buffers are padded
-            if (nvalid < 16u) {
-                auto keep = [&](uint32_t word, uint32_t first) -> uint32_t {
-                    if (nvalid >= first + 4u) return word;
-                    if (nvalid <= first) return 0u;
-                    return word & ((1u << (8u * (nvalid - first))) - 1u);
-                };
-                v.x = keep(v.x, 0); v.y = keep(v.y, 4); v.z = keep(v.z, 8); v.w = keep(v.w, 12);
-            }
+    // All of a lane's loads go out before the first is waited for: one after the other they were five memory round trips in
+    // a row, ~3 us each under a saturated write stream — the longest phase of a tile.
+    {
+        constexpr int NLOAD = (BYTES_W * 4 + PWG * 16 - 1) / (PWG * 16);
+        uint4 v[NLOAD];
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const uint32_t o = tid * 16u + (uint32_t)q * (PWG * 16u), at = tile_byte0 + o;
+            v[q] = make_uint4(0, 0, 0, 0);
+            // (MODE 3 reads the caller's own memory: the frame's last, partial 16 bytes are fetched byte by byte below)
+            if (o < (uint32_t)BYTES_W * 4u && at < data_end && !(MODE == 3 && data_end - at < 16u))
+                v[q] = *reinterpret_cast<const uint4*>(stream + at);   // buffers are padded
         }
-        *reinterpret_cast<uint4*>(lds_bytes + o) = v;
-        if (MODE == 3 && keep && o < TILE_BYTES && at < data_end) *reinterpret_cast<uint4*>(keep + at) = v;   // the frame's bytes stay in HBM
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const uint32_t o = tid * 16u + (uint32_t)q * (PWG * 16u), at = tile_byte0 + o;
+            if (o >= (uint32_t)BYTES_W * 4u) continue;
+            if (at < data_end) {
+                const uint32_t nvalid = data_end - at;
+                if (nvalid < 16u) {
+                    if (MODE == 3) {
+                        uint32_t wds[4] = {0, 0, 0, 0};
+                        for (uint32_t i = 0; i < nvalid; ++i) wds[i >> 2] |= (uint32_t)stream[at + i] << (8u * (i & 3u));
+                        v[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+                    }
+                    auto keep_bytes = [&](uint32_t word, uint32_t first) -> uint32_t {
+                        if (nvalid >= first + 4u) return word;
+                        if (nvalid <= first) return 0u;
+                        return word & ((1u << (8u * (nvalid - first))) - 1u);
+                    };
+                    v[q].x = keep_bytes(v[q].x, 0); v[q].y = keep_bytes(v[q].y, 4); v[q].z = keep_bytes(v[q].z, 8); v[q].w = keep_bytes(v[q].w, 12);
+                }
+            }
+            *reinterpret_cast<uint4*>(lds_bytes + o) = v[q];
+            if (MODE == 3 && keep && o < TILE_BYTES && at < data_end) *reinterpret_cast<uint4*>(keep + at) = v[q];   // the frame's bytes stay in HBM
+        }
     }
     __syncthreads();
     const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
@@ -844,7 +858,44 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         }
         __syncthreads();
         // ---- 5. reconstruction: lane = block, raster order; block coordinates advance by PWG blocks per round ----
+        // 5a. skipped blocks are copies from the previous frame: U blocks per lane at a time, all their row loads out before
+        //     the first store (one at a time, every block waits a memory round trip of its own: an inter frame of a single
+        //     stream has a dozen workgroups on the whole GPU and nothing else to hide it behind).  The batch form keeps U = 1:
+        //     its launches fill the GPU, and its register budget is what the headline path runs on.
+        {
+            constexpr int U = MODE == 0 ? 1 : 4;
+            uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
+            for (uint32_t i = tid; i < wn; i += PWG * (uint32_t)U) {
+                uint32_t di[U];
+                bool sk[U], any = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t idx = i + (uint32_t)u * PWG;
+                    sk[u] = idx < wn && stage[idx] == F_SKIP;
+                    any |= sk[u];
+                    di[u] = (by * (uint32_t)X + bx) * 4u;
+                    bx += PWG;
+                    while (bx >= (uint32_t)nbx) { bx -= (uint32_t)nbx; ++by; }
+                }
+                if (!any) continue;
+                fu32x4 q[U][4];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (sk[u]) {
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) q[u][y] = *(fcgu32x4*)(prev + di[u] + (size_t)y * X);
+                    }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (sk[u]) {
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) __builtin_nontemporal_store(q[u][y], (fgu32x4*)(dstf + di[u] + (size_t)y * X));
+                    }
+            }
+        }
+        // 5b. coded blocks
         uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
+        bool compare = r.cmp_row_lo != 0xFFFFFFFFu;                    // (wave-uniform) stage-2 significance still open
         for (uint32_t i = tid; i < wn; i += PWG) {
             const uint32_t o = stage[i];
             const uint32_t di = (by * (uint32_t)X + bx) * 4u;          // pixel index: a frame has fewer than 2^28 pixels
@@ -852,31 +903,35 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             const uint32_t by_now = by;
             bx += PWG;
             while (bx >= (uint32_t)nbx) { bx -= (uint32_t)nbx; ++by; }
-            if (o == F_SKIP) {
+            const bool coded = o != F_SKIP;
+            fu32x4 q[4];
+            constexpr bool EARLY = MODE != 0;                          // (the batch form keeps its register budget: loads after the stores)
+            if (EARLY && compare && coded) {                           // the previous frame's rows travel while the block is decoded
                 const uint32_t* __restrict__ pv = prev + di;
 #pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    const fu32x4 q = *(fcgu32x4*)(pv + (size_t)y * X);
-                    __builtin_nontemporal_store(q, (fgu32x4*)(dst + (size_t)y * X));
-                }
-                continue;
+                for (int y = 0; y < 4; ++y) q[y] = *(fcgu32x4*)(pv + (size_t)y * X);
             }
-            uint32_t px[16];
-            decode_block<BITS>(lds_bytes + o, data_end - (tile_byte0 + o), s_pal, px);
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-                __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
-            if (r.cmp_row_lo != 0xFFFFFFFFu) {                  // stage-2 significance, MSVideo1.hx:195-204
-                const uint32_t* __restrict__ pv = prev + di;
-                bool diff = false;
+            bool diff = false;
+            if (coded) {
+                uint32_t px[16];
+                decode_block<BITS>(lds_bytes + o, data_end - (tile_byte0 + o), s_pal, px);
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
-                    if (by_now * 4u + y >= r.cmp_row_lo) {
-                        const fu32x4 q = *(fcgu32x4*)(pv + (size_t)y * X);
-                        diff |= (q.x != px[y * 4]) | (q.y != px[y * 4 + 1]) | (q.z != px[y * 4 + 2]) | (q.w != px[y * 4 + 3]);
+                    __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
+                if (compare) {                                         // stage-2 significance, MSVideo1.hx:195-204
+                    if (!EARLY) {
+                        const uint32_t* __restrict__ pv = prev + di;
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) q[y] = *(fcgu32x4*)(pv + (size_t)y * X);
                     }
-                if (diff && __hip_atomic_load(r.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(r.signif, 1u);
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        if (by_now * 4u + y >= r.cmp_row_lo)
+                            diff |= (q[y].x != px[y * 4]) | (q[y].y != px[y * 4 + 1]) | (q[y].z != px[y * 4 + 2]) | (q[y].w != px[y * 4 + 3]);
+                    if (diff && __hip_atomic_load(r.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(r.signif, 1u);
+                }
             }
+            if (compare && __any(diff)) compare = false;               // one differing pixel settles it: no more rows of the previous frame
         }
         if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
     }

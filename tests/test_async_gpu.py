@@ -95,7 +95,7 @@ def test_msvideo1_async_matches_oracle(bits, size, pinned):
     drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, pinned=pinned)
 
 
-@pytest.mark.parametrize("form", ["one_launch_dma", "one_launch", "two_launches"])
+@pytest.mark.parametrize("form", ["auto", "one_launch_dma", "one_launch", "two_launches"])
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
 def test_msvideo1_async_forms_match_oracle(form, pinned):
     """The three ways a frame runs on the asynchronous path (option msv1_async): one launch fed by the copy engine
