@@ -117,6 +117,8 @@ struct Msv1AsyncInfo {
     uint32_t finished; //         on from launch to launch (see `want`)
     uint32_t pad[3];
 };
+// mode 4 (batch form): nothing is rebuilt; every tile writes its blocks' entries of the frame's descriptor table (the record's
+// `dst` points at it) — the on-GPU descriptor parse in ONE launch, for the batches whose frames depend on each other.
 // mode 3 (one frame per launch, at most MSV1_MERGED_MAX_TILES tiles): scout and decode in ONE launch — every tile parses
 // and reports, waits until all `ntiles` reports are in (`want` = the value of d_info->arrived / finished once this launch is
 // through), and only then writes, or does not.  All tiles share `*one_rec` (k = the tile's index); the last workgroup copies

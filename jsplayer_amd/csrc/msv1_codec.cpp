@@ -35,10 +35,11 @@ struct Msv1Staged : jsp_staged {
     DeviceBuffer d_pframes, d_tile_frame, d_tile_tab, d_tile_entry, d_tile_block0, d_info;
     PinnedBuffer h_pframes, h_tile_frame, h_info;
     // fused parse + reconstruction (msv1_fused_kernel): published tile tables, ticket / fault words
-    DeviceBuffer d_agg, d_sync, d_recs;
-    PinnedBuffer h_fault, h_recs;
+    DeviceBuffer d_agg, d_sync, d_recs, d_recs_emit;
+    PinnedBuffer h_fault, h_recs, h_recs_emit;
     uint32_t epoch = 0;
     bool needs_desc = false;   // some launch reads the descriptor table the parse kernels build
+    std::vector<uint32_t> scrub;   // (tests: option "msv1_scrub_tables") frames whose table a replay rewrites: poisoned before it does
     bool any_fused = false;
 
     void launch_parse(hipStream_t stream) {
@@ -54,7 +55,15 @@ struct Msv1Staged : jsp_staged {
         // A replay re-executes the whole device pipeline: with the on-GPU parse that includes the
         // parse kernels, so a staged batch can be timed from raw stream bytes.  (The first decode
         // uses the tables the staging pass left behind.)
-        if (gpu_parse && decoded && needs_desc) launch_parse(stream);
+        if (gpu_parse && decoded && needs_desc)   // one launch: the fused kernel's parse, writing block tables instead of pixels
+        {
+            for (uint32_t i : scrub)
+                JSP_HIP(hipMemsetAsync(static_cast<uint32_t*>(d_desc.p) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE,
+                                       sizeof(uint32_t) * (size_t)geo.nblocks, stream));
+            msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
+                              static_cast<unsigned long long*>(d_agg.p), ++epoch, 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
+                              nullptr, 0, 4);
+        }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
         for (const Group& g : groups) {
@@ -79,14 +88,14 @@ struct Msv1Staged : jsp_staged {
         if (need_signif)
             JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
                                    stream));
-        if (any_fused)
+        if (any_fused || needs_desc)
             JSP_HIP(hipMemcpyAsync(h_fault.p, d_sync.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         decoded = true;
     }
     void after_sync() override {
-        if (any_fused && *static_cast<const uint32_t*>(h_fault.p)) {   // a tile gave up waiting for its predecessors' tables
+        if ((any_fused || needs_desc) && *static_cast<const uint32_t*>(h_fault.p)) {   // a tile gave up waiting for its predecessors' tables
             for (const Group& g : groups)
-                if (g.fused) std::fill(status.begin() + g.first, status.begin() + g.first + g.count, (int)JSP_ERROR_OCCURED);
+                if (g.fused || needs_desc) std::fill(status.begin() + g.first, status.begin() + g.first + g.count, (int)JSP_ERROR_OCCURED);
             char buf[96];
             std::snprintf(buf, sizeof buf, "msv1_fused_kernel: look-back timed out (fault word %u)", *static_cast<const uint32_t*>(h_fault.p));
             why = buf;
@@ -165,6 +174,7 @@ struct Msv1Codec : jsp_codec {
     int32_t palette[256];
     DeviceBuffer d_palette;
     bool opt_gpu_parse = false;
+    bool opt_scrub_tables = false;
     bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
     bool counted_async = false;   // this instance is in g_async_streams
     hipStream_t up_stream = nullptr;
@@ -236,6 +246,10 @@ struct Msv1Codec : jsp_codec {
         if (std::strcmp(key, "msv1_parse") == 0) {
             if (std::strcmp(value, "gpu") == 0) { opt_gpu_parse = true; return 0; }
             if (std::strcmp(value, "host") == 0) { opt_gpu_parse = false; return 0; }
+        }
+        if (std::strcmp(key, "msv1_scrub_tables") == 0) {   // tests: a replay must rebuild every block table it reads
+            opt_scrub_tables = std::strcmp(value, "1") == 0;
+            return 0;
         }
         if (std::strcmp(key, "msv1_async") == 0) {   // frames of up to MSV1_MERGED_MAX_TILES tiles: one launch, or scout + decode
             if (std::strcmp(value, "auto") == 0) { opt_async_merged = true; opt_async_auto = true; return 0; }
@@ -712,13 +726,13 @@ struct Msv1Codec : jsp_codec {
                 }
                 if (g.edge_compare) st->note_kernel("msv1_edge_compare_kernel");
             }
-            if (st->needs_desc) {
-                moved += 2 * st->info.stream_bytes + sizeof(uint32_t) * (uint64_t)geo.nblocks * nf;
-                st->kernels = "msv1_parse_tiles + msv1_parse_chain + msv1_parse_emit" + (st->kernels.empty() ? std::string() : " + " + st->kernels);
+            if (st->needs_desc) {   // (a replay: msv1_fused_kernel in its descriptor form reads the stream once and writes the tables)
+                moved += st->info.stream_bytes + sizeof(uint32_t) * (uint64_t)geo.nblocks * nf;
+                if (!st->any_fused) st->kernels = "msv1_fused_kernel" + (st->kernels.empty() ? std::string() : " + " + st->kernels);
             }
             st->info.moved_bytes = moved;
-            st->info.kernel_launches = st->groups.size() + (st->needs_desc ? 3 : 0);
-            if (st->any_fused) {
+            st->info.kernel_launches = st->groups.size() + (st->needs_desc ? 1 : 0);
+            if (st->any_fused || st->needs_desc) {
                 st->d_agg.reserve(sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1));
                 st->d_sync.reserve(2 * sizeof(uint32_t));
                 st->h_fault.reserve(sizeof(uint32_t));
@@ -746,6 +760,29 @@ struct Msv1Codec : jsp_codec {
                         r.pad = 0;
                     }
                 JSP_HIP(hipMemcpyAsync(st->d_recs.p, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
+                if (st->needs_desc) {   // the same records for the descriptor form: `dst` = the frame's block table; frames whose
+                                        // table nobody reads (fused groups) or that came from the host parser are skipped
+                    st->h_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
+                    st->d_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
+                    auto* er = static_cast<Msv1TileRec*>(st->h_recs_emit.p);
+                    std::memcpy(er, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles);
+                    std::vector<uint8_t> in_fused(nf, 0);
+                    for (const auto& g : st->groups)
+                        if (g.fused) std::fill(in_fused.begin() + g.first, in_fused.begin() + g.first + g.count, 1);
+                    for (int i = 0; i < nf; ++i)
+                        for (uint32_t k = 0; k < h_pf[i].ntiles; ++k) {
+                            Msv1TileRec& r = er[h_pf[i].first_tile + k];
+                            r.dst = reinterpret_cast<int32_t*>(static_cast<uint32_t*>(st->d_desc.p) + (size_t)i * nblk);
+                            r.prev = nullptr;
+                            r.cmp_row_lo = 0xFFFFFFFFu;
+                            r.flags = (h_pf[i].host_parsed || in_fused[i]) ? MSV1_TILE_SKIP : 0u;
+                        }
+                    JSP_HIP(hipMemcpyAsync(st->d_recs_emit.p, er, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
+                    st->scrub.clear();
+                    if (opt_scrub_tables)
+                        for (int i = 0; i < nf; ++i)
+                            if (!h_pf[i].host_parsed && !in_fused[i]) st->scrub.push_back((uint32_t)i);
+                }
                 // published tile tables carry the launch epoch (first launch: 1), so stale words must read as epoch 0
                 JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1), stream));
                 JSP_HIP(hipMemsetAsync(st->d_sync.p, 0, 2 * sizeof(uint32_t), stream));   // the fault word

@@ -143,11 +143,19 @@ __device__ __forceinline__ void lane_table_fast(const uint32_t (&w)[17], uint32_
 // Stage a tile through LDS and hand every lane its 17 dwords.
 __device__ __forceinline__ void load_lane_bytes(const uint8_t* __restrict__ stream, uint32_t tile_byte0, uint32_t end,
                                                 uint32_t* lds_bytes /* TSLOTS*2/4 + 4 dwords */, uint32_t (&w)[17]) {
-    const uint32_t tile_bytes = TSLOTS * 2;
-    for (uint32_t o = threadIdx.x * 16u; o < tile_bytes + 16u; o += PWG * 16u) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (tile_byte0 + o < end) v = *reinterpret_cast<const uint4*>(stream + tile_byte0 + o);  // buffers are padded
-        *reinterpret_cast<uint4*>(lds_bytes + o / 4) = v;
+    constexpr uint32_t tile_bytes = TSLOTS * 2;
+    constexpr int NLOAD = (tile_bytes + 16u + PWG * 16u - 1u) / (PWG * 16u);
+    uint4 v[NLOAD];   // every load is out before the first is waited for (one by one: NLOAD memory round trips in a row)
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) {
+        const uint32_t o = threadIdx.x * 16u + (uint32_t)q * (PWG * 16u);
+        v[q] = make_uint4(0, 0, 0, 0);
+        if (o < tile_bytes + 16u && tile_byte0 + o < end) v[q] = *reinterpret_cast<const uint4*>(stream + tile_byte0 + o);  // buffers are padded
+    }
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) {
+        const uint32_t o = threadIdx.x * 16u + (uint32_t)q * (PWG * 16u);
+        if (o < tile_bytes + 16u) *reinterpret_cast<uint4*>(lds_bytes + o / 4) = v[q];
     }
     __syncthreads();
     const uint32_t* mine = lds_bytes + threadIdx.x * (LSLOTS * 2 / 4);
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
     uint32_t* stage = arena;
     const uint32_t t = blockIdx.x;
     const uint32_t f = tile_frame[t];
+    const uint32_t te = tile_entry[t], tb0 = tile_block0[t];   // asked for now: needed after the up-sweep, a round trip away
     const Msv1ParseFrame fr = frames[f];
     if (fr.host_parsed) return;
     const uint32_t tile_byte0 = fr.beg + (t - fr.first_tile) * (TSLOTS * 2);
@@ -253,8 +262,7 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
     }
     // down-sweep of ONE value per node: where the real chain enters the node and with which block.
     // packed as entry | block << 4 (block saturates at BSAT like everything else)
-    const uint32_t tb0 = tile_block0[t];
-    if (threadIdx.x == 0) enter[tree_row(8)] = pack(tile_entry[t], tb0);
+    if (threadIdx.x == 0) enter[tree_row(8)] = pack(te, tb0);
     __syncthreads();
     for (int l = 8; l >= 1; --l) {
         const int nodes = PWG >> l, hi = tree_row(l), lo = tree_row(l - 1);
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
     }
     const uint32_t mine = enter[threadIdx.x];
     // blocks this tile is responsible for: [tb0, span_end)
-    const uint32_t whole = add_blocks(tree[tree_row(8)][tile_entry[t]], tb0) >> 4;
+    const uint32_t whole = add_blocks(tree[tree_row(8)][te], tb0) >> 4;
     const uint32_t span_end = whole < nblocks ? whole : nblocks;
     const uint32_t span = span_end > tb0 ? span_end - tb0 : 0u;
     const bool staged = span <= (uint32_t)STAGE;
@@ -857,6 +865,16 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             if (s_entry) break;                                // vetoed: `dst` stays exactly as the caller left it
         }
         __syncthreads();
+        if (MODE == 4) {
+            // ---- 5'. the descriptor form: the window goes out as the frame's block table (byte offset of each block's code
+            //      in the stream buffer, or "copy from the previous frame"), which msv1_blocks_temporal_kernel /
+            //      msv1_blocks_kernel read — what msv1_parse_tiles + _chain + _emit build in three launches ----
+            uint32_t* __restrict__ table = dstf;               // (the record's `dst` is the frame's table)
+            for (uint32_t i = tid; i < wn; i += PWG) {
+                const uint32_t o = stage[i];
+                table[w0 + i] = o == F_SKIP ? MSV1_DESC_SKIP : tile_byte0 + o;
+            }
+        } else {
         // ---- 5. reconstruction: lane = block, raster order; block coordinates advance by PWG blocks per round ----
         // 5a. skipped blocks are copies from the previous frame: U blocks per lane at a time, all their row loads out before
         //     the first store (one at a time, every block waits a memory round trip of its own: an inter frame of a single
@@ -933,6 +951,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             }
             if (compare && __any(diff)) compare = false;               // one differing pixel settles it: no more rows of the previous frame
         }
+        }
         if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
     }
     if (MODE == 1) {
@@ -987,7 +1006,7 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
     hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
                        d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep)
 #define JSP_FUSED_MODES(BITS)                                                                                            \
-    switch (mode) { case 1: JSP_FUSED(BITS, 1); break; case 2: JSP_FUSED(BITS, 2); break; case 3: JSP_FUSED(BITS, 3); break; default: JSP_FUSED(BITS, 0); }
+    switch (mode) { case 1: JSP_FUSED(BITS, 1); break; case 2: JSP_FUSED(BITS, 2); break; case 3: JSP_FUSED(BITS, 3); break; case 4: JSP_FUSED(BITS, 4); break; default: JSP_FUSED(BITS, 0); }
     if (geo.bits == 16) { JSP_FUSED_MODES(16) } else { JSP_FUSED_MODES(8) }
 #undef JSP_FUSED_MODES
 #undef JSP_FUSED

@@ -99,8 +99,8 @@ def build_clips(name: str, rank: int = 0, frames: Optional[int] = None) -> List[
     return [make(spec, rank, c) for c in range(spec.get("clips", 1))]
 
 
-def make_codec(name: str, palette: Optional[bytes] = None, device: int = 0):
-    """A product codec instance configured as bench.py runs workload `name`."""
+def make_codec(name: str, palette: Optional[bytes] = None, device: int = 0, options: Optional[dict] = None):
+    """A product codec instance configured as bench.py runs workload `name` (`options`: further set_option pairs, tests)."""
     from . import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
     spec = WORKLOADS[name]
     if spec["codec"] == "sp":
@@ -110,6 +110,8 @@ def make_codec(name: str, palette: Optional[bytes] = None, device: int = 0):
     codec.Preinit(36)
     if spec.get("parse"):
         codec.set_option("msv1_parse", spec["parse"])
+    for key, value in (options or {}).items():
+        codec.set_option(key, value)
     return codec
 
 
@@ -137,13 +139,13 @@ class StagedWorkload:
     destination frame buffers and a staged batch (inter-mode clips: the key frame is decoded up front into
     `firsts[i]`, the batch is the inter frames)."""
 
-    def __init__(self, name: str, clips: List[Clip], device: int = 0, hip_stream: Optional[int] = None):
+    def __init__(self, name: str, clips: List[Clip], device: int = 0, hip_stream: Optional[int] = None, options: Optional[dict] = None):
         import torch
         spec = WORKLOADS[name]
         self.name, self.clips, self.inter = name, clips, spec.get("mode") == "inter"
         self.codecs, self.staged, self.dsts, self.firsts = [], [], [], []
         for clip in clips:
-            codec = make_codec(name, clip.palette, device=device)
+            codec = make_codec(name, clip.palette, device=device, options=options)
             if hip_stream:
                 codec.set_stream(hip_stream)
             frames, keys, first = clip.frames, clip.keys, None
