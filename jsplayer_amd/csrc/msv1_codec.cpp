@@ -73,7 +73,7 @@ struct Msv1Staged : jsp_staged {
                 const Msv1ParseFrame& last = pf[g.first + g.count - 1];
                 msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs.p), d_palette,
                                   static_cast<unsigned long long*>(d_agg.p), ++epoch, tile0, (int)(last.first_tile + last.ntiles - tile0),
-                                  static_cast<uint32_t*>(d_sync.p), stream);
+                                  static_cast<uint32_t*>(d_sync.p), stream, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);
             } else if (g.temporal)
                 msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
                                             static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette,
@@ -90,9 +90,29 @@ struct Msv1Staged : jsp_staged {
                                    stream));
         if (any_fused || needs_desc)
             JSP_HIP(hipMemcpyAsync(h_fault.p, d_sync.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+#ifdef JSP_FUSED_CLOCKS
+        ++clock_launches;
+#endif
         decoded = true;
     }
+#ifdef JSP_FUSED_CLOCKS
+    int clock_launches = 0;
+#endif
     void after_sync() override {
+#ifdef JSP_FUSED_CLOCKS
+        if (clock_launches) {   // lab build: per-phase cycle sums since the last sync (see JSP_CLOCK), printed and cleared
+            std::vector<unsigned long long> c((size_t)ntiles * 8);
+            unsigned long long* dev = static_cast<unsigned long long*>(d_agg.p) + (size_t)ntiles * 9;
+            JSP_HIP(hipMemcpy(c.data(), dev, c.size() * 8, hipMemcpyDeviceToHost));
+            JSP_HIP(hipMemset(dev, 0, c.size() * 8));
+            unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < c.size(); ++i) h[i & 7] += c[i];
+            const unsigned long long n = (unsigned long long)ntiles * clock_launches;
+            std::fprintf(stderr, "fused clocks per tile (cycles; %d tiles x %d launches): load %llu | tables+trees %llu | look-back %llu | down %llu | replay %llu | decode %llu\n",
+                         ntiles, clock_launches, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+            clock_launches = 0;
+        }
+#endif
         if ((any_fused || needs_desc) && *static_cast<const uint32_t*>(h_fault.p)) {   // a tile gave up waiting for its predecessors' tables
             for (const Group& g : groups)
                 if (g.fused || needs_desc) std::fill(status.begin() + g.first, status.begin() + g.first + g.count, (int)JSP_ERROR_OCCURED);
@@ -733,8 +753,8 @@ struct Msv1Codec : jsp_codec {
             st->info.moved_bytes = moved;
             st->info.kernel_launches = st->groups.size() + (st->needs_desc ? 1 : 0);
             if (st->any_fused || st->needs_desc) {
-                st->d_agg.reserve(sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1));
-                st->d_sync.reserve(2 * sizeof(uint32_t));
+                st->d_agg.reserve(sizeof(unsigned long long) * (9 + 8) * (size_t)std::max(st->ntiles, 1));   // (+ 8 per tile: the lab build's phase clocks)
+                st->d_sync.reserve(2 * sizeof(uint32_t) + 64);   // (+ room for the lab build's phase clocks)
                 st->h_fault.reserve(sizeof(uint32_t));
                 *static_cast<uint32_t*>(st->h_fault.p) = 0;
                 st->epoch = 0;
@@ -784,8 +804,8 @@ struct Msv1Codec : jsp_codec {
                             if (!h_pf[i].host_parsed && !in_fused[i]) st->scrub.push_back((uint32_t)i);
                 }
                 // published tile tables carry the launch epoch (first launch: 1), so stale words must read as epoch 0
-                JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, sizeof(unsigned long long) * 9 * (size_t)std::max(st->ntiles, 1), stream));
-                JSP_HIP(hipMemsetAsync(st->d_sync.p, 0, 2 * sizeof(uint32_t), stream));   // the fault word
+                JSP_HIP(hipMemsetAsync(st->d_agg.p, 0, sizeof(unsigned long long) * (9 + 8) * (size_t)std::max(st->ntiles, 1), stream));
+                JSP_HIP(hipMemsetAsync(st->d_sync.p, 0, 2 * sizeof(uint32_t) + 64, stream));   // the fault word
             }
         }
         st->info.host_stage_ms = now_ms() - t0 - gpu_parse_ms;

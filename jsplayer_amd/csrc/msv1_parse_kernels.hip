@@ -517,6 +517,14 @@ __device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&
 //   MODE 2: the decode proper, which returns at once when the scout found one of the conditions in `bad_mask` — such a
 //           frame is re-done by the synchronous path, and must find `dst` exactly as the caller left it.
 // MODE 0 is the batch form (no report).
+#ifdef JSP_FUSED_CLOCKS   // lab build: thread 0 of every tile adds the cycles of each phase to its own counters behind the tile tables (`want` = tiles of the batch)
+#define JSP_CLOCK(k) do { if (MODE == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    agg[(size_t)want * 9u + (size_t)(tile0 + blockIdx.x) * 8u + (k)] += now_ - clk_; clk_ = now_; } } while (0)
+#elif defined(JSP_FUSED_STOP)   // lab build: the batch form returns after phase JSP_FUSED_STOP (instruction counts per phase, by subtraction)
+#define JSP_CLOCK(k) do { if (MODE == 0 && (k) == JSP_FUSED_STOP) return; } while (0)
+#else
+#define JSP_CLOCK(k) do { } while (0)
+#endif
 template <int BITS, int MODE>
 __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
                                                             const Msv1TileRec* __restrict__ recs,
@@ -548,6 +556,9 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     // record (a uniform, scalar load); its bytes sit at t * TILE_BYTES (frames start on tile boundaries), so the
     // stream loads do not wait for the record: under a saturated write stream every dependent global round trip
     // costs microseconds.
+#ifdef JSP_FUSED_CLOCKS
+    unsigned long long clk_ = __builtin_readcyclecounter();
+#endif
     const uint32_t t = tile0 + blockIdx.x;
     Msv1TileRec r = MODE == 3 ? one_rec : recs[t];             // MODE 3: one frame per launch, the record is a kernel argument
     if (MODE == 3) r.k = blockIdx.x;
@@ -641,6 +652,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         }
     }
     __syncthreads();
+    JSP_CLOCK(0);   // bytes in LDS
     const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
     const bool inside = tile_byte0 + TILE_BYTES + 4u <= r.frame_end;   // every tile of a frame but the last: no end-of-data tests
     LaneMasks masks{0, 0, 0};
@@ -678,6 +690,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         wave_sync();
     }
     __syncthreads();                                           // the four wave tables (level 6) are in place
+    JSP_CLOCK(1);   // lane tables + wave trees
     // the tile's table = the four wave tables chained, one entry slot per lane
     if (tid < 9) {
         uint32_t v = tree[tree_row(6)][tid];
@@ -696,12 +709,17 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             const bool last = j0 + LOOKBACK_BATCH >= k;        // the batch whose loads are already in flight
             const uint32_t b0 = last ? look0 : j0, nj = last ? nlook : (uint32_t)LOOKBACK_BATCH;
             const unsigned long long* src = agg + (size_t)(r.first_tile + b0) * 9u;
+            // (the loads of a round all go out before any is looked at: checked one by one, each cost a round trip of its own)
             unsigned long long v[3];
             bool have = true;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
                 v[q] = last ? lv[q] : (wanted ? __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
                 have &= !wanted || (uint32_t)(v[q] >> 32) == epoch;
             }
             for (int spin = 0; !__syncthreads_and(have); ++spin) {
@@ -714,11 +732,15 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                 }
                 __builtin_amdgcn_s_sleep(8);
                 have = true;
+                bool stale[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) stale[q] = (uint32_t)(tid + q * PWG) < nj * 9u && (uint32_t)(v[q] >> 32) != epoch;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (stale[q]) v[q] = __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
-                    if (wanted && (uint32_t)(v[q] >> 32) != epoch)
-                        v[q] = __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     have &= !wanted || (uint32_t)(v[q] >> 32) == epoch;
                 }
             }
@@ -756,6 +778,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     __syncthreads();
     // ---- 4. down-sweep of ONE value per node: where the chain enters the node and with which block ----------
     const uint32_t entry = s_entry;
+    JSP_CLOCK(2);   // publish + look-back
     const uint32_t tb0 = entry >> 4;
     if (lane == 0) {                                           // where the chain enters this wave
         uint32_t v = entry;
@@ -778,6 +801,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     const uint32_t span_end = whole < nblocks ? whole : nblocks;
     if (INFO && tid == 0 && k + 1u == r.ntiles && whole < nblocks) atomicOr(&info->flags, MSV1_ASYNC_SHORT);   // the stream ends early
     __syncthreads();                                           // tree and enter are dead: the staging window takes their place
+    JSP_CLOCK(3);   // down-sweep
 
     uint32_t seen = 0;                                         // INFO: what this lane's codes on the chain were
     bool arrived = false;                                      // MODE 3 (uniform): this workgroup has been through the verdict
@@ -865,6 +889,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             if (s_entry) break;                                // vetoed: `dst` stays exactly as the caller left it
         }
         __syncthreads();
+        JSP_CLOCK(4);   // replay into the staging window
         if (MODE == 4) {
             // ---- 5'. the descriptor form: the window goes out as the frame's block table (byte offset of each block's code
             //      in the stream buffer, or "copy from the previous frame"), which msv1_blocks_temporal_kernel /
@@ -933,9 +958,13 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             if (coded) {
                 uint32_t px[16];
                 decode_block<BITS>(lds_bytes + o, data_end - (tile_byte0 + o), s_pal, px);
+#ifdef JSP_FUSED_NOSTORE   // lab build: the decode runs, its rows are not written (parse + decode time without the store stream)
+                if ((px[0] ^ px[5] ^ px[10] ^ px[15]) == 0xDEADBEEFu) atomicOr(fault, 2u);
+#else
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
                     __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
+#endif
                 if (compare) {                                         // stage-2 significance, MSVideo1.hx:195-204
                     if (!EARLY) {
                         const uint32_t* __restrict__ pv = prev + di;
@@ -954,6 +983,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         }
         if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
     }
+    JSP_CLOCK(5);   // decode + store issue
     if (MODE == 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, o);
