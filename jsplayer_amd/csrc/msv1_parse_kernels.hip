@@ -656,7 +656,11 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
     const bool inside = tile_byte0 + TILE_BYTES + 4u <= r.frame_end;   // every tile of a frame but the last: no end-of-data tests
     LaneMasks masks{0, 0, 0};
-    bool fast = false;        // (wave-uniform) the mask form serves: 16-bit, inside the frame, no skip code in this wave's slots
+    // (wave-uniform) the mask form serves: 16-bit, inside the frame, no skip-LIKE word among this wave's 2048.  That holds for
+    // flat content (solid blocks, few colour pairs: what screens mostly show); in frames of random colours one word in a
+    // hundred has a high byte of 0x84..0x87 and every wave takes the general form — the M1 bench mix is such a frame.
+    // A skip-aware mask form was built and measured (27 % fewer VALU instructions, 6 % slower: profiles/r02_fused_notes.txt).
+    bool fast = false;
     {
         uint32_t w[17], tab[9];
         const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
