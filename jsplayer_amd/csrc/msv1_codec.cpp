@@ -124,10 +124,12 @@ struct Msv1Staged : jsp_staged {
     }
 };
 
-// One frame on the asynchronous path (jsp_decompress_*_async) with the on-GPU parse: the raw bytes, one record per
-// tile and a zeroed report go up, a scout launch and the fused launch parse and rebuild the frame, the report comes back.  Nothing here
-// waits for the GPU; what the host could not know (stage-1 / stage-2 significance, a stream the host parser has to
-// settle) is read from the report once the frame's event has fired (Msv1Codec::async_finish).
+// One frame on the asynchronous path (jsp_decompress_*_async) with the on-GPU parse.  Nothing here waits for the GPU; what the
+// host could not know (stage-1 / stage-2 significance, a stream the host parser has to settle) is read from the frame's
+// report once its event has fired (Msv1Codec::async_finish).  Frames of up to MSV1_MERGED_MAX_TILES tiles take ONE launch
+// (msv1_fused_kernel mode 3: parse, frame-wide verdict, then the pixels or nothing; the record is a kernel argument, the
+// report lands in pinned memory); larger ones, or "msv1_async" = "two_launches", a scout launch and a decode launch it may
+// veto, with per-tile records and the report copied up and down.
 struct Msv1AsyncStaged : jsp_staged {
     Msv1AsyncStaged() { verdict_pending = true; }
     Msv1Geometry geo{};

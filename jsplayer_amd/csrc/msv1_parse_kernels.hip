@@ -510,12 +510,15 @@ __device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&
 // Measured and dropped (profiles/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
 // prefetched into registers, 2-bit packed slot kinds instead of 32 classification registers) hid the tile load but ran
 // the workgroups of a CU in lockstep — every phase then competes for the same issue slots — and was 10 % slower.
-// The asynchronous per-frame path (one frame per launch) runs the kernel twice:
+// The asynchronous per-frame path (one frame per launch):
+//   MODE 3: one launch — every tile parses and reports into `info`, waits for the whole frame's verdict, then writes its
+//           pixels or nothing (see msv1.h); what frames of up to MSV1_MERGED_MAX_TILES tiles get;
 //   MODE 1, "scout": everything up to the replay, no pixel is written; reports in `info` what the host stage of the
 //           descriptor path learns from its parse — stream too short, coded block in a significant block row (stage-1
 //           significance), 8-bit end marker or skip code on the chain;
 //   MODE 2: the decode proper, which returns at once when the scout found one of the conditions in `bad_mask` — such a
 //           frame is re-done by the synchronous path, and must find `dst` exactly as the caller left it.
+// MODE 4: the batch form writing block tables instead of pixels (the descriptor parse of inter-frame batches).
 // MODE 0 is the batch form (no report).
 #ifdef JSP_FUSED_CLOCKS   // lab build: thread 0 of every tile adds the cycles of each phase to its own counters behind the tile tables (`want` = tiles of the batch)
 #define JSP_CLOCK(k) do { if (MODE == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
