@@ -243,27 +243,53 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 #pragma unroll
     for (int j = 0; j < PPL; ++j) d24[j] = dlo[j] = m_left[j] = m_above[j] = 0;
     int y = yb;
-    while (y < ye) {
-        // window: rows y .. y_end-1 whose records fit in win_cap.  A single row with more records than that
-        // (more than one run every other pixel) is scattered straight from global memory.
-        const uint32_t w0 = idx[y - yb] & OFF;
-        int y_end = y + 1;
+    // window: rows y .. y_end-1 whose records fit in win_cap.  A single row with more records than that (more than one run
+    // every other pixel) is scattered straight from global memory.
+    constexpr int WMAX = 6;                                    // win_cap <= 64 * WMAX (tile_plan)
+    uint32_t w0 = 0;
+    int y_end = yb, wn = 0;
+    bool direct = false;
+    uint2 wv[WMAX];                                            // the window's records on their way from memory
+    auto plan_and_fetch = [&](int from) {
+        w0 = idx[from - yb] & OFF;
+        y_end = from + 1;
         while (y_end < ye && (int)((idx[y_end + 1 - yb] & OFF) - w0) <= win_cap) ++y_end;
-        int wn = (int)((idx[y_end - yb] & OFF) - w0);
-        const bool direct = wn > win_cap;             // only possible with y_end == y + 1
+        wn = (int)((idx[y_end - yb] & OFF) - w0);
+        direct = wn > win_cap;                                 // only possible with y_end == from + 1
         if (direct) wn = 0;
-        for (int k = lane; k < wn; k += 64) win[k] = load2_global(gruns + w0 + k);
+#pragma unroll
+        for (int q = 0; q < WMAX; ++q) {
+            const int k = lane + 64 * q;
+            wv[q] = make_uint2(0, 0);
+            if (k < wn) wv[q] = load2_global(gruns + w0 + k);
+        }
+    };
+    plan_and_fetch(yb);
+    while (y < ye) {
+        // The window's records were asked for a window ago — all of them at once, and BEFORE the rows of the window in
+        // between were stored: in a load -> wait -> LDS-write loop each 64 records cost a memory round trip of their own, and
+        // every wait also waited for the frame stores in front of it (loads and stores share the counter); a tile has a
+        // dozen windows.  Now a window costs one wait for the stores behind its loads.
+        const uint32_t cw0 = w0;
+        const int cy_end = y_end, cwn = wn;
+        const bool cdirect = direct;
+#pragma unroll
+        for (int q = 0; q < WMAX; ++q) {
+            const int k = lane + 64 * q;
+            if (k < cwn) win[k] = wv[q];
+        }
+        if (cy_end < ye) plan_and_fetch(cy_end);               // the next window's records start travelling now
         {
-            const uint32_t r0 = w0, r1 = idx[y + 1 - yb] & OFF, origin = (uint32_t)((size_t)y * X + xs);
-            if (direct) {
+            const uint32_t r0 = cw0, r1 = idx[y + 1 - yb] & OFF, origin = (uint32_t)((size_t)y * X + xs);
+            if (cdirect) {
                 for (int r = lane; r < (int)(r1 - r0); r += 64) {
                     const uint2 q = load2_global(gruns + r0 + r);
                     head[q.x - origin] = q.y | HEAD_PRESENT;
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (cdirect) __builtin_amdgcn_s_waitcnt(0x0F70);   // (its scatter above read straight from memory)
             __builtin_amdgcn_wave_barrier();
-            if (!direct)
+            if (!cdirect)
                 for (int r = lane; r < (int)(r1 - r0); r += 64) {
                     const uint2 q = win[r];
                     head[q.x - origin] = q.y | HEAD_PRESENT;
@@ -271,10 +297,10 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         }
         uint32_t e0 = idx[y - yb];                                        // this row's entry (its flag matters)
         uint32_t e1 = idx[y + 1 - yb];
-        uint32_t e2 = y + 1 < y_end ? idx[y + 2 - yb] : e1;
-        for (; y < y_end; ++y) {
-            const bool more = y + 1 < y_end;
-            const uint32_t e3 = y + 2 < y_end ? idx[y + 3 - yb] : e2;     // a row ahead, off the critical path
+        uint32_t e2 = y + 1 < cy_end ? idx[y + 2 - yb] : e1;
+        for (; y < cy_end; ++y) {
+            const bool more = y + 1 < cy_end;
+            const uint32_t e3 = y + 2 < cy_end ? idx[y + 3 - yb] : e2;     // a row ahead, off the critical path
             const uint32_t r1 = e1 & OFF, r2 = e2 & OFF;
             const bool repeat = (e0 & kRowRepeats) != 0u;                  // (uniform) no records: the words of the row above stay
             const uint32_t eg = left[y - yb];
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             }
             const int n_next = more ? (int)(r2 - r1) : 0;
             uint2 nrec = make_uint2(0, 0);
-            if (lane < n_next) nrec = win[(int)(r1 - w0) + lane];
+            if (lane < n_next) nrec = win[(int)(r1 - cw0) + lane];
             const uint32_t row0 = (uint32_t)((size_t)y * X);
             uint32_t u0 = lane_to_the_left(p[PPL - 1]);
             if (lane == 0) u0 = eg;
@@ -332,7 +358,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             const uint32_t origin_next = row0 + (uint32_t)X + (uint32_t)xs;
             if (lane < n_next) head[nrec.x - origin_next] = nrec.y | HEAD_PRESENT;
             for (int r = lane + 64; r < n_next; r += 64) {   // rows with more records than lanes
-                const uint2 q2 = win[(int)(r1 - w0) + r];
+                const uint2 q2 = win[(int)(r1 - cw0) + r];
                 head[q2.x - origin_next] = q2.y | HEAD_PRESENT;
             }
             __builtin_amdgcn_wave_barrier();
@@ -620,6 +646,7 @@ TilePlan tile_plan(const Geometry& g, int band_rows) {
     const size_t budget = 4608 / 4;
     size_t cap = budget > fixed ? (budget - fixed) / 2 : 0;
     if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
+    if (cap > 384) cap = 384;                                  // the kernel fetches a window with at most six loads per lane
     t.win_cap = (int)cap;
     t.lds = 4 * (fixed + 2 * cap);
     return t;
