@@ -133,6 +133,84 @@ class Manager:
 
     _last_was_key = False
 
+    def play_pipelined(self, frames: Sequence[bytes], depth: int = 4,
+                       on_frame: Optional[Callable[[DecodedFrame, object], None]] = None,
+                       key_flags: Optional[Sequence[bool]] = None):
+        """play() through the asynchronous calls (DecompressI_async / DecompressP_async / wait): up to `depth` frames are in
+        flight, the host stage of frame n+1 runs while the uploads and kernels of frame n do.  The log is the one play()
+        writes.  HIP codecs only; the pool must hold `depth` more buffers than play() needs (Manager(..., num_buffers =
+        NUM_BUFFERS + depth)): a frame in flight keeps its destination AND the buffer it was decoded against."""
+        from collections import deque
+        from .codec import CodecError
+        dec = self.decoder
+        dec.set_option("async_depth", str(depth))
+        flying: deque = deque()      # (ticket, index, key, slot, prev_slot, prev buffer, compare bytes?, frame bytes)
+
+        def collect():
+            ticket, index, key, slot, prev_slot, prev, cmp_bytes, blob, prev_blob = flying.popleft()
+            got = dec.wait(ticket)
+            if key:
+                state, sig = int(got), None
+                if state == 0:
+                    if index == 0:
+                        sig = True
+                    elif cmp_bytes:
+                        sig = prev_blob != blob
+                    elif prev is None:
+                        sig = True
+                    else:
+                        sig = _differ(self.buffers[slot], prev, INSIGNIFICANT_LINES * self.vi.X)
+                out = DecodedFrame(index, True, slot, sig, state)
+            else:
+                shown = slot
+                if got.data_pnt is not None and got.data_pnt is prev and prev_slot >= 0:
+                    shown = prev_slot
+                out = DecodedFrame(index, False, shown, got.significant_changes)
+            self.log.append(out)
+            if on_frame:
+                on_frame(out, self.buffers[out.buffer_index])
+
+        prev_key, last_was_key = None, False
+        for i, f in enumerate(frames):
+            if len(flying) == depth:
+                collect()
+            key = bool(key_flags[i]) if key_flags is not None else (i == 0 or dec.IsKeyFrame(f))
+            prev = dec.PreviousFrame()                      # as of the last SUBMITTED frame
+            prev_slot = self._slot_of(prev) if prev is not None else -1
+            busy = {prev_slot} | {fl[3] for fl in flying} | {fl[4] for fl in flying}
+            # what may still be looked at: everything from the oldest frame in flight on
+            horizon = flying[0][1] - 1 if flying else i
+            slot, oldest, oldest_first = -1, -1, 1 << 30
+            for k, h in enumerate(self.holds):
+                if k in busy:
+                    continue
+                if h is None:
+                    slot = k
+                    break
+                if h.stop - 1 < horizon and h.start < oldest_first:
+                    oldest, oldest_first = k, h.start
+            if slot < 0:
+                slot = oldest
+                if slot >= 0:
+                    self.holds[slot] = None
+            if slot < 0:
+                raise CodecError("no free frame buffer: the pool needs NUM_BUFFERS + depth + 1 buffers")
+            dst = self.buffers[slot]
+            ticket = dec.DecompressI_async(f, dst) if key else dec.DecompressP_async(f, dst)
+            now = dec.PreviousFrame()                        # adoption is decided by the host stage: known at submission
+            if now is dst:
+                self.holds[slot] = range(i, i + 1)
+            elif now is not None and now is prev and prev_slot >= 0:
+                h = self.holds[prev_slot]
+                self.holds[prev_slot] = range(h.start, i + 1) if h else range(i, i + 1)
+            flying.append((ticket, i, key, slot, prev_slot, prev, key and last_was_key and i > 0, f, prev_key))
+            last_was_key = key
+            prev_key = f if key else prev_key
+            self.next_frame_to_decode = i + 1
+        while flying:
+            collect()
+        return self.log
+
 
 def play_incremental(pieces, classes, alloc: Callable[[int], object],
                      on_frame: Optional[Callable[[DecodedFrame, object], None]] = None) -> Optional[Manager]:

@@ -102,6 +102,37 @@ def test_avi_clip_gpu_matches_cpu_reference_path(bits):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what", ["msvc16", "msvc8", "screenpressor"])
+@pytest.mark.parametrize("depth", [1, 3])
+def test_python_player_pipelined_shows_the_same_pictures(what, depth):
+    """Manager.play_pipelined (DecompressI_async / DecompressP_async / wait, `depth` frames in flight) writes the log
+    Manager.play writes through the oracle — key flags, significance, states — and every frame shows the same picture
+    (the pool is larger, so slot numbers may differ)."""
+    import torch
+    from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
+    if what == "screenpressor":
+        chunks, keys, _ = sg.sp_clip(32, 320, 240, 14, version=4, key_every=5, unchanged_at=(2, 7))
+        blob = avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys)
+    else:
+        bits = 16 if what == "msvc16" else 8
+        frames, pal = config0_clip(bits, 40)
+        blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=bits, palette=pal)
+    vi, got = avi.read_avi(blob)
+    shown_cpu, shown_gpu = [], []
+    cpu = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
+    cpu.play(got, on_frame=lambda d, buf: shown_cpu.append(buf.copy()))
+    dec = player.make_decoder(vi, (MSVideo1_16bit, MSVideo1_8bit, ScreenPressor))
+    if what != "screenpressor":
+        dec.set_option("msv1_parse", "gpu")
+    gpu = player.Manager(vi, dec, lambda n: torch.zeros(n, dtype=torch.int32, device="cuda"), num_buffers=player.NUM_BUFFERS + depth)
+    gpu.play_pipelined(got, depth=depth, on_frame=lambda d, buf: shown_gpu.append(buf.cpu().numpy()))
+    assert len(cpu.log) == len(gpu.log) == len(got)
+    for a, b, pa, pb in zip(cpu.log, gpu.log, shown_cpu, shown_gpu):
+        assert (a.index, a.key, a.significant_changes, a.state) == (b.index, b.key, b.significant_changes, b.state)
+        assert np.array_equal(pa, pb), a.index
+
+
+@pytest.mark.gpu
 def test_display_convert_and_frames_differ_kernels():
     """jsp_display_convert / jsp_frames_differ against the oracle's restatement of Manager.fill_bitmap_data
     (Manager.hx:325-390, all four conversions, with and without the row flip) and of the pixel loop of
