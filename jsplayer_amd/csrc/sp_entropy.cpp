@@ -45,6 +45,24 @@ private:
     bool poisoned_ = false;
 };
 
+
+// the shared shape of EntropyDecoder::literal(): three components, each in the context the one before left behind
+template <class Coder>
+inline int64_t literal_of(Coder& self, int& cx, int& cx1, int cxshift) {
+    int comp[3];
+#pragma GCC unroll 3
+    for (int k = 0; k < 3; ++k) {
+        const int ctx = k * 4096 + cx + cx1;
+        if (ctx < 0 || ctx >= 3 * 4096) return -1;
+        const int v = self.clr_inline(ctx);
+        cx1 = (cx << 6) & 0xFC0;
+        cx = v < 0 ? 0 : v >> cxshift;
+        comp[k] = v;
+    }
+    if (comp[0] < 0) return 0;  // (b<<16)+(g<<8)+undefined is NaN, stored as 0
+    return (int64_t)(((uint32_t)(comp[2] < 0 ? 0 : comp[2]) << 16) + ((uint32_t)(comp[1] < 0 ? 0 : comp[1]) << 8) + (uint32_t)comp[0]);
+}
+
 class RangeDecoder final : public EntropyDecoder {
 public:
     RangeDecoder() {
@@ -65,11 +83,13 @@ public:
         for (auto& t : mv_) t.reset();
     }
     void begin(const uint8_t* src, size_t n, size_t pos0) override { rc_.begin(src, n, pos0); }
-    int clr(int ctx) override {
+    int clr_inline(int ctx) {
         const Interval iv = clr_.take(ctx, rc_.slot(clr_.total(ctx)));
         rc_.consume(iv.cum, iv.freq);
         return iv.sym;
     }
+    int clr(int ctx) override { return clr_inline(ctx); }
+    int64_t literal(int& cx, int& cx1, int cxshift) override { return literal_of(*this, cx, cx1, cxshift); }
     int run(int ptype) override { return plain(ntab_[ptype]); }
     int ptype(int prev) override { return plain(ptab_[prev]); }
     int xx() override { return plain(xx_); }
@@ -141,7 +161,7 @@ public:
         for (auto& m : mv_) m.renew();
     }
     void begin(const uint8_t* src, size_t n, size_t pos0) override { bits_.begin(src, n, pos0); ndec_ = 0; }
-    int clr(int ctx) override {
+    int clr_inline(int ctx) {
         int c;
         if (clr_.coded(ctx)) {
             const Interval iv = clr_.take(ctx, bits_.slot());
@@ -154,6 +174,8 @@ public:
         tick();
         return c;
     }
+    int clr(int ctx) override { return clr_inline(ctx); }
+    int64_t literal(int& cx, int& cx1, int cxshift) override { return literal_of(*this, cx, cx1, cxshift); }
     int run(int ptype) override { return fixed(ntab_[ptype]); }
     int ptype(int prev) override { return fixed(ptab_[prev]); }
     int xx() override { return fixed(xx_); }

@@ -2,6 +2,7 @@
 // implementations: v2 range coder (RangeCoder.hx, EntroCoders.hx:31-180) and v3/v4 rANS
 // (ANS.hx:5-49, EntroCoders.hx:182-313), both on top of the models in sp_models.h.
 #pragma once
+#include <cstdint>
 #include <memory>
 
 #include "sp_models.h"
@@ -18,6 +19,10 @@ public:
     virtual void renewI() = 0;
     virtual void begin(const uint8_t* src, size_t n, size_t pos0) = 0;
     virtual int clr(int ctx) = 0;   // one colour component; -1 = the reference's `undefined`
+    // The three components of a literal colour in one call (ScreenPressor.hx:173-189 / 224-235 / 419-430): `cx` / `cx1` are the
+    // caller's context halves, updated as the reference updates them after every component.  Returns the pixel, or -1 when a
+    // context index leaves the tables (the reference would index past its arrays).
+    virtual int64_t literal(int& cx, int& cx1, int cxshift) = 0;
     virtual int run(int ptype) = 0; // decodeN
     virtual int ptype(int prev) = 0;
     virtual int xx() = 0;

@@ -49,18 +49,10 @@ void HostDecoder::renew_i() {  // ScreenPressor.hx:108-115
     ec_->renewI();
 }
 
-int32_t HostDecoder::literal() {  // ScreenPressor.hx:173-189 / 224-235 / 419-430
-    auto comp = [&](int base) {
-        const int ctx = base + cx_ + cx1_;
-        if (ctx < 0 || ctx >= 3 * 4096) throw DecodeAbort{"colour context outside the table"};
-        const int v = ec_->clr(ctx);
-        cx1_ = (cx_ << 6) & 0xFC0;
-        cx_ = v < 0 ? 0 : v >> cxshift_;
-        return v;
-    };
-    const int r = comp(0), g = comp(4096), b = comp(8192);
-    if (r < 0) return 0;  // (b<<16)+(g<<8)+undefined is NaN, stored as 0
-    return (int32_t)(((uint32_t)(b < 0 ? 0 : b) << 16) + ((uint32_t)(g < 0 ? 0 : g) << 8) + (uint32_t)r);
+int32_t HostDecoder::literal() {  // ScreenPressor.hx:173-189 / 224-235 / 419-430 (one call into the coder for the three components)
+    const int64_t v = ec_->literal(cx_, cx1_, cxshift_);
+    if (v < 0) throw DecodeAbort{"colour context outside the table"};
+    return (int32_t)v;
 }
 
 void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
