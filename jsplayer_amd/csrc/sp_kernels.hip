@@ -681,10 +681,8 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     // pixels of a chunk fetched by a flat index space in one round trip (3 % slower than rectangle by rectangle).
     // With the block records withheld (every block "unchanged", nothing staged but the destinations) the same loop
     // takes 483 us — the temporal fill ceiling; without the literal fetches 539 us.
-    // JSP_SP_GROUP_CHUNK (<= 64) / JSP_SP_GROUP_LITERALS: tuning knobs.
-    static const int chunk = [] { const char* e = getenv("JSP_SP_GROUP_CHUNK"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 32; }();
-    static const int lit_words = [] { const char* e = getenv("JSP_SP_GROUP_LITERALS"); const int v = e ? atoi(e) : 0; return v >= GROUP_LITERALS_MIN && v <= 8192 ? v : 2048; }();
-    static const int stagger = [] { const char* e = getenv("JSP_SP_GROUP_STAGGER"); return e ? atoi(e) : 1; }();
+    constexpr int chunk = 32, lit_words = 2048, stagger = 1;   // (chunk <= 64: one (frame, block) item per lane in the kernel's scan)
+    static_assert(lit_words >= GROUP_LITERALS_MIN, "one frame's literals must fit");
     const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 32;
     hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
                        reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec, chunk, lit_words, stagger);
