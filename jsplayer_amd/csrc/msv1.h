@@ -72,7 +72,8 @@ struct Msv1FrameInfo {    // counters the parse kernels return per frame
     uint32_t consumed;        // bytes up to the end of the code covering the last block
     uint32_t pad[3];
 };
-uint32_t msv1_parse_tile_bytes();
+uint32_t msv1_parse_tile_bytes();    // 16 KiB: staged batches (frames start on tile boundaries of the stream buffer)
+uint32_t msv1_small_tile_bytes();    // 8 KiB: `small_tiles` launches (one frame per launch: modes 1, 2, 3 of msv1_launch_fused)
 void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_frames, int nframes,
                        const uint32_t* d_tile_frame, int ntiles, int max_tiles_per_frame, uint32_t* d_tile_tab,
                        uint32_t* d_tile_entry, uint32_t* d_tile_block0, uint32_t* d_desc, Msv1FrameInfo* d_info,
@@ -126,11 +127,16 @@ struct Msv1AsyncInfo {
 // (any alignment, nothing read past the frame's last byte): each tile reads its bytes once, over the bus, and leaves a copy
 // in `d_keep` (HBM, the frame's size rounded up to 16 bytes).
 constexpr int MSV1_MERGED_MAX_TILES = 128;
+// One-frame launches of a small frame (an inter frame, an 8-bit frame: a few hundred KB) use 8 KiB tiles — `small_tiles` —: twice the
+// workgroups, half the serial work in each; the kernel's time is a chain of dependent steps per tile, and such a launch has the
+// GPU to itself.  (1080p inter frames with 70 % skipped blocks: 28.8 -> 37.9 Gpixels/s on one stream, 8-bit key frames 42.4 -> 52.8;
+// frames of a megabyte gain nothing on one stream and lose a fifth on sixteen: they keep 16 KiB tiles.)
+constexpr size_t MSV1_SMALL_TILE_FRAME_BYTES = 640 * 1024;
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
                        hipStream_t stream, Msv1AsyncInfo* d_info = nullptr, int insignificant_blocks = 0, int mode = 0,
                        uint32_t bad_mask = 0, uint32_t* d_poison = nullptr, const Msv1TileRec* one_rec = nullptr,
-                       Msv1AsyncInfo* h_info = nullptr, uint32_t want = 0, uint8_t* d_keep = nullptr);
+                       Msv1AsyncInfo* h_info = nullptr, uint32_t want = 0, uint8_t* d_keep = nullptr, bool small_tiles = false);
 
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,

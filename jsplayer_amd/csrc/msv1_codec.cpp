@@ -145,7 +145,7 @@ struct Msv1AsyncStaged : jsp_staged {
     // one-launch form (frames of at most MSV1_MERGED_MAX_TILES tiles): the record all tiles share travels as a kernel
     // argument, the report comes back through pinned memory, and the kernel reads the frame's bytes from pinned host
     // memory itself (the caller's, or h_stream), leaving a copy in d_stream: no copy is queued at all
-    bool merged = false;
+    bool merged = false, small_tiles = false;
     Msv1TileRec rec{};
     DeviceBuffer d_report;                    // one Msv1AsyncInfo, allocated (and zeroed) once: its counters run on
     uint32_t want = 0;                        // ... to this value once every launch so far is through
@@ -166,7 +166,7 @@ struct Msv1AsyncStaged : jsp_staged {
             if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
             msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
                               ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad, d_poison, &rec,
-                              static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p));
+                              static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles);
             JSP_HIP(hipGetLastError());
             decoded = true;
             return;
@@ -174,7 +174,7 @@ struct Msv1AsyncStaged : jsp_staged {
         for (int mode = 1; mode <= 2; ++mode)   // scout, then the decode it may veto
             msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_meta.p), d_palette,
                               static_cast<unsigned long long*>(d_agg.p), ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev,
-                              insignificant_blocks, mode, bad, d_poison);
+                              insignificant_blocks, mode, bad, d_poison, nullptr, nullptr, 0, nullptr, small_tiles);
         JSP_HIP(hipGetLastError());
         JSP_HIP(hipMemcpyAsync(h_info.p, info_dev, sizeof(Msv1AsyncInfo), hipMemcpyDeviceToHost, stream));
         decoded = true;
@@ -329,7 +329,8 @@ struct Msv1Codec : jsp_codec {
 
     jsp_staged* stage_async(const jsp_frame_in& f, jsp_staged* reuse) override {
         activate();
-        const size_t tile_bytes = msv1_parse_tile_bytes();
+        const bool small_tiles = f.n <= MSV1_SMALL_TILE_FRAME_BYTES;
+        const size_t tile_bytes = small_tiles ? msv1_small_tile_bytes() : msv1_parse_tile_bytes();
         const Prescan ps = prescan(f.src, f.n);
         if (sync_staging(f, ps)) {
             // the synchronous staging (it may wait for the GPU: tiny, odd or pre-parsed frames only)
@@ -363,6 +364,7 @@ struct Msv1Codec : jsp_codec {
         const int nt = (int)((f.n + tile_bytes - 1) / tile_bytes);
         st->ntiles = nt;
         st->merged = opt_async_merged && nt <= MSV1_MERGED_MAX_TILES;
+        st->small_tiles = small_tiles;
         const size_t slot = (size_t)nt * tile_bytes;
         st->d_stream.reserve(slot + 64);
         st->h_info.reserve(sizeof(Msv1AsyncInfo));

@@ -64,11 +64,11 @@ __device__ __forceinline__ uint32_t classify(uint32_t a, uint32_t b, uint32_t hi
 // The lane's 32 slots: classification of every slot (cls[]) and the 9-entry table tab[e].
 // `w` = the lane's 64 bytes + 4 bytes of halo as 17 dwords; `p0` = absolute byte offset of slot 0;
 // `end` = absolute end of the frame's bytes.  Everything indexes registers statically.
-template <int BITS>
-__device__ __forceinline__ void lane_table(const uint32_t (&w)[17], uint32_t p0, uint32_t end, uint32_t (&cls)[LSLOTS],
+template <int BITS, int LS = LSLOTS>
+__device__ __forceinline__ void lane_table(const uint32_t (&w)[LS / 2 + 1], uint32_t p0, uint32_t end, uint32_t (&cls)[LS],
                                            uint32_t (&tab)[9]) {
 #pragma unroll
-    for (int s = 0; s < LSLOTS; ++s) {
+    for (int s = 0; s < LS; ++s) {
         const uint32_t a = (w[(2 * s) >> 2] >> (8 * ((2 * s) & 3))) & 0xFFu;
         const uint32_t b = (w[(2 * s + 1) >> 2] >> (8 * ((2 * s + 1) & 3))) & 0xFFu;
         const uint32_t hi = (w[(2 * s + 3) >> 2] >> (8 * ((2 * s + 3) & 3))) & 0xFFu;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void lane_table(const uint32_t (&w)[17], uint32_t p0,
 #pragma unroll
     for (int k = 0; k < 9; ++k) d[k] = pack(k, 0);
 #pragma unroll
-    for (int s = LSLOTS - 1; s >= 0; --s) {
+    for (int s = LS - 1; s >= 0; --s) {
         const uint32_t len = cls[s] & 15u;
         uint32_t nx;
         if (BITS == 16) nx = len == 1u ? d[0] : (len == 3u ? d[2] : d[8]);
@@ -102,15 +102,15 @@ __device__ __forceinline__ void lane_table(const uint32_t (&w)[17], uint32_t p0,
 // read through such an index lie inside the kernels' own arenas.
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
 
-template <int BITS>
-__device__ __forceinline__ void lane_table_fast(const uint32_t (&w)[17], uint32_t (&cls)[LSLOTS], uint32_t (&tab)[9]) {
+template <int BITS, int LS = LSLOTS>
+__device__ __forceinline__ void lane_table_fast(const uint32_t (&w)[LS / 2 + 1], uint32_t (&cls)[LS], uint32_t (&tab)[9]) {
     // one reverse pass: a slot is classified and folded into the 9-deep window (dw[k] = value of slot s+1+k) while
     // its predicates are still in flight
     uint32_t dw[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) dw[k] = pack(k, 0);
 #pragma unroll
-    for (int s = LSLOTS - 1; s >= 0; --s) {
+    for (int s = LS - 1; s >= 0; --s) {
         const uint32_t d = w[s >> 1], dn = w[(s + 1) >> 1];
         const int sh = (s & 1) * 16, shn = ((s + 1) & 1) * 16;       // where the slot's / the next slot's 16-bit word sits
         const bool skip = (d & (0xFC00u << sh)) == (0x8400u << sh);
@@ -356,11 +356,10 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
 // The whole frame batch is one launch; the stream is read from HBM exactly once.
 // Frames the host parser has to settle (Msv1ParseFrame::host_parsed) are skipped here and take the
 // descriptor path.  Requires X % 4 == 0 and 16-byte aligned frame buffers (msv1_codec.cpp checks).
-constexpr int FSTAGE = TSLOTS;                 // blocks per staging window
 constexpr uint32_t F_SKIP = 0xFFFFu;
-constexpr uint32_t TILE_BYTES = TSLOTS * 2;
-constexpr int LOOKBACK_BATCH = 3 * PWG / 9;    // 85 earlier tiles per poll (3 words per lane)
-constexpr int LOOKBACK_SEGS = 7;               // the chain through a batch is walked in 7 segments side by side
+// look-back: LBW words per lane hold the tables of the nearest LBW * PWG / 9 earlier tiles of the frame in one poll (3 words = 85
+// tiles with 16 KiB tiles, 5 words = 142 with 8 KiB tiles: a 1080p M1 frame is 64 / 127 tiles); the chain through a batch is
+// walked in LBW * 7 / 3 segments side by side
 constexpr int LOOKBACK_SPIN_LIMIT = 1 << 18;   // polls before the tile gives up and raises the fault word
 constexpr int VERDICT_SPIN_LIMIT = 1 << 15;    // MODE 3: polls for the frame's other tiles before the frame goes to the host path
 
@@ -466,10 +465,11 @@ __device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail
 // table pass and the replay need is three bit masks over the slots — S: solid (bit 15 of the code word set), E: 8-colour
 // (pattern word followed by a word with bit 15 set), T: 2-colour (the other pattern words); every code is one block.
 struct LaneMasks { uint32_t S, T, E; };
-__device__ __forceinline__ LaneMasks lane_masks16(const uint32_t (&w)[17], bool& has_skip) {
+template <int LS = LSLOTS>
+__device__ __forceinline__ LaneMasks lane_masks16(const uint32_t (&w)[LS / 2 + 1], bool& has_skip) {
     uint32_t notp = 0, z = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < LS / 2; ++i) {
         const uint32_t d = w[i];
         notp |= ((d >> 15) & 1u) << (2 * i);
         notp |= (d >> 31) << (2 * i + 1);
@@ -477,7 +477,7 @@ __device__ __forceinline__ LaneMasks lane_masks16(const uint32_t (&w)[17], bool&
         z |= (t - 0x00010001u) & ~t & 0x80008000u;                     // (a borrow out of a zero low half can only add a hit)
     }
     has_skip = z != 0u;
-    const uint32_t next_set = (notp >> 1) | (((w[16] >> 15) & 1u) << 31);   // bit 15 of the word after the slot's
+    const uint32_t next_set = (notp >> 1) | (((w[LS / 2] >> 15) & 1u) << (LS - 1));   // bit 15 of the word after the slot's
     LaneMasks m;
     m.S = notp;
     m.E = ~notp & next_set;
@@ -485,13 +485,14 @@ __device__ __forceinline__ LaneMasks lane_masks16(const uint32_t (&w)[17], bool&
     return m;
 }
 // the 9-entry table from the masks: the reverse pass of lane_table_fast with the slot's two predicates read off the masks
+template <int LS = LSLOTS>
 __device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&tab)[9]) {
     uint32_t dw[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) dw[k] = pack(k, 0);
     const uint32_t P = ~m.S;
 #pragma unroll
-    for (int s = LSLOTS - 1; s >= 0; --s) {
+    for (int s = LS - 1; s >= 0; --s) {
         uint32_t mp, me;
         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mp) : "v"(P), "n"(s));       // 0 / ~0: pattern code
         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(me) : "v"(m.E), "n"(s));     // 0 / ~0: ... with 8 colours
@@ -528,7 +529,9 @@ __device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&
 #else
 #define JSP_CLOCK(k) do { } while (0)
 #endif
-template <int BITS, int MODE>
+// LS = slots (2 bytes) per lane: 32 (16 KiB tiles) for the batch forms, 16 (8 KiB tiles) for the one-frame-per-launch forms,
+// whose few dozen workgroups have the GPU to themselves: half the serial work per tile, twice the tiles.
+template <int BITS, int MODE, int LS>
 __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
                                                             const Msv1TileRec* __restrict__ recs,
                                                             const int32_t* __restrict__ palette,
@@ -540,6 +543,10 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                                                             Msv1TileRec one_rec, Msv1AsyncInfo* __restrict__ host_info, uint32_t want,
                                                             uint8_t* __restrict__ keep) {
     constexpr bool INFO = MODE == 1 || MODE == 3;
+    constexpr int TSLOTS = PWG * LS, FSTAGE = TSLOTS;          // (shadow the file's 32-slot constants)
+    constexpr uint32_t TILE_BYTES = TSLOTS * 2;
+    constexpr int LSLOTS = LS;
+    constexpr int LBW = LS == 32 ? 3 : 5, LOOKBACK_BATCH = LBW * PWG / 9, LOOKBACK_SEGS = LBW * 7 / 3;
     // one LDS arena: [tile bytes | composition tree | per-node entry]; the tree's space becomes the staging
     // window once every lane knows where the chain enters its slots; `enter` doubles as the look-back scratch
     constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = LOOKBACK_BATCH * 9 + 4;
@@ -607,11 +614,13 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     //         of them, 3 words per lane) travel while this tile builds its own -----------------------------------
     const uint32_t nlook = k < (uint32_t)LOOKBACK_BATCH ? k : (uint32_t)LOOKBACK_BATCH;
     const uint32_t look0 = k - nlook;                          // first tile (within the frame) of that batch
-    unsigned long long lv[3] = {0, 0, 0};
+    unsigned long long lv[LBW];
+#pragma unroll
+    for (int q = 0; q < LBW; ++q) lv[q] = 0ull;
     {
         const unsigned long long* look_src = agg + (size_t)(r.first_tile + look0) * 9u;
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < LBW; ++q)
             if ((uint32_t)(tid + q * PWG) < nlook * 9u)
                 lv[q] = __hip_atomic_load(look_src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -665,22 +674,22 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     // A skip-aware mask form was built and measured (27 % fewer VALU instructions, 6 % slower: profiles/r02_fused_notes.txt).
     bool fast = false;
     {
-        uint32_t w[17], tab[9];
+        uint32_t w[LS / 2 + 1], tab[9];
         const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
 #pragma unroll
-        for (int i = 0; i < 17; ++i) w[i] = mine_w[i];
+        for (int i = 0; i < LS / 2 + 1; ++i) w[i] = mine_w[i];
 #ifndef JSP_FUSED_MASKS
 #define JSP_FUSED_MASKS 1
 #endif
         if (JSP_FUSED_MASKS && BITS == 16 && inside) {
             bool has_skip;
-            masks = lane_masks16(w, has_skip);
+            masks = lane_masks16<LS>(w, has_skip);
             fast = __ballot(has_skip) == 0ull;
         }
-        if (fast) lane_table_masks(masks, tab);
+        if (fast) lane_table_masks<LS>(masks, tab);
         else {
             uint32_t cls[LSLOTS];
-            lane_table<BITS>(w, p0, r.frame_end, cls, tab);
+            lane_table<BITS, LS>(w, p0, r.frame_end, cls, tab);
         }
 #pragma unroll
         for (int e = 0; e < 9; ++e) tree[tid][e] = tab[e];
@@ -711,21 +720,21 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     // ---- 3. look-back: chain the earlier tiles' tables from entry slot 0 of the frame --------------------------
     {
         uint32_t e = 0, blocks = 0;                            // thread 0 carries the chain
-        // frames with more than LOOKBACK_BATCH earlier tiles: the far ones first, batch by batch (rare: > 1.3 MB frames)
+        // frames with more than LOOKBACK_BATCH earlier tiles: the far ones first, batch by batch (frames of more than LOOKBACK_BATCH tiles)
         for (uint32_t j0 = 0; j0 < k; j0 += LOOKBACK_BATCH) {
             const bool last = j0 + LOOKBACK_BATCH >= k;        // the batch whose loads are already in flight
             const uint32_t b0 = last ? look0 : j0, nj = last ? nlook : (uint32_t)LOOKBACK_BATCH;
             const unsigned long long* src = agg + (size_t)(r.first_tile + b0) * 9u;
             // (the loads of a round all go out before any is looked at: checked one by one, each cost a round trip of its own)
-            unsigned long long v[3];
+            unsigned long long v[LBW];
             bool have = true;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < LBW; ++q) {
                 const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
                 v[q] = last ? lv[q] : (wanted ? __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
             }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < LBW; ++q) {
                 const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
                 have &= !wanted || (uint32_t)(v[q] >> 32) == epoch;
             }
@@ -739,20 +748,20 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                 }
                 __builtin_amdgcn_s_sleep(8);
                 have = true;
-                bool stale[3];
+                bool stale[LBW];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) stale[q] = (uint32_t)(tid + q * PWG) < nj * 9u && (uint32_t)(v[q] >> 32) != epoch;
+                for (int q = 0; q < LBW; ++q) stale[q] = (uint32_t)(tid + q * PWG) < nj * 9u && (uint32_t)(v[q] >> 32) != epoch;
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < LBW; ++q)
                     if (stale[q]) v[q] = __hip_atomic_load(src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < LBW; ++q) {
                     const bool wanted = (uint32_t)(tid + q * PWG) < nj * 9u;
                     have &= !wanted || (uint32_t)(v[q] >> 32) == epoch;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < LBW; ++q)
                 if ((uint32_t)(tid + q * PWG) < nj * 9u) enter[tid + q * PWG] = (uint32_t)v[q];
             __syncthreads();
             // chain tables [skip, nj) of the batch: LOOKBACK_SEGS segments walked side by side for all 9 entry slots
@@ -831,6 +840,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                 V = V2;
                 if (!__any(grew)) break;
             }
+            if (LS < 32) V &= (1u << LS) - 1u;               // (marks past the lane's last slot belong to the next lane)
             if (INFO && w0 == tb0) {                            // a coded block in a significant block row?
                 const uint32_t cnt = (uint32_t)__popc(V), lo = blk0 > s1_first_block ? blk0 : s1_first_block;
                 const uint32_t hi = blk0 + cnt < nblocks ? blk0 + cnt : nblocks;
@@ -846,13 +856,13 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             }
         } else {
             // replay the lane's slots one by one: the chain visits slot `pos`; a coded block leaves the offset of its code
-            uint32_t w[17], cls[LSLOTS];
+            uint32_t w[LS / 2 + 1], cls[LSLOTS];
             const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
 #pragma unroll
-            for (int i = 0; i < 17; ++i) w[i] = mine_w[i];
+            for (int i = 0; i < LS / 2 + 1; ++i) w[i] = mine_w[i];
             {
                 uint32_t tab[9];
-                lane_table<BITS>(w, p0, r.frame_end, cls, tab);   // (for its classification; the table is not used again)
+                lane_table<BITS, LS>(w, p0, r.frame_end, cls, tab);   // (for its classification; the table is not used again)
             }
             uint32_t pos = mine & 15u, blk = mine >> 4;
 #pragma unroll
@@ -1008,6 +1018,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
 }  // namespace
 
 uint32_t msv1_parse_tile_bytes() { return TSLOTS * 2; }
+uint32_t msv1_small_tile_bytes() { return PWG * 16 * 2; }   // `small_tiles` of msv1_launch_fused: 16 slots per lane
 
 void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1ParseFrame* d_frames, int nframes,
                        const uint32_t* d_tile_frame, int ntiles, int max_tiles_per_frame, uint32_t* d_tile_tab,
@@ -1035,17 +1046,22 @@ void msv1_launch_parse(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
                        hipStream_t stream, Msv1AsyncInfo* d_info, int insignificant_blocks, int mode, uint32_t bad_mask,
-                       uint32_t* d_poison, const Msv1TileRec* one_rec, Msv1AsyncInfo* h_info, uint32_t want, uint8_t* d_keep) {
+                       uint32_t* d_poison, const Msv1TileRec* one_rec, Msv1AsyncInfo* h_info, uint32_t want, uint8_t* d_keep,
+                       bool small_tiles) {
     if (ntiles <= 0) return;
     const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
     const Msv1TileRec rec = one_rec ? *one_rec : Msv1TileRec{};
-#define JSP_FUSED(BITS, MODE)                                                                                            \
-    hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
+    if (mode == 0 || mode == 4) small_tiles = false;           // the batch forms lay frames out on 16 KiB boundaries
+#define JSP_FUSED(BITS, MODE, LS)                                                                                            \
+    hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE, LS>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
                        d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep)
-#define JSP_FUSED_MODES(BITS)                                                                                            \
-    switch (mode) { case 1: JSP_FUSED(BITS, 1); break; case 2: JSP_FUSED(BITS, 2); break; case 3: JSP_FUSED(BITS, 3); break; case 4: JSP_FUSED(BITS, 4); break; default: JSP_FUSED(BITS, 0); }
+#define JSP_FUSED_LS(BITS, MODE) do { if (small_tiles) JSP_FUSED(BITS, MODE, 16); else JSP_FUSED(BITS, MODE, 32); } while (0)
+#define JSP_FUSED_MODES(BITS)                                                                                                \
+    switch (mode) { case 1: JSP_FUSED_LS(BITS, 1); break; case 2: JSP_FUSED_LS(BITS, 2); break; case 3: JSP_FUSED_LS(BITS, 3); break; \
+                    case 4: JSP_FUSED(BITS, 4, 32); break; default: JSP_FUSED(BITS, 0, 32); }
     if (geo.bits == 16) { JSP_FUSED_MODES(16) } else { JSP_FUSED_MODES(8) }
 #undef JSP_FUSED_MODES
+#undef JSP_FUSED_LS
 #undef JSP_FUSED
 }
 
