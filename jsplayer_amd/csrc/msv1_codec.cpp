@@ -13,6 +13,9 @@
 namespace jsp {
 namespace {
 
+// Published tile tables carry the launch's epoch; 0 is what freshly zeroed memory reads as, so the counter skips it when it wraps.
+inline uint32_t next_epoch(uint32_t& e) { if (++e == 0) ++e; return e; }
+
 struct Msv1Staged : jsp_staged {
     Msv1Geometry geo{};
     const int32_t* d_palette = nullptr;
@@ -61,7 +64,7 @@ struct Msv1Staged : jsp_staged {
                 JSP_HIP(hipMemsetAsync(static_cast<uint32_t*>(d_desc.p) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE,
                                        sizeof(uint32_t) * (size_t)geo.nblocks, stream));
             msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                              static_cast<unsigned long long*>(d_agg.p), ++epoch, 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
+                              static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
                               nullptr, 0, 4);
         }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
@@ -72,7 +75,7 @@ struct Msv1Staged : jsp_staged {
                 const uint32_t tile0 = pf[g.first].first_tile;
                 const Msv1ParseFrame& last = pf[g.first + g.count - 1];
                 msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs.p), d_palette,
-                                  static_cast<unsigned long long*>(d_agg.p), ++epoch, tile0, (int)(last.first_tile + last.ntiles - tile0),
+                                  static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), tile0, (int)(last.first_tile + last.ntiles - tile0),
                                   static_cast<uint32_t*>(d_sync.p), stream, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);
             } else if (g.temporal)
                 msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
@@ -165,7 +168,7 @@ struct Msv1AsyncStaged : jsp_staged {
             want += (uint32_t)ntiles;
             if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
             msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
-                              ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad, d_poison, &rec,
+                              next_epoch(epoch), 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad, d_poison, &rec,
                               static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles);
             JSP_HIP(hipGetLastError());
             decoded = true;
@@ -173,7 +176,7 @@ struct Msv1AsyncStaged : jsp_staged {
         }
         for (int mode = 1; mode <= 2; ++mode)   // scout, then the decode it may veto
             msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_meta.p), d_palette,
-                              static_cast<unsigned long long*>(d_agg.p), ++epoch, 0, ntiles, &info_dev->fault, stream, info_dev,
+                              static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, &info_dev->fault, stream, info_dev,
                               insignificant_blocks, mode, bad, d_poison, nullptr, nullptr, 0, nullptr, small_tiles);
         JSP_HIP(hipGetLastError());
         JSP_HIP(hipMemcpyAsync(h_info.p, info_dev, sizeof(Msv1AsyncInfo), hipMemcpyDeviceToHost, stream));
