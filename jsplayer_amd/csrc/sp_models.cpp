@@ -340,7 +340,7 @@ uint32_t ColourModels::full_from_table(const Table& t) {  // Cx7.createFrom6
 }
 
 // ---- the context state machine (Context, ANS.hx:785-860) -------------------------------------------------------
-void ColourModels::learn(int ctx, int c) {
+void ColourModels::learn_slow(int ctx, int c) {
     Small& s = small_[ctx];
     const uint8_t byte = (uint8_t)(c < 0 ? 0 : c);   // a missing byte is stored as 0 (and matches a later 0)
     auto big_find_or_add = [&](ListBig& l, int capacity) -> int {   // 0 found, 1 added, 2 no room

@@ -261,7 +261,21 @@ public:
     // Coded stages: interval of the symbol owning `slot`, then adapt (may upgrade the stage).
     Interval take(int ctx, int slot);
     // Raw stages: learn symbol c (c < 0 = the reference's `undefined`: stored as 0, never found by itself).
-    void learn(int ctx, int c);
+    // The two cases a noisy key frame spends its raw bytes on stay in the caller's loop: the first symbol of a context, and
+    // a new symbol for a short list with room (sixteen list entries compared at once); the rest is learn_slow().
+    void learn(int ctx, int c) {
+#ifndef JSP_MODEL_TOOLS   // (the stream generator counts stage entries: it takes the one path that does)
+        Small& s = small_[ctx];
+        const uint8_t byte = (uint8_t)(c < 0 ? 0 : c);
+        if (s.stage == Empty) { s.n = 1; s.sym[0] = byte; s.stage = List14; return; }
+        if (s.stage == List14 && s.n < 14) {
+            const unsigned same = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(s.sym)), _mm_set1_epi8((char)byte)));
+            if (!(c >= 0 && (same & ((1u << s.n) - 1u)))) { s.sym[s.n++] = byte; return; }
+        }
+#endif
+        learn_slow(ctx, c);
+    }
+    void learn_slow(int ctx, int c);
 #ifdef JSP_MODEL_TOOLS   // stream generator only
     int locate(int ctx, int c) const;                         // a slot inside c's current interval (coded stages)
     uint64_t census[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // how often a context entered each Stage
