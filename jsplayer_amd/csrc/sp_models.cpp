@@ -393,37 +393,6 @@ void ColourModels::learn_slow(int ctx, int c) {
     }
 }
 
-Interval ColourModels::take(int ctx, int slot) {
-    Small& s = small_[ctx];
-    Interval iv{0, 0, 0};
-    switch (s.stage) {
-        case Sparse4: {
-            const int tot = s.freq[0] + s.freq[1] + s.freq[2] + s.freq[3] + 256 - s.n;
-            if (!sparse_take(s, slot, tot, iv)) { sparse16_from_sparse4(s, iv.sym); enter(s, Sparse16); }
-            break;
-        }
-        case Sparse16:
-            if (!sparse_take(s, slot, s.cached_tot, iv)) {
-                s.cached_tot = (uint16_t)tot_;
-                s.big = table_from_sparse16(s, iv.sym);
-                enter(s, Table40);
-            } else
-                s.cached_tot = (uint16_t)tot_;
-            break;
-        case Table40:
-            if (!table_take(tables_[s.big], slot, iv)) { s.big = full_from_table(tables_[s.big]); enter(s, Full); }
-            break;
-        case Full: {
-            Full256& m = fulls_[s.big];
-            m.prefetch();   // hint and starts together: the second read does not wait for the first
-            iv = m.take(slot);
-            break;
-        }
-        default: break;
-    }
-    return iv;
-}
-
 #ifdef JSP_MODEL_TOOLS
 int ColourModels::locate(int ctx, int c) const {
     const Small& s = small_[ctx];
