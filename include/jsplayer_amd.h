@@ -116,6 +116,10 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *   "sp_band_rows" = "auto" (default) | "0" | "<n>" : ScreenPressor only.  Key frames are rebuilt by one
  *       workgroup per band of n rows (0 = the whole frame is one band; auto = sized so a batch fills
  *       the GPU); the host stage hands each band the row above it.  Results do not depend on it.
+ *   "sp_host_threads" = "auto" (default: up to 8) | "1".."64" : ScreenPressor only, jsp_stage_batch.  A coded key frame renews
+ *       every bit of decoder state, so the frames from one coded key frame up to the next depend on nothing before them:
+ *       the host entropy stage takes up to this many such groups of a batch side by side, a decoder and a host thread each
+ *       (one-frame calls have nothing to split).  Results do not depend on it.
  *   "sp_inter_fusion" = "on" (default) | "off" : ScreenPressor only.  In a staged batch, consecutive inter
  *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
  *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its

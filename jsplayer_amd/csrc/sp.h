@@ -80,6 +80,7 @@ struct FrameOut {
     uint64_t data_pixels = 0;        // Inter: pixels the stream codes (data rectangles)
     uint64_t motion_pixels = 0;      // Inter: part of prev_pixels that is motion-compensated
     uint64_t stream_bytes = 0;
+    bool literalised = false;        // Inter: literalise_motion() has been applied
     const char* error = nullptr;
     // Back to the empty state WITHOUT giving the tables' memory back: a stream's frames need about the same room one
     // after the other, and megabyte-sized allocations per frame (page faults, allocator locks shared by the host
@@ -87,7 +88,7 @@ struct FrameOut {
     void reset() {
         kind = FrameKind::None; status = 0; adopted = prev_cleared = significant = false; flat_colour = 0;
         runs.clear(); stream_runs = 0; row_run.clear(); seeds.clear(); band_rows = 0; span_px = 0; tile_idx.clear(); left.clear();
-        blocks.clear(); payload.clear(); prev_pixels = data_pixels = motion_pixels = stream_bytes = 0; error = nullptr;
+        blocks.clear(); payload.clear(); prev_pixels = data_pixels = motion_pixels = stream_bytes = 0; literalised = false; error = nullptr;
     }
 };
 
@@ -111,6 +112,16 @@ public:
     // the shadow frame appended to the payload): no block of `out` then reads the previous frame anywhere
     // but at its own position, which is what lets consecutive inter frames share one launch.
     void literalise_motion(FrameOut& out) const;
+    // ---- decoding the GOPs of a batch side by side (decode_frames below) ----
+    HostDecoder(HostDecoder&&) = default;
+    HostDecoder& operator=(HostDecoder&&) = default;
+    int pinned_version() const { return version_; }            // 0: no coded key frame has chosen the entropy coder yet
+    bool pin_version(int version) { return ec_ ? version_ == version : init_entropy(version); }
+    void adopt_settings(const HostDecoder& o) {                 // Preinit and key-frame layout of the stream's decoder
+        insignificant_blocks_ = o.insignificant_blocks_;
+        band_rows_ = o.band_rows_;
+        span_px_ = o.span_px_;
+    }
 
 private:
     int32_t literal();
@@ -118,6 +129,7 @@ private:
     void renew_i();
     Geometry g_;
     int cx_ = 0, cx1_ = 0, cxshift_;
+    int version_ = 0;               // which entropy coder ec_ is (2, 3, 4); pinned by the first coded key frame
     std::unique_ptr<EntropyDecoder> ec_;
     std::vector<int32_t> shadow_[2];  // [cur_] is being written, [1-cur_] is the previous frame
     int cur_ = 0;
@@ -136,6 +148,18 @@ private:
     std::vector<uint32_t> row_slot_; // tile slot of (row, span 0) for the current layout
     int row_slot_rows_ = 0, row_slot_span_ = 0;
 };
+
+// A run of a stream's frames through the host stage, groups of pictures side by side: a coded key frame renews every bit of
+// decoder state (ScreenPressor.hx:108-115 + :117-295), so the frames from one coded key frame up to the next depend on
+// nothing before them and are decoded by a decoder of their own on a host thread of their own.  outs[i] is what
+// `stream_decoder` would have produced for frames[i] decoding them one after the other, and `stream_decoder` ends in the
+// state that run would leave it in (the decoder that took the last group takes its place).  A group whose key frame does
+// not decode (its failure leaves older state showing through) is re-run in order.  `literalise`: inter frames that move at
+// most a quarter of their pixels get literalise_motion() applied (what the staged batch's group launches need).
+struct HostFrame { const uint8_t* src; size_t n; bool key; };
+bool starts_group(const HostFrame& f);   // a coded key frame
+void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<HostDecoder>>& spare, const HostFrame* frames,
+                   int count, FrameOut* outs, int threads, bool literalise);
 
 // ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------
 struct IFrameArgs {    // one per frame of an intra launch (grid.x = frame, grid.y = band)

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_set>
 
 #include "codec.h"
@@ -55,7 +56,9 @@ struct SpStaged : jsp_staged {
 
 struct SpCodec : jsp_codec {
     HostDecoder host;
-    FrameOut frame_out;   // what the host stage says about the frame in hand (its tables keep their memory)
+    std::vector<FrameOut> outs;                          // what the host stage says about the frames in hand (their tables keep their memory)
+    std::vector<std::unique_ptr<HostDecoder>> spare;     // decoders for the groups of pictures of a batch decoded side by side
+    int opt_host_threads = 0;                            // 0 = auto
     SpCodec(int w, int h, int bpp) : host(w, h, bpp) {
         kind = JSP_CODEC_SCREENPRESSOR;
         X = w;
@@ -70,6 +73,14 @@ struct SpCodec : jsp_codec {
     int opt_band_rows = -1;   // -1: chosen per batch (choose_band_rows); 0: one band per frame; n: n rows per band
     bool opt_inter_fusion = true;   // consecutive inter frames of a staged batch share one launch
     int set_option(const char* key, const char* value) override {
+        if (std::strcmp(key, "sp_host_threads") == 0) {
+            if (std::strcmp(value, "auto") == 0) { opt_host_threads = 0; return 0; }
+            char* end = nullptr;
+            const long v = std::strtol(value, &end, 10);
+            if (end == value || *end || v < 1 || v > 64) return -1;
+            opt_host_threads = (int)v;
+            return 0;
+        }
         if (std::strcmp(key, "sp_inter_fusion") == 0) {
             if (std::strcmp(value, "on") == 0) { opt_inter_fusion = true; return 0; }
             if (std::strcmp(value, "off") == 0) { opt_inter_fusion = false; return 0; }
@@ -126,11 +137,23 @@ struct SpCodec : jsp_codec {
         // frame in size) and gets a launch of its own.
         const bool fuse_inter = opt_inter_fusion && nf - nkey >= 2;
         std::unordered_set<const void*> group_dsts;
-        FrameOut& fo = frame_out;
-        for (int i = 0; i < nf; ++i) {
+        // The host stage runs over the batch in waves: up to `threads` groups of pictures (a coded key frame and what follows it)
+        // side by side, at most 64 frames, then their tables are taken into the batch in stream order.
+        std::vector<HostFrame> hf(nf);
+        for (int i = 0; i < nf; ++i) hf[i] = HostFrame{frames[i].src, frames[i].n, frames[i].key};
+        int threads = opt_host_threads;
+        if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads); }
+        for (int w0 = 0; w0 < nf;) {
+            int w1 = w0 + 1, groups = 1;
+            while (w1 < nf && w1 - w0 < 64) {
+                if (starts_group(hf[w1])) { if (groups == threads) break; ++groups; }
+                ++w1;
+            }
+            if ((int)outs.size() < w1 - w0) outs.resize(w1 - w0);
+            decode_frames(host, spare, hf.data() + w0, w1 - w0, outs.data(), threads, fuse_inter);
+        for (int i = w0; i < w1; ++i) {
             const jsp_frame_in& f = frames[i];
-            if (f.key) host.decode_i(f.src, f.n, fo);
-            else host.decode_p(f.src, f.n, fo);
+            FrameOut& fo = outs[i - w0];
             st->status[i] = fo.status;
             st->adopted[i] = fo.adopted ? 1 : 0;
             st->significant[i] = fo.significant ? 1 : 0;
@@ -174,8 +197,7 @@ struct SpCodec : jsp_codec {
                 }
                 case FrameKind::Inter: {
                     group_dsts.clear();
-                    if (fuse_inter && fo.motion_pixels * 4 <= npx && blocks.size() < (1u << 31) && payload.size() < (1u << 31)) {
-                        host.literalise_motion(fo);
+                    if (fuse_inter && fo.literalised && blocks.size() < (1u << 31) && payload.size() < (1u << 31)) {
                         // (the group kernel relies on the block tables of a group's frames following each other)
                         const bool extend = !st->ops.empty() && st->ops.back().kind == SpStaged::Op::InterGroup &&
                                             (size_t)gframes.back().block_off + fo.blocks.size() == blocks.size();
@@ -198,6 +220,8 @@ struct SpCodec : jsp_codec {
                 case FrameKind::None: break;
             }
             if (fo.adopted) prev_dev = f.dst;
+        }
+            w0 = w1;
         }
         st->info.frames = nf;
         st->info.pixels = (uint64_t)g.X * g.Y * nf;

@@ -4,6 +4,7 @@
 #include "sp.h"
 
 #include <cstring>
+#include <thread>
 
 namespace jsp::sp {
 
@@ -32,11 +33,12 @@ bool HostDecoder::is_key_frame(const uint8_t* src, size_t n) {
 }
 
 bool HostDecoder::init_entropy(int version) {  // ScreenPressor.hx:66-79
+    version_ = version;
     switch (version) {
         case 2: ec_ = make_range_decoder(); break;
         case 3: ec_ = make_rans_decoder(64); cxshift_ = 2; break;
         case 4: ec_ = make_rans_decoder(32); cxshift_ = 2; break;
-        default: return false;
+        default: version_ = 0; return false;
     }
     use_bool_ = ec_->has_bool();
     return true;
@@ -470,6 +472,74 @@ void HostDecoder::literalise_motion(FrameOut& out) const {
             for (int y = by * 16 + pb.y1; y < by * 16 + pb.y2; ++y)
                 for (int x = bx * 16 + pb.x1; x < bx * 16 + pb.x2; ++x) out.payload.push_back((uint32_t)pic[(long)y * X + x]);
         }
+}
+
+
+// ---- groups of pictures side by side ---------------------------------------------------------------------------------
+namespace {
+void decode_one(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise) {
+    if (f.key) d.decode_i(f.src, f.n, out);
+    else d.decode_p(f.src, f.n, out);
+    const Geometry& g = d.geo();
+    if (literalise && out.kind == FrameKind::Inter && out.motion_pixels * 4 <= (uint64_t)g.X * g.Y) {
+        d.literalise_motion(out);
+        out.literalised = true;
+    }
+}
+}  // namespace
+bool starts_group(const HostFrame& f) { return f.key && f.n > 0 && (f.src[0] & 0xF) == 2; }   // a CODED key frame (flat ones renew nothing)
+
+void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<HostDecoder>>& spare, const HostFrame* frames,
+                   int count, FrameOut* outs, int threads, bool literalise) {
+    // groups: [0, first coded key frame) continues whatever the stream decoder holds; then one group per coded key frame
+    std::vector<int> begin;
+    begin.push_back(0);
+    for (int i = 1; i < count; ++i)
+        if (starts_group(frames[i])) begin.push_back(i);
+    begin.push_back(count);
+    const int ngroups = (int)begin.size() - 1;
+    // which entropy coder the later groups must start with: the stream's, or the one its first coded key frame picks
+    int version = stream_decoder.pinned_version();
+    for (int i = 0; i < count && version == 0; ++i)
+        if (starts_group(frames[i])) version = (frames[i].src[0] >> 4) + 1;
+    const bool side_by_side = threads > 1 && ngroups > 1 && version >= 2 && version <= 4;
+    if (!side_by_side) {
+        for (int i = 0; i < count; ++i) decode_one(stream_decoder, frames[i], outs[i], literalise);
+        return;
+    }
+    const Geometry g = stream_decoder.geo();
+    while ((int)spare.size() < ngroups - 1) spare.push_back(std::make_unique<HostDecoder>(g.X, g.Y, g.bpp));
+    auto decoder_of = [&](int grp) -> HostDecoder& { return grp == 0 ? stream_decoder : *spare[grp - 1]; };
+    std::vector<char> usable(ngroups, 1);
+    for (int grp = 1; grp < ngroups; ++grp) {
+        const HostDecoder& d = decoder_of(grp);
+        if (d.pinned_version() != 0 && d.pinned_version() != version) spare[grp - 1] = std::make_unique<HostDecoder>(g.X, g.Y, g.bpp);   // it served another coder
+        HostDecoder& e = decoder_of(grp);
+        e.adopt_settings(stream_decoder);
+        usable[grp] = e.pin_version(version) ? 1 : 0;
+    }
+    auto run_group = [&](int grp) {
+        if (!usable[grp]) return;
+        HostDecoder& d = decoder_of(grp);
+        for (int i = begin[grp]; i < begin[grp + 1]; ++i) decode_one(d, frames[i], outs[i], literalise);
+    };
+    {   // groups are dealt to the threads round robin; the calling thread takes its share
+        const int nthreads = threads < ngroups ? threads : ngroups;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t)
+            pool.emplace_back([&, t] { for (int grp = t; grp < ngroups; grp += nthreads) run_group(grp); });
+        for (int grp = 0; grp < ngroups; grp += nthreads) run_group(grp);
+        for (auto& th : pool) th.join();
+    }
+    // A group stands if its key frame decoded (then nothing older shows through it).  The first that does not — and
+    // everything behind it — is decoded again in order, by the decoder holding the state in front of it.
+    int last_good = 0;
+    for (int grp = 1; grp < ngroups; ++grp) {
+        if (!usable[grp] || outs[begin[grp]].status != 0) break;
+        last_good = grp;
+    }
+    if (last_good > 0) std::swap(stream_decoder, *spare[last_good - 1]);   // the stream goes on from the last group that stands
+    for (int i = begin[last_good + 1]; i < count; ++i) decode_one(stream_decoder, frames[i], outs[i], literalise);
 }
 
 }  // namespace jsp::sp

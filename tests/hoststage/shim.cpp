@@ -3,6 +3,8 @@
 // descriptor tables it emits can be checked on a machine without a GPU.  Not part of the product
 // and not linked into libjsplayer_amd.so.
 #include <cstring>
+#include <memory>
+#include <vector>
 #include "../../jsplayer_amd/csrc/msv1.h"
 #include "../../jsplayer_amd/csrc/sp.h"
 
@@ -11,6 +13,8 @@ using namespace jsp::sp;
 struct Shim {
     HostDecoder host;
     FrameOut out;
+    std::vector<FrameOut> outs;                          // hs_decode_batch
+    std::vector<std::unique_ptr<HostDecoder>> spare;
     Shim(int w, int h, int bpp) : host(w, h, bpp) {}
 };
 
@@ -41,6 +45,27 @@ int hs_decode(void* p, int key, const uint8_t* src, size_t n, uint64_t* meta) {
     meta[4] = o.runs.size(); meta[5] = o.row_run.size(); meta[6] = o.blocks.size(); meta[7] = o.payload.size();
     meta[8] = o.flat_colour; meta[9] = o.prev_pixels; meta[10] = o.data_pixels; meta[11] = o.stream_bytes;
     return o.status;
+}
+static void fill_meta(const FrameOut& o, uint64_t* meta) {
+    meta[0] = (uint64_t)o.kind; meta[1] = o.adopted; meta[2] = o.significant; meta[3] = o.prev_cleared;
+    meta[4] = o.runs.size(); meta[5] = o.row_run.size(); meta[6] = o.blocks.size(); meta[7] = o.payload.size();
+    meta[8] = o.flat_colour; meta[9] = o.prev_pixels; meta[10] = o.data_pixels; meta[11] = o.stream_bytes;
+}
+// decode_frames(): a run of frames, groups of pictures side by side on `threads` host threads; results kept for hs_select
+void hs_decode_batch(void* p, int n, const uint8_t* const* srcs, const size_t* lens, const uint8_t* keys, int threads, int literalise) {
+    auto* s = (Shim*)p;
+    std::vector<HostFrame> hf(n);
+    for (int i = 0; i < n; ++i) hf[i] = HostFrame{srcs[i], lens[i], keys[i] != 0};
+    s->outs.assign(n, FrameOut{});
+    decode_frames(s->host, s->spare, hf.data(), n, s->outs.data(), threads, literalise != 0);
+}
+// make frame i of the last batch "the frame just decoded" for the hs_fetch* calls; returns its status, meta as hs_decode
+int hs_select(void* p, int i, uint64_t* meta) {
+    auto* s = (Shim*)p;
+    s->out = s->outs[i];
+    fill_meta(s->out, meta);
+    meta[12] = s->out.literalised;
+    return s->out.status;
 }
 // rewrite the motion rectangles of the inter frame just decoded as literal ones; meta as hs_decode
 void hs_literalise_motion(void* p, uint64_t* meta) {

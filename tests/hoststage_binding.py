@@ -34,6 +34,8 @@ def lib():
         L.hs_error.argtypes = [C.c_void_p]
         L.hs_literalise_motion.argtypes = [C.c_void_p, C.c_void_p]
         L.hs_set_iframe_layout.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.hs_decode_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.hs_select.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hs_tile_words.restype = C.c_size_t
         L.hs_tile_words.argtypes = [C.c_void_p, C.c_int]
         L.hs_fetch_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -61,11 +63,30 @@ class HostStage:
         self.band_rows, self.span_px = rows, span
         self.L.hs_set_iframe_layout(self.h, rows, span)
 
+    def decode_batch(self, frames, keys, threads: int, literalise: bool = False):
+        """HostDecoder-level decode_frames(): the frames of a stream, groups of pictures side by side; one dict per frame as
+        decode() returns (plus `literalised`)."""
+        n = len(frames)
+        keep = [bytes(f) for f in frames]
+        srcs = (C.c_char_p * n)(*keep)
+        lens = (C.c_size_t * n)(*[len(f) for f in keep])
+        self.L.hs_decode_batch(self.h, n, srcs, lens, bytes(bytearray(1 if k else 0 for k in keys)), threads, 1 if literalise else 0)
+        outs = []
+        for i in range(n):
+            meta = np.zeros(16, dtype=np.uint64)
+            status = self.L.hs_select(self.h, i, meta.ctypes.data)
+            d = self._fetch(status, [int(v) for v in meta])
+            d["literalised"] = bool(meta[12])
+            outs.append(d)
+        return outs
+
     def decode(self, key: bool, src: bytes):
         meta = np.zeros(12, dtype=np.uint64)
         src = bytes(src)
         status = self.L.hs_decode(self.h, 1 if key else 0, src, len(src), meta.ctypes.data)
-        m = [int(v) for v in meta]
+        return self._fetch(status, [int(v) for v in meta])
+
+    def _fetch(self, status, m):
         out = dict(status=status, error=self.L.hs_error(self.h).decode(), kind=m[0], adopted=bool(m[1]), significant=bool(m[2]), prev_cleared=bool(m[3]),
                    flat_colour=m[8], prev_pixels=m[9], data_pixels=m[10], stream_bytes=m[11])
         runs = np.zeros((m[4], 2), dtype=np.uint32)

@@ -199,3 +199,60 @@ def test_truncated_streams_agree(version):
         assert (rc == 0) == (d["status"] == 0), (version, cut, rc, d["status"])
         if rc == 0:
             assert np.array_equal(hs.expand_iframe(d, w, h), dst.view(np.uint32))
+
+
+def _same_frame(a, b, tag):
+    for k in ("status", "kind", "adopted", "significant", "prev_cleared", "flat_colour", "prev_pixels", "data_pixels", "stream_bytes"):
+        assert a[k] == b[k], (tag, k, a[k], b[k])
+    for k in ("runs", "rows", "blocks", "payload", "seeds", "tile_idx", "left"):
+        assert np.array_equal(a[k], b[k]), (tag, k)
+
+
+@pytest.mark.parametrize("version", [2, 4])
+@pytest.mark.parametrize("threads", [2, 5])
+def test_groups_of_pictures_side_by_side_equal_one_by_one(version, threads):
+    """decode_frames(): the frames between one coded key frame and the next are decoded by a decoder of their own on a host
+    thread of their own; every table of every frame, and the state the stream's decoder is left in, must be what decoding
+    the frames one after the other gives — with flat key frames and unchanged frames inside the groups, inter frames in
+    front of the first key frame, a key frame that does not decode (its group and the rest fall back to decoding in order)
+    and a second batch continuing the first."""
+    w, h = 320, 240
+    chunks, keys, _ = sg.sp_clip(61, w, h, 26, version=version, key_every=4, flat_at=(9, 10), unchanged_at=(2, 14))
+    chunks, keys = list(chunks), list(keys)
+    tail, tail_keys = chunks[20:], keys[20:]
+    cases = {
+        "plain": (chunks[:20], keys[:20]),
+        "starts with inter frames": (chunks[1:20], keys[1:20]),
+        "broken key frame": (chunks[:12] + [chunks[12][:len(chunks[12]) // 3]] + chunks[13:20], keys[:20]),
+    }
+    for name, (fr, ks) in cases.items():
+        assert sum(ks) >= 4
+        seq, par = hs.HostStage(w, h, 24), hs.HostStage(w, h, 24)
+        for d in (seq, par):
+            d.preinit(36)
+            d.set_iframe_layout(24, 256)
+        one = [seq.decode(k, f) for f, k in zip(fr, ks)]
+        side = par.decode_batch(fr, ks, threads)
+        for i, (a, b) in enumerate(zip(one, side)):
+            _same_frame(a, b, (name, i))
+        # the stream goes on: the decoder the batch left behind continues like the one that saw every frame
+        one2 = [seq.decode(k, f) for f, k in zip(tail, tail_keys)]
+        side2 = par.decode_batch(tail, tail_keys, threads)
+        for i, (a, b) in enumerate(zip(one2, side2)):
+            _same_frame(a, b, (name, "continued", i))
+        seq.close()
+        par.close()
+
+
+def test_side_by_side_literalises_what_one_by_one_does():
+    w, h = 320, 240
+    chunks, keys, _ = sg.sp_clip(62, w, h, 12, version=4, key_every=3, p_mix_at={i: dict(unchanged=0.5, motion=0.1) for i in range(12)})
+    seq, par = hs.HostStage(w, h, 24), hs.HostStage(w, h, 24)
+    side = par.decode_batch(chunks, keys, 3, literalise=True)
+    for i, (f, k) in enumerate(zip(chunks, keys)):
+        a = seq.decode(k, f)
+        if a["kind"] == hs.KIND_INTER and side[i]["literalised"]:
+            a = seq.literalise_motion(a)
+        _same_frame(a, side[i], i)
+    seq.close()
+    par.close()
