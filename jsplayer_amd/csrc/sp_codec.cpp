@@ -223,6 +223,7 @@ struct SpCodec : jsp_codec {
         }
             w0 = w1;
         }
+        if (outs.size() > 1) outs.resize(1);   // (a wave's worth of frame tables is hundreds of MB: only the per-frame calls' one stays)
         st->info.frames = nf;
         st->info.pixels = (uint64_t)g.X * g.Y * nf;
         st->info.kernel_launches = st->ops.size();
