@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <deque>
@@ -231,12 +232,71 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
     return failed ? -1 : done;
 }
 
+// --batch B: the file through the batch calls (jsp_stage_batch / jsp_staged_decode), B frames at a time, every frame of a batch
+// into a buffer of its own.  Prints what each frame shows as "<index> <key|inter> <adopted> <crc32>" (a frame that changes
+// nothing shows the picture before it), or with --quiet plays the file `repeat` times and returns the frames decoded.
+long play_batched(const Clip& clip, int batch, int repeat, bool quiet, int warmup = 0, double* seconds = nullptr) {
+    jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
+                                      (int)clip.palette.size(), 0);
+    if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return -1; }
+    jsp_preinit(dec, kInsignificantLines);
+    if (clip.kind != JSP_CODEC_SCREENPRESSOR) jsp_set_option(dec, "msv1_parse", "gpu");
+    jsp_pool* pool = jsp_pool_create(0, clip.X, clip.Y, batch + 1);     // + the picture carried over from the batch before
+    if (!pool) { std::fprintf(stderr, "jsp_pool_create: %s\n", jsp_last_error()); jsp_codec_destroy(dec); return -1; }
+    const size_t npx = (size_t)clip.X * clip.Y;
+    std::vector<int32_t> host(quiet ? 0 : npx);
+    std::vector<const uint8_t*> srcs(batch);
+    std::vector<size_t> lens(batch);
+    std::vector<uint8_t> keys(batch);
+    std::vector<int32_t*> dsts(batch);
+    std::vector<int> status(batch), adopted(batch), signif(batch);
+    long done = 0;
+    bool failed = false;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int rep = -warmup; rep < repeat && !failed; ++rep) {
+        if (rep == 0) { t0 = std::chrono::steady_clock::now(); done = 0; }   // (untimed passes first: buffers, clocks)
+        int carry = batch;                                  // pool slot holding the last picture of the batch before (none yet: unused)
+        bool have_picture = false;
+        for (size_t f0 = 0; f0 < clip.frames.size() && !failed; f0 += batch) {
+            const int n = (int)std::min<size_t>(batch, clip.frames.size() - f0);
+            int slot = 0;
+            for (int i = 0; i < n; ++i) {
+                if (slot == carry) ++slot;                  // the picture the first inter frames are decoded against stays
+                srcs[i] = clip.bytes.data() + clip.frames[f0 + i].first;
+                lens[i] = clip.frames[f0 + i].second;
+                keys[i] = frame_is_key(clip, dec, f0 + i) ? 1 : 0;
+                dsts[i] = jsp_pool_buffer(pool, slot++);
+            }
+            jsp_staged* st = jsp_stage_batch(dec, n, srcs.data(), lens.data(), keys.data(), dsts.data());
+            if (!st) { std::fprintf(stderr, "jsp_stage_batch: %s\n", jsp_last_error()); failed = true; break; }
+            if (jsp_staged_decode(dec, st) != 0 || jsp_sync(dec) != 0) { std::fprintf(stderr, "decode: %s\n", jsp_last_error()); failed = true; }
+            jsp_staged_results(st, status.data(), adopted.data(), signif.data());
+            jsp_staged_destroy(st);
+            const int32_t* shown = have_picture ? jsp_pool_buffer(pool, carry) : nullptr;
+            for (int i = 0; i < n && !failed; ++i) {
+                if (adopted[i]) { shown = dsts[i]; have_picture = true; }
+                ++done;
+                if (quiet) continue;
+                uint32_t crc = 0;
+                if (shown && jsp_download(shown, host.data(), npx) == 0) crc = crc32(reinterpret_cast<const uint8_t*>(host.data()), npx * 4);
+                std::printf("%zu %s %d %08x\n", f0 + i, keys[i] ? "key" : "inter", adopted[i], crc);
+            }
+            if (shown)
+                for (int k = 0; k <= batch; ++k) if (jsp_pool_buffer(pool, k) == shown) carry = k;
+        }
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    jsp_pool_destroy(pool);
+    jsp_codec_destroy(dec);
+    return failed ? -1 : done;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R] [--warmup W]]]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R] [--warmup W]]] | --batch B [--quiet [--repeat R]]\n", argv[0]); return 2; }
     Clip clip;
     if (!load(argv[1], clip)) { std::fprintf(stderr, "%s: not a RIFF/AVI file this player understands\n", argv[1]); return 2; }
     bool pipelined = false, quiet = false;
-    int depth = 4, streams = 1, repeat = 1, warmup = 1;
+    int depth = 4, streams = 1, repeat = 1, warmup = 1, batch = 0;
     for (int a = 2; a < argc; ++a) {
         const std::string o = argv[a];
         if (o == "--pipelined") pipelined = true;
@@ -245,7 +305,18 @@ int main(int argc, char** argv) {
         else if (o == "--streams" && a + 1 < argc) streams = std::atoi(argv[++a]);
         else if (o == "--repeat" && a + 1 < argc) repeat = std::atoi(argv[++a]);
         else if (o == "--warmup" && a + 1 < argc) warmup = std::atoi(argv[++a]);
+        else if (o == "--batch" && a + 1 < argc) batch = std::atoi(argv[++a]);
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
+    }
+    if (batch > 0) {
+        batch = batch > 1024 ? 1024 : batch;
+        if (!quiet) return play_batched(clip, batch, 1, false) < 0 ? 1 : 0;
+        double sec = 0;
+        const long frames = play_batched(clip, batch, repeat, true, warmup, &sec);
+        if (frames < 0) return 1;
+        std::printf("{\"batch\": %d, \"frames\": %ld, \"seconds\": %.6f, \"mpixels_per_s\": %.1f}\n", batch, frames, sec,
+                    frames * (double)clip.X * clip.Y / sec / 1e6);
+        return 0;
     }
     if (pipelined) {
         depth = depth < 1 ? 1 : (depth > 16 ? 16 : depth);

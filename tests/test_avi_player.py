@@ -262,6 +262,38 @@ def test_cpp_player_over_the_c_abi(what, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("what", ["msvc16", "msvc8", "screenpressor"])
+@pytest.mark.parametrize("batch", [1, 7, 64])
+def test_cpp_player_batched_shows_the_same_pictures(what, batch, tmp_path):
+    """examples/jsp_play --batch B: the file through jsp_stage_batch / jsp_staged_decode, B frames at a time (for
+    ScreenPressor the host stage takes the batch's groups of pictures side by side), shows frame for frame the picture
+    the synchronous loop shows."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "jsp_play")
+    if what == "screenpressor":
+        chunks, keys, _ = sg.sp_clip(33, 320, 240, 20, version=4, key_every=4, unchanged_at=(2, 9), flat_at=(6,))
+        blob = avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys)
+    else:
+        bits = 16 if what == "msvc16" else 8
+        frames, pal = config0_clip(bits, 30)
+        probe = ORACLE_CLASSES[0](320, 240) if bits == 16 else ORACLE_CLASSES[1](320, 240, pal)
+        blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=bits, palette=pal,
+                             key_flags=[i == 0 or probe.IsKeyFrame(f) for i, f in enumerate(frames)])
+    path = tmp_path / "clip.avi"
+    path.write_bytes(blob)
+    outs = []
+    for extra in ([], ["--batch", str(batch)]):
+        res = subprocess.run([exe, str(path)] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert res.returncode == 0, res.stderr.decode()
+        outs.append([l.split() for l in res.stdout.decode().splitlines()])
+    assert len(outs[0]) == len(outs[1]) > 0
+    for a, b in zip(*outs):
+        assert (a[0], a[1], a[-1]) == (b[0], b[1], b[-1]), (a, b)   # index, key / inter, CRC-32 of the picture shown
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["msvc16", "msvc8", "screenpressor"])
 def test_cpp_player_pipelined_shows_the_same_pictures(what, tmp_path):
     """examples/jsp_play --pipelined: the same loop over jsp_decompress_*_async / jsp_wait with three frames in flight and
     the file's bytes in pinned memory shows, frame for frame, what the synchronous loop shows (the pool is larger, so slot
