@@ -252,6 +252,7 @@ long play_batched(const Clip& clip, int batch, int repeat, bool quiet, int warmu
     std::vector<int> status(batch), adopted(batch), signif(batch);
     long done = 0;
     bool failed = false;
+    jsp_staged* st = nullptr;
     auto t0 = std::chrono::steady_clock::now();
     for (int rep = -warmup; rep < repeat && !failed; ++rep) {
         if (rep == 0) { t0 = std::chrono::steady_clock::now(); done = 0; }   // (untimed passes first: buffers, clocks)
@@ -267,11 +268,12 @@ long play_batched(const Clip& clip, int batch, int repeat, bool quiet, int warmu
                 keys[i] = frame_is_key(clip, dec, f0 + i) ? 1 : 0;
                 dsts[i] = jsp_pool_buffer(pool, slot++);
             }
-            jsp_staged* st = jsp_stage_batch(dec, n, srcs.data(), lens.data(), keys.data(), dsts.data());
-            if (!st) { std::fprintf(stderr, "jsp_stage_batch: %s\n", jsp_last_error()); failed = true; break; }
+            jsp_staged* next = st ? jsp_restage_batch(dec, st, n, srcs.data(), lens.data(), keys.data(), dsts.data())
+                                  : jsp_stage_batch(dec, n, srcs.data(), lens.data(), keys.data(), dsts.data());
+            if (!next) { std::fprintf(stderr, "jsp_stage_batch: %s\n", jsp_last_error()); failed = true; break; }
+            st = next;                                      // one batch object for the whole file: its buffers are taken over
             if (jsp_staged_decode(dec, st) != 0 || jsp_sync(dec) != 0) { std::fprintf(stderr, "decode: %s\n", jsp_last_error()); failed = true; }
             jsp_staged_results(st, status.data(), adopted.data(), signif.data());
-            jsp_staged_destroy(st);
             const int32_t* shown = have_picture ? jsp_pool_buffer(pool, carry) : nullptr;
             for (int i = 0; i < n && !failed; ++i) {
                 if (adopted[i]) { shown = dsts[i]; have_picture = true; }
@@ -286,6 +288,7 @@ long play_batched(const Clip& clip, int batch, int repeat, bool quiet, int warmu
         }
     }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st) jsp_staged_destroy(st);
     jsp_pool_destroy(pool);
     jsp_codec_destroy(dec);
     return failed ? -1 : done;

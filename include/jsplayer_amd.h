@@ -175,6 +175,12 @@ int jsp_decompress_i_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs
  * any number of times into the same `dsts`. */
 jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs,
                             const size_t* lens, const uint8_t* is_key, int32_t* const* dsts);
+/* The same into an existing batch object, whose pinned and device buffers are taken over (a caller that stages batch after
+ * batch: no allocation per batch).  Every decode of `reuse` must have finished (jsp_sync).  Returns the batch to use from
+ * now on — `reuse` itself, or a new object when `reuse` was of a kind that cannot hold this batch (then it has been
+ * destroyed) —, NULL on error (`reuse` stays valid). */
+jsp_staged* jsp_restage_batch(jsp_codec* c, jsp_staged* reuse, int nframes, const uint8_t* const* srcs,
+                              const size_t* lens, const uint8_t* is_key, int32_t* const* dsts);
 int jsp_staged_decode(jsp_codec* c, jsp_staged* s);
 void jsp_staged_destroy(jsp_staged* s);
 

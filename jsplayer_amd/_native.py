@@ -72,6 +72,8 @@ SIGNATURES = {
                                          C.POINTER(C.c_void_p)]),
     "jsp_stage_batch": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                      C.c_void_p, C.POINTER(C.c_void_p)]),
+    "jsp_restage_batch": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                       C.c_void_p, C.POINTER(C.c_void_p)]),
     "jsp_staged_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jsp_staged_destroy": (None, [C.c_void_p]),
     "jsp_staged_get_info": (C.c_int, [C.c_void_p, C.POINTER(StagedInfo)]),

@@ -195,7 +195,10 @@ class _NativeCodec:
         if self._lib.jsp_sync(self._h) != 0:
             raise CodecError(N.last_error())
 
-    def stage_batch(self, srcs: Sequence, dsts: Sequence, is_key: Optional[Sequence[bool]] = None) -> "StagedBatch":
+    def stage_batch(self, srcs: Sequence, dsts: Sequence, is_key: Optional[Sequence[bool]] = None,
+                    reuse: Optional["StagedBatch"] = None) -> "StagedBatch":
+        """jsp_stage_batch; with `reuse` (a batch of this codec whose decodes have finished) jsp_restage_batch: the batch
+        object's buffers are taken over, `reuse` itself is returned, now holding this batch."""
         n = len(srcs)
         if len(dsts) != n:
             raise CodecError("srcs and dsts differ in length")
@@ -210,6 +213,13 @@ class _NativeCodec:
             self._bufs[addr] = d
             dptrs[i] = addr
         keys = bytes(bytearray(1 if k else 0 for k in is_key)) if is_key is not None else None
+        if reuse is not None and reuse._h:
+            h = self._lib.jsp_restage_batch(self._h, reuse._h, n, ptrs, lens, keys, dptrs)
+            if not h:
+                raise CodecError(N.last_error())
+            self._track_prev()
+            reuse._h, reuse.n, reuse._dsts = h, n, list(dsts)
+            return reuse
         h = self._lib.jsp_stage_batch(self._h, n, ptrs, lens, keys, dptrs)
         if not h:
             raise CodecError(N.last_error())

@@ -370,8 +370,21 @@ int jsp_sync(jsp_codec* c) {
     });
 }
 
+namespace {
+jsp_staged* stage_batch_into(jsp_codec* c, jsp_staged* reuse, int nframes, const uint8_t* const* srcs, const size_t* lens,
+                             const uint8_t* is_key, int32_t* const* dsts);
+}
 jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs, const size_t* lens,
                             const uint8_t* is_key, int32_t* const* dsts) {
+    return stage_batch_into(c, nullptr, nframes, srcs, lens, is_key, dsts);
+}
+jsp_staged* jsp_restage_batch(jsp_codec* c, jsp_staged* reuse, int nframes, const uint8_t* const* srcs, const size_t* lens,
+                              const uint8_t* is_key, int32_t* const* dsts) {
+    return stage_batch_into(c, reuse, nframes, srcs, lens, is_key, dsts);
+}
+namespace {
+jsp_staged* stage_batch_into(jsp_codec* c, jsp_staged* reuse, int nframes, const uint8_t* const* srcs, const size_t* lens,
+                             const uint8_t* is_key, int32_t* const* dsts) {
     try {
         if (!c || nframes < 0 || (nframes && (!srcs || !lens || !dsts))) throw std::runtime_error("null argument");
         c->activate();
@@ -383,7 +396,8 @@ jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* src
         }
         if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
         if (nframes) c->ptr_mode = 1;
-        jsp_staged* st = c->stage(frames, nullptr);
+        jsp_staged* st = c->stage(frames, reuse);
+        if (reuse && st != reuse) delete reuse;       // (a batch object of another kind: replaced)
         for (int i = 0; i < nframes; ++i) {
             if (!st->cleared.empty() && st->cleared[i]) c->prev_caller = nullptr;
             if (st->adopted[i]) c->prev_caller = dsts[i];
@@ -394,6 +408,7 @@ jsp_staged* jsp_stage_batch(jsp_codec* c, int nframes, const uint8_t* const* src
         return nullptr;
     }
 }
+}  // namespace
 
 int jsp_staged_decode(jsp_codec* c, jsp_staged* s) {
     return guarded([&] {
