@@ -308,3 +308,53 @@ def test_wide_frames_use_the_other_kernel_instantiations(size):
     w, h = size
     chunks, keys, frames = sg.sp_clip(980, w, h, 4, version=4, rects=30, gradients=8)
     drive_pair(w, h, 24, chunks, keys, frames)
+
+
+@pytest.mark.gpu
+def test_batches_staged_into_one_batch_object():
+    """jsp_restage_batch (stage_batch(reuse=)): a clip taken in three batches of different sizes through ONE batch object —
+    its pinned and device buffers taken over each time, the host stage of every batch with its groups of pictures side by
+    side — leaves the frames the encoder was given; also for MSVideo1 against the oracle."""
+    w, h = 640, 360
+    chunks, keys, frames = sg.sp_clip(994, w, h, 30, version=4, key_every=4, unchanged_at=(5, 17), flat_at=(9,))
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    dsts = [dev_buf(w * h, -1) for _ in range(30)]
+    st = None
+    for lo, hi in ((0, 7), (7, 23), (23, 30)):
+        st = gpu.stage_batch(chunks[lo:hi], dsts[lo:hi], is_key=keys[lo:hi], reuse=st)
+        st.decode()
+        gpu.sync()
+        status, adopted, _ = st.results()
+        assert all(s == 0 for s in status)
+        for i in range(lo, hi):
+            if adopted[i - lo]:
+                assert np.array_equal(to_np(dsts[i]).view(np.uint32), frames[i]), f"frame {i}"
+    st.close()
+    from jsplayer_amd import MSVideo1_16bit
+    from oracle_binding import OracleMSVideo1
+    mf, mk, _ = sg.msv1_clip(995, w, h, 12, p_mix=sg.msv1_p_mix(0.6, 10.0), key_every=5)
+    g16, orc = MSVideo1_16bit(w, h), OracleMSVideo1(16, w, h)
+    g16.set_option("msv1_parse", "gpu")
+    want = []
+    prev = None
+    for f, k in zip(mf, mk):
+        buf = np.full(w * h, -1, dtype=np.int32) if prev is None else prev.copy()
+        if k:
+            orc.DecompressI(f, buf)
+        else:
+            orc.DecompressP(f, buf)
+        p = orc.PreviousFrame()
+        prev = p if p is not None else buf
+        want.append(prev.copy())
+    md = [dev_buf(w * h, -1) for _ in range(12)]
+    st = None
+    for lo, hi in ((0, 5), (5, 12)):
+        st = g16.stage_batch(mf[lo:hi], md[lo:hi], is_key=mk[lo:hi], reuse=st)
+        st.decode()
+        g16.sync()
+        _, adopted, _ = st.results()
+        for i in range(lo, hi):
+            if adopted[i - lo]:
+                assert np.array_equal(to_np(md[i]), want[i]), f"msvideo1 frame {i}"
+    st.close()
