@@ -521,7 +521,12 @@ void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<Host
     auto run_group = [&](int grp) {
         if (!usable[grp]) return;
         HostDecoder& d = decoder_of(grp);
-        for (int i = begin[grp]; i < begin[grp + 1]; ++i) decode_one(d, frames[i], outs[i], literalise);
+        try {
+            for (int i = begin[grp]; i < begin[grp + 1]; ++i) decode_one(d, frames[i], outs[i], literalise);
+        } catch (...) {            // (out of memory on a thread of its own must not end the process: the group is decoded again, in order)
+            if (grp > 0) usable[grp] = 0;
+            else throw;
+        }
     };
     {   // groups are dealt to the threads round robin; the calling thread takes its share
         const int nthreads = threads < ngroups ? threads : ngroups;
