@@ -109,7 +109,7 @@ int jsp_upload(int32_t* device_frame, const int32_t* host, size_t npixels);
  * of the codec's own stream.  NULL restores the codec's own stream. */
 int jsp_set_stream(jsp_codec* c, void* hip_stream);
 /* Codec options.  Returns 0 when accepted, -1 for an unknown key/value.
- *   "msv1_parse" = "host" (default) | "gpu" : MSVideo1 only.  "gpu" builds the per-block descriptor
+ *   "msv1_parse" = "gpu" (default) | "host" : MSVideo1 only.  "gpu" builds the per-block descriptor
  *       table with the on-GPU parse kernels (raw frame bytes are all the device needs; a replay of a
  *       staged batch re-runs the parse); frames the parse flags as special fall back to the host
  *       parser one by one, so results are identical either way.

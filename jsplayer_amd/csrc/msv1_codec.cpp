@@ -198,7 +198,7 @@ struct Msv1Codec : jsp_codec {
     std::vector<uint8_t> palette_bytes;
     int32_t palette[256];
     DeviceBuffer d_palette;
-    bool opt_gpu_parse = false;
+    bool opt_gpu_parse = true;    // "msv1_parse": frames are parsed on the GPU unless the caller asks for the host parser
     bool opt_scrub_tables = false;
     bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
     bool counted_async = false;   // this instance is in g_async_streams

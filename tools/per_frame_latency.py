@@ -26,10 +26,10 @@ def run(name, codec, chunks, keys, reps=3):
     print(f"{name:55s} {best / n * 1e3:8.3f} ms/frame  {n * w * h / best / 1e6:10.0f} Mpx/s")
 
 frames, keys, _ = sg.msv1_clip(2, w, h, 32)
-c = MSVideo1_16bit(w, h); run("MSVideo1 key frames, host parse, per-frame calls", c, frames, [True] * 32)
+c = MSVideo1_16bit(w, h); c.set_option("msv1_parse", "host"); run("MSVideo1 key frames, host parse, per-frame calls", c, frames, [True] * 32)
 c = MSVideo1_16bit(w, h); c.set_option("msv1_parse", "gpu"); run("MSVideo1 key frames, on-GPU parse, per-frame calls", c, frames, [True] * 32)
 frames, keys, _ = sg.msv1_clip(2, w, h, 32, p_mix=sg.msv1_p_mix(0.7, 40.0))
-c = MSVideo1_16bit(w, h); run("MSVideo1 70% skipped inter frames, host parse", c, frames, keys)
+c = MSVideo1_16bit(w, h); c.set_option("msv1_parse", "host"); run("MSVideo1 70% skipped inter frames, host parse", c, frames, keys)
 c = MSVideo1_16bit(w, h); c.set_option("msv1_parse", "gpu"); run("MSVideo1 70% skipped inter frames, on-GPU parse", c, frames, keys)
 chunks, keys, _ = sg.sp_clip(4, w, h, 24, version=4)
 c = ScreenPressor(w, h, 24); run("ScreenPressor v4 clip (1 key + 23 inter), per-frame calls", c, chunks, keys, reps=1)
