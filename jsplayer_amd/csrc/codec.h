@@ -98,6 +98,9 @@ struct jsp_codec {
     // staging): every earlier frame still in flight is then settled first — re-run, if the GPU could not settle it —
     // because the caller may already have handed this frame a buffer an earlier frame's re-run still reads.
     virtual bool async_settle_first(const jsp_frame_in&) { return false; }
+    // True when the synchronous calls are better served by submit + wait on the asynchronous path (one launch that settles
+    // the frame by itself) than by the batch staging of one frame (parse at staging, a wait, then the decode launch).
+    virtual bool sync_through_async() const { return false; }
     // Called (stream idle) before frames are re-run through the synchronous path: undo whatever made the frames in
     // flight behind the failed one stand still.
     virtual void async_reset() {}

@@ -329,6 +329,7 @@ struct Msv1Codec : jsp_codec {
                f.n + msv1_parse_tile_bytes() > 0xFFFFFFF0u || (geo.bits == 8 && !d_palette.p);
     }
     bool async_settle_first(const jsp_frame_in& f) override { return sync_staging(f, prescan(f.src, f.n)); }
+    bool sync_through_async() const override { return opt_gpu_parse; }
 
     jsp_staged* stage_async(const jsp_frame_in& f, jsp_staged* reuse) override {
         activate();
