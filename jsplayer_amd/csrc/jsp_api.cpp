@@ -24,6 +24,10 @@ using namespace jsp;
 // ---- jsp_codec common parts ---------------------------------------------------------------
 
 jsp_codec::~jsp_codec() {
+    if (next_ticket != oldest_ticket) {   // frames still in flight (never waited for): their kernels write the buffers freed below
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+    }
     for (auto& j : jobs) {
         j.st.reset();
         if (j.done) (void)hipEventDestroy(j.done);

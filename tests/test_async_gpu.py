@@ -183,3 +183,21 @@ def test_async_usage_errors():
     with pytest.raises(CodecError):
         gpu.DecompressI_async(frames[0], np.zeros(w * h, dtype=np.int32))   # host frame buffers are for the synchronous calls
     gpu.StopAndClean()
+
+
+@pytest.mark.gpu
+def test_codec_destroyed_with_frames_in_flight():
+    """StopAndClean with tickets never waited for: the kernels of the frames in flight still write the codec's own buffers
+    (the report in pinned memory, the stream copy in HBM); destruction waits for them first."""
+    import torch
+    w, h = 1920, 1080
+    frames, keys, _ = sg.msv1_clip(59, w, h, 6)
+    for _ in range(3):
+        gpu = MSVideo1_16bit(w, h)
+        gpu.Preinit(36)
+        gpu.set_option("async_depth", "8")
+        bufs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(6)]
+        for f, b in zip(frames, bufs):
+            gpu.DecompressI_async(f, b)
+        gpu.StopAndClean()
+    torch.cuda.synchronize()
