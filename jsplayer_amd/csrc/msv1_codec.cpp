@@ -787,13 +787,40 @@ struct Msv1Codec : jsp_codec {
                         r.signif = h_frames[i].signif;
                         r.pad = 0;
                     }
+                // Launch order: tile-major over the frames of a launch — tile j of every frame before tile j + 1 of any — so that
+                // when a tile starts, its predecessor in the frame is long done and has published where the chain stands (the
+                // kernel's one-word look-back).  A launch covers the contiguous record range of its frames; the records are
+                // permuted inside that range (a record carries its own byte offset and its number in stream order).
+                auto tile_major = [&](Msv1TileRec* rr, int f0, int f1) {   // frames [f0, f1)
+                    if (f1 - f0 < 2) return;
+                    const uint32_t t0 = h_pf[f0].first_tile, t1 = h_pf[f1 - 1].first_tile + h_pf[f1 - 1].ntiles;
+                    std::vector<Msv1TileRec> tmp(rr + t0, rr + t1);
+                    uint32_t maxt = 0, o = t0;
+                    for (int i = f0; i < f1; ++i) maxt = std::max(maxt, h_pf[i].ntiles);
+                    for (uint32_t j = 0; j < maxt; ++j)
+                        for (int i = f0; i < f1; ++i)
+                            if (j < h_pf[i].ntiles) rr[o++] = tmp[h_pf[i].first_tile - t0 + j];
+                };
+                for (const auto& g : st->groups)
+                    if (g.fused) tile_major(recs, g.first, g.first + g.count);
                 JSP_HIP(hipMemcpyAsync(st->d_recs.p, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
                 if (st->needs_desc) {   // the same records for the descriptor form: `dst` = the frame's block table; frames whose
                                         // table nobody reads (fused groups) or that came from the host parser are skipped
                     st->h_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
                     st->d_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
                     auto* er = static_cast<Msv1TileRec*>(st->h_recs_emit.p);
-                    std::memcpy(er, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles);
+                    for (int i = 0; i < nf; ++i)                     // (from the frames again: `recs` is in launch order by now)
+                        for (uint32_t k = 0; k < h_pf[i].ntiles; ++k) {
+                            Msv1TileRec& r = er[h_pf[i].first_tile + k];
+                            r.byte0 = h_pf[i].beg + k * tile_bytes;
+                            r.frame_end = h_pf[i].end;
+                            r.data_end = geo.bits == 16 ? h_pf[i].end : h_frames[i].stream_end;
+                            r.k = k;
+                            r.first_tile = h_pf[i].first_tile;
+                            r.ntiles = h_pf[i].ntiles;
+                            r.signif = h_frames[i].signif;
+                            r.pad = 0;
+                        }
                     std::vector<uint8_t> in_fused(nf, 0);
                     for (const auto& g : st->groups)
                         if (g.fused) std::fill(in_fused.begin() + g.first, in_fused.begin() + g.first + g.count, 1);
@@ -805,6 +832,7 @@ struct Msv1Codec : jsp_codec {
                             r.cmp_row_lo = 0xFFFFFFFFu;
                             r.flags = (h_pf[i].host_parsed || in_fused[i]) ? MSV1_TILE_SKIP : 0u;
                         }
+                    tile_major(er, 0, nf);
                     JSP_HIP(hipMemcpyAsync(st->d_recs_emit.p, er, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
                     st->scrub.clear();
                     if (opt_scrub_tables)

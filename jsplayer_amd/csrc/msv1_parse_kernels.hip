@@ -24,13 +24,17 @@
 #include <cstdlib>
 #include <vector>
 #include "msv1.h"
+#include "msv1_lanes.h"
 
 namespace jsp {
 namespace {
 
 constexpr int PWG = 256;                 // lanes per workgroup
-constexpr int LSLOTS = 32;               // slots (2 bytes each) per lane
-constexpr int TSLOTS = PWG * LSLOTS;     // 8192 slots = 16 KiB per tile
+#ifndef JSP_BATCH_LS
+#define JSP_BATCH_LS 32                  // 32: 16 KiB tiles, 16: 8 KiB tiles (staged batches; one-frame launches of small frames always use 16)
+#endif
+constexpr int LSLOTS = JSP_BATCH_LS;     // slots (2 bytes each) per lane
+constexpr int TSLOTS = PWG * LSLOTS;     // slots per tile
 constexpr uint32_t BSAT = (1u << 28) - 1;
 
 __device__ __forceinline__ uint32_t pack(uint32_t exit_slot, uint32_t blocks) { return exit_slot | (blocks << 4); }
@@ -142,7 +146,7 @@ __device__ __forceinline__ void lane_table_fast(const uint32_t (&w)[LS / 2 + 1],
 
 // Stage a tile through LDS and hand every lane its 17 dwords.
 __device__ __forceinline__ void load_lane_bytes(const uint8_t* __restrict__ stream, uint32_t tile_byte0, uint32_t end,
-                                                uint32_t* lds_bytes /* TSLOTS*2/4 + 4 dwords */, uint32_t (&w)[17]) {
+                                                uint32_t* lds_bytes /* TSLOTS*2/4 + 4 dwords */, uint32_t (&w)[LSLOTS / 2 + 1]) {
     constexpr uint32_t tile_bytes = TSLOTS * 2;
     constexpr int NLOAD = (tile_bytes + 16u + PWG * 16u - 1u) / (PWG * 16u);
     uint4 v[NLOAD];   // every load is out before the first is waited for (one by one: NLOAD memory round trips in a row)
@@ -160,7 +164,7 @@ __device__ __forceinline__ void load_lane_bytes(const uint8_t* __restrict__ stre
     __syncthreads();
     const uint32_t* mine = lds_bytes + threadIdx.x * (LSLOTS * 2 / 4);
 #pragma unroll
-    for (int k = 0; k < 17; ++k) w[k] = mine[k];
+    for (int k = 0; k < LSLOTS / 2 + 1; ++k) w[k] = mine[k];
 }
 
 template <int BITS>
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(PWG) void msv1_parse_tiles(const uint8_t* __restric
     const Msv1ParseFrame fr = frames[tile_frame[t]];
     if (fr.host_parsed) return;
     const uint32_t tile_byte0 = fr.beg + (t - fr.first_tile) * (TSLOTS * 2);
-    uint32_t w[17], cls[LSLOTS], tab[9];
+    uint32_t w[LSLOTS / 2 + 1], cls[LSLOTS], tab[9];
     load_lane_bytes(stream, tile_byte0, fr.end, lds_bytes, w);
     lane_table<BITS>(w, tile_byte0 + threadIdx.x * (LSLOTS * 2), fr.end, cls, tab);
 #pragma unroll
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
                                                        uint32_t nblocks, uint32_t s1_first_block) {
     // one LDS arena: [tile bytes | composition tree | per-node entry]; once every lane knows where
     // the chain enters its slots, the front of the arena is reused as the descriptor staging buffer
-    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, STAGE = 8192;
+    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, STAGE = TSLOTS;
     static_assert(BYTES_W + TREE_W >= STAGE, "staging overlay must fit in front of `enter`");
     __shared__ __align__(16) uint32_t arena[BYTES_W + TREE_W + 2 * PWG];
     uint32_t* lds_bytes = arena;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
     const Msv1ParseFrame fr = frames[f];
     if (fr.host_parsed) return;
     const uint32_t tile_byte0 = fr.beg + (t - fr.first_tile) * (TSLOTS * 2);
-    uint32_t w[17], cls[LSLOTS], tab[9];
+    uint32_t w[LSLOTS / 2 + 1], cls[LSLOTS], tab[9];
     load_lane_bytes(stream, tile_byte0, fr.end, lds_bytes, w);
     const uint32_t p0 = tile_byte0 + threadIdx.x * (LSLOTS * 2);
     lane_table<BITS>(w, p0, fr.end, cls, tab);
@@ -356,7 +360,8 @@ __global__ __launch_bounds__(PWG) void msv1_parse_emit(const uint8_t* __restrict
 // The whole frame batch is one launch; the stream is read from HBM exactly once.
 // Frames the host parser has to settle (Msv1ParseFrame::host_parsed) are skipped here and take the
 // descriptor path.  Requires X % 4 == 0 and 16-byte aligned frame buffers (msv1_codec.cpp checks).
-constexpr uint32_t F_SKIP = 0xFFFFu;
+constexpr uint32_t F_SKIP = 0xFFFFu;    // staging window: the block is skipped (a copy of the previous frame's)
+constexpr uint32_t F_NONE = 0xFFFEu;    //   ... the block belongs to another tile (code offsets are even and below 16 KiB)
 // look-back: LBW words per lane hold the tables of the nearest LBW * PWG / 9 earlier tiles of the frame in one poll (3 words = 85
 // tiles with 16 KiB tiles, 5 words = 142 with 8 KiB tiles: a 1080p M1 frame is 64 / 127 tiles); the chain through a batch is
 // walked in LBW * 7 / 3 segments side by side
@@ -461,56 +466,21 @@ __device__ __forceinline__ void decode_block(const uint8_t* code, uint32_t avail
         }
 }
 
-// 16-bit frames, lane wholly inside the frame's data, no skip code among its 32 slots (the wave checks): everything the
-// table pass and the replay need is three bit masks over the slots — S: solid (bit 15 of the code word set), E: 8-colour
-// (pattern word followed by a word with bit 15 set), T: 2-colour (the other pattern words); every code is one block.
-struct LaneMasks { uint32_t S, T, E; };
-template <int LS = LSLOTS>
-__device__ __forceinline__ LaneMasks lane_masks16(const uint32_t (&w)[LS / 2 + 1], bool& has_skip) {
-    uint32_t notp = 0, z = 0;
-#pragma unroll
-    for (int i = 0; i < LS / 2; ++i) {
-        const uint32_t d = w[i];
-        notp |= ((d >> 15) & 1u) << (2 * i);
-        notp |= (d >> 31) << (2 * i + 1);
-        const uint32_t t = (d & 0xFC00FC00u) ^ 0x84008400u;           // a zero half = a skip code (high byte 0x84..0x87)
-        z |= (t - 0x00010001u) & ~t & 0x80008000u;                     // (a borrow out of a zero low half can only add a hit)
-    }
-    has_skip = z != 0u;
-    const uint32_t next_set = (notp >> 1) | (((w[LS / 2] >> 15) & 1u) << (LS - 1));   // bit 15 of the word after the slot's
-    LaneMasks m;
-    m.S = notp;
-    m.E = ~notp & next_set;
-    m.T = ~notp & ~next_set;
-    return m;
-}
-// the 9-entry table from the masks: the reverse pass of lane_table_fast with the slot's two predicates read off the masks
-template <int LS = LSLOTS>
-__device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&tab)[9]) {
-    uint32_t dw[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dw[k] = pack(k, 0);
-    const uint32_t P = ~m.S;
-#pragma unroll
-    for (int s = LS - 1; s >= 0; --s) {
-        uint32_t mp, me;
-        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mp) : "v"(P), "n"(s));       // 0 / ~0: pattern code
-        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(me) : "v"(m.E), "n"(s));     // 0 / ~0: ... with 8 colours
-        uint32_t nx = (dw[8] & me) | (dw[2] & ~me);
-        nx = (nx & mp) | (dw[0] & ~mp);
-        const uint32_t v = nx + 16u;                                       // one block per code: no saturation in 32 slots
-#pragma unroll
-        for (int k = 8; k > 0; --k) dw[k] = dw[k - 1];
-        dw[0] = v;
-    }
-#pragma unroll
-    for (int e = 0; e < 9; ++e) tab[e] = dw[e];
+// OR of a 32-bit value over the wave, as a wave-uniform (scalar) value: four DPP steps leave every row's OR in all 16 of
+// its lanes, then one lane of each row is read.
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // One launch: grid = tiles, in stream order.
 // Measured and dropped (profiles/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
-// prefetched into registers, 2-bit packed slot kinds instead of 32 classification registers) hid the tile load but ran
-// the workgroups of a CU in lockstep — every phase then competes for the same issue slots — and was 10 % slower.
+// prefetched into registers) hid the tile load but ran the workgroups of a CU in lockstep — every phase then competes
+// for the same issue slots — and was 10 % slower.
 // The asynchronous per-frame path (one frame per launch):
 //   MODE 3: one launch — every tile parses and reports into `info`, waits for the whole frame's verdict, then writes its
 //           pixels or nothing (see msv1.h); what frames of up to MSV1_MERGED_MAX_TILES tiles get;
@@ -520,7 +490,9 @@ __device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&
 //   MODE 2: the decode proper, which returns at once when the scout found one of the conditions in `bad_mask` — such a
 //           frame is re-done by the synchronous path, and must find `dst` exactly as the caller left it.
 // MODE 4: the batch form writing block tables instead of pixels (the descriptor parse of inter-frame batches).
-// MODE 0 is the batch form (no report).
+// MODE 0 is the batch form (no report); its frames never read a previous frame (msv1_codec.cpp only fuses frames without
+// skipped blocks and without a stage-2 compare), so it is compiled without the copy and compare paths: its decode loop
+// then holds no load at all, and the row stores of consecutive blocks are never waited for.
 #ifdef JSP_FUSED_CLOCKS   // lab build: thread 0 of every tile adds the cycles of each phase to its own counters behind the tile tables (`want` = tiles of the batch)
 #define JSP_CLOCK(k) do { if (MODE == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
     agg[(size_t)want * 9u + (size_t)(tile0 + blockIdx.x) * 8u + (k)] += now_ - clk_; clk_ = now_; } } while (0)
@@ -529,10 +501,19 @@ __device__ __forceinline__ void lane_table_masks(const LaneMasks& m, uint32_t (&
 #else
 #define JSP_CLOCK(k) do { } while (0)
 #endif
+#ifndef JSP_FUSED_ALIGN
+#define JSP_FUSED_ALIGN 1      // lab: 0 = staging windows start at the tile's first block (row stores begin anywhere in a memory line)
+#endif
+#ifndef JSP_FUSED_VMCNT
+#define JSP_FUSED_VMCNT 4      // row stores of earlier blocks a wave may still have in flight when it issues a block's four (63 = no limit)
+#endif
+#ifndef JSP_FUSED_WAVES
+#define JSP_FUSED_WAVES 4      // __launch_bounds__: waves per SIMD the register allocation must leave room for
+#endif
 // LS = slots (2 bytes) per lane: 32 (16 KiB tiles) for the batch forms, 16 (8 KiB tiles) for the one-frame-per-launch forms,
 // whose few dozen workgroups have the GPU to themselves: half the serial work per tile, twice the tiles.
 template <int BITS, int MODE, int LS>
-__global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
+__global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
                                                             const Msv1TileRec* __restrict__ recs,
                                                             const int32_t* __restrict__ palette,
                                                             unsigned long long* __restrict__ agg, uint32_t epoch,
@@ -543,21 +524,29 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                                                             Msv1TileRec one_rec, Msv1AsyncInfo* __restrict__ host_info, uint32_t want,
                                                             uint8_t* __restrict__ keep) {
     constexpr bool INFO = MODE == 1 || MODE == 3;
-    constexpr int TSLOTS = PWG * LS, FSTAGE = TSLOTS;          // (shadow the file's 32-slot constants)
+    constexpr bool USES_PREV = MODE != 0;                      // copies of skipped blocks, stage-2 compare (see above)
+    constexpr int TSLOTS = PWG * LS;                           // (shadow the file's 32-slot constants)
+    constexpr int FSTAGE = 4096;                               // blocks per staging window (a 16 KiB tile of solid codes: two windows)
     constexpr uint32_t TILE_BYTES = TSLOTS * 2;
     constexpr int LSLOTS = LS;
     constexpr int LBW = LS == 32 ? 3 : 5, LOOKBACK_BATCH = LBW * PWG / 9, LOOKBACK_SEGS = LBW * 7 / 3;
-    // one LDS arena: [tile bytes | composition tree | per-node entry]; the tree's space becomes the staging
-    // window once every lane knows where the chain enters its slots; `enter` doubles as the look-back scratch
-    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TREE_W = 2 * PWG * 9, ENTER_W = LOOKBACK_BATCH * 9 + 4;
-    static_assert(TREE_W * 2 >= FSTAGE, "staging window must fit in the tree's space");
-    static_assert(ENTER_W >= 2 * PWG, "`enter` holds one word per tree node");
-    __shared__ __align__(16) uint32_t arena[BYTES_W + TREE_W + ENTER_W];
+    // one LDS arena: [tile bytes | lane tables | look-back scratch]; the tables' space becomes the staging window once every
+    // lane knows where the chain enters its slots
+    // The batch forms take their tiles tile-major over the batch's frames (tile j of every frame before tile j + 1 of any,
+    // see msv1_launch_order): when a tile starts, its predecessor in the frame finished about a thousand workgroups ago and has
+    // left the one value this tile needs — where the chain stands at the tile's first slot — so the look-back is ONE word,
+    // asked for before anything else and there when it is needed (PREFIX).  The one-frame launches have all of a frame's
+    // tiles in flight together: those publish their tables and every tile chains the tables of all tiles before it.
+    constexpr bool PREFIX = MODE == 0 || MODE == 4;
+    constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TAB_W = PWG * 9 + 16, ENTER_W = PREFIX ? 4 : LOOKBACK_BATCH * 9 + 4;
+    static_assert(TAB_W * 2 >= FSTAGE, "staging window must fit in the tables' space");
+    __shared__ __align__(16) uint32_t arena[BYTES_W + TAB_W + ENTER_W];
     __shared__ uint32_t s_pal[BITS == 8 ? 256 : 1];
-    __shared__ uint32_t s_entry, s_root[9], s_seg[LOOKBACK_SEGS][9];
+    __shared__ uint32_t s_entry, s_root[16], s_seg[PREFIX ? 1 : LOOKBACK_SEGS][9];
+    __shared__ uint32_t s_grp[PWG / 64][7][16], s_wav[PWG / 64][16];   // (16 per row: a saturated value indexes entry 15, see msv1_lanes.h)
     uint8_t* lds_bytes = reinterpret_cast<uint8_t*>(arena);
-    uint32_t (*tree)[9] = reinterpret_cast<uint32_t (*)[9]>(arena + BYTES_W);
-    uint32_t* enter = arena + BYTES_W + TREE_W;
+    uint32_t* tabs = arena + BYTES_W;
+    uint32_t* enter = arena + BYTES_W + TAB_W;
     uint16_t* stage = reinterpret_cast<uint16_t*>(arena + BYTES_W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
@@ -569,9 +558,9 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
 #ifdef JSP_FUSED_CLOCKS
     unsigned long long clk_ = __builtin_readcyclecounter();
 #endif
-    const uint32_t t = tile0 + blockIdx.x;
-    Msv1TileRec r = MODE == 3 ? one_rec : recs[t];             // MODE 3: one frame per launch, the record is a kernel argument
+    Msv1TileRec r = MODE == 3 ? one_rec : recs[tile0 + blockIdx.x];   // MODE 3: one frame per launch, the record is a kernel argument
     if (MODE == 3) r.k = blockIdx.x;
+    const uint32_t t = PREFIX ? r.first_tile + r.k : tile0 + blockIdx.x;   // the tile's number in stream order (its slot in `agg`)
     if (MODE != 3 && (r.flags & MSV1_TILE_SKIP)) return;
     // MODE 3 bookkeeping (thread 0): `arrived` counts the workgroups whose findings are in info->flags, `finished` those
     // that have written their last pixel; both run on from launch to launch (`want` = their value once this launch is
@@ -607,7 +596,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     }
     if (BITS == 8) s_pal[tid] = (uint32_t)palette[tid];
     const uint32_t k = r.k;                                    // which tile of its frame
-    const uint32_t tile_byte0 = t * TILE_BYTES;                // == r.byte0
+    const uint32_t tile_byte0 = PREFIX ? r.byte0 : t * TILE_BYTES;   // (frames start on tile boundaries: r.byte0 == t * TILE_BYTES)
     const uint32_t data_end = r.data_end;                      // 16-bit: whole code units only; 8-bit: every byte
 
     // ---- 0. look-back loads go out first: the tables of the nearest earlier tiles of the frame (up to LOOKBACK_BATCH
@@ -617,7 +606,9 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     unsigned long long lv[LBW];
 #pragma unroll
     for (int q = 0; q < LBW; ++q) lv[q] = 0ull;
-    {
+    if (PREFIX) {
+        if (tid == 0 && k) lv[0] = __hip_atomic_load(agg + (size_t)(t - 1u) * 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
         const unsigned long long* look_src = agg + (size_t)(r.first_tile + look0) * 9u;
 #pragma unroll
         for (int q = 0; q < LBW; ++q)
@@ -625,7 +616,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
                 lv[q] = __hip_atomic_load(look_src + tid + q * PWG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- 1. tile bytes -> LDS (zero past the end of the frame's data), lane tables, composition tree ----
+    // ---- 1. tile bytes -> LDS (zero past the end of the frame's data), lane masks and tables -------------------
     // All of a lane's loads go out before the first is waited for: one after the other they were five memory round trips in
     // a row, ~3 us each under a saturated write stream — the longest phase of a tile.
     {
@@ -665,60 +656,97 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
     }
     __syncthreads();
     JSP_CLOCK(0);   // bytes in LDS
+    // The lane's slots as bit masks (msv1_lanes.h), kept in registers from here to the replay: the table pass and the replay
+    // both read them, nothing is classified twice.
     const uint32_t p0 = tile_byte0 + tid * (LSLOTS * 2);
-    const bool inside = tile_byte0 + TILE_BYTES + 4u <= r.frame_end;   // every tile of a frame but the last: no end-of-data tests
-    LaneMasks masks{0, 0, 0};
-    // (wave-uniform) the mask form serves: 16-bit, inside the frame, no skip-LIKE word among this wave's 2048.  That holds for
-    // flat content (solid blocks, few colour pairs: what screens mostly show); in frames of random colours one word in a
-    // hundred has a high byte of 0x84..0x87 and every wave takes the general form — the M1 bench mix is such a frame.
-    // A skip-aware mask form was built and measured (27 % fewer VALU instructions, 6 % slower: profiles/r02_fused_notes.txt).
-    bool fast = false;
+    lanes::Masks masks;
     {
         uint32_t w[LS / 2 + 1], tab[9];
         const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
 #pragma unroll
         for (int i = 0; i < LS / 2 + 1; ++i) w[i] = mine_w[i];
-#ifndef JSP_FUSED_MASKS
-#define JSP_FUSED_MASKS 1
-#endif
-        if (JSP_FUSED_MASKS && BITS == 16 && inside) {
-            bool has_skip;
-            masks = lane_masks16<LS>(w, has_skip);
-            fast = __ballot(has_skip) == 0ull;
-        }
-        if (fast) lane_table_masks<LS>(masks, tab);
-        else {
-            uint32_t cls[LSLOTS];
-            lane_table<BITS, LS>(w, p0, r.frame_end, cls, tab);
-        }
+        masks = lanes::build_masks<BITS, LS>(w, r.frame_end > p0 ? (r.frame_end - p0) >> 1 : 0u);
+        lanes::lane_table<BITS, LS>(w, masks, wave_or(masks.Z), tab);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) tree[tid][e] = tab[e];
+        for (int e = 0; e < 9; ++e) tabs[tid * 9 + e] = tab[e];
     }
-    // Composition tree, levels 1..6 inside each wave: a wave's LDS accesses execute in order, so no workgroup
-    // barrier is needed between levels — only the wave's own writes have to have been issued (wave_sync).
+    // ---- 2. the tile's table by chaining, not by a tree: within a wave 7 groups of lane tables (10 + 6 x 9), each walked
+    //         by 9 lanes (one per entry slot) table after table; then the 7 group tables, then the 4 wave tables.  Every
+    //         walk leaves its running value in place of the table it has just passed, so afterwards row i holds "where the
+    //         chain stands after table i, per entry slot of the walk" — what the down-sweep reads, once, per lane.
+    //         (A wave's LDS accesses execute in order: no workgroup barrier inside a wave's walks.) -------------------
     wave_sync();
-    for (int l = 1; l <= 6; ++l) {
-        const int nodes = 64 >> l, lo = tree_row(l - 1), hi = tree_row(l), base = (wave * 64) >> l;
-        for (int i = lane; i < nodes * 9; i += 64) {
-            const int j = base + i / 9, e = i % 9;
-            tree[hi + j][e] = compose(tree[lo + 2 * j][e], tree[lo + 2 * j + 1]);
+    const int grp = lane < 10 ? 0 : (lane - 1) / 9;            // group of this lane's TABLE (down-sweep)
+    {
+        const int g1 = lane / 9, e1 = lane - g1 * 9;           // the walk this lane takes part in (lane 63: none)
+        if (lane < 63) {
+            const int start = g1 == 0 ? 0 : 1 + 9 * g1, cnt = g1 == 0 ? 10 : 9;
+            uint32_t* row = tabs + (wave * 64 + start) * 9;
+            uint32_t v = (uint32_t)e1;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                if (q < cnt) {
+                    v = lanes::sat_add(row[v & 15u], v & ~15u);
+                    row[e1] = v;                               // (all 9 lanes have read the row: same instruction)
+                    row += 9;
+                }
+            }
+            s_grp[wave][g1][e1] = v;
         }
         wave_sync();
-    }
-    __syncthreads();                                           // the four wave tables (level 6) are in place
-    JSP_CLOCK(1);   // lane tables + wave trees
-    // the tile's table = the four wave tables chained, one entry slot per lane
-    if (tid < 9) {
-        uint32_t v = tree[tree_row(6)][tid];
+        if (lane < 9) {
+            uint32_t v = (uint32_t)lane;
 #pragma unroll
-        for (int u = 1; u < 4; ++u) v = compose(v, tree[tree_row(6) + u]);
-        s_root[tid] = v;
-        // ---- 2. publish the tile's table (the last tile of a frame has no reader): a word is its own flag --------
-        if (k + 1u < r.ntiles)
-            __hip_atomic_store(agg + (size_t)t * 9u + tid, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = 0; g < 7; ++g) {
+                v = lanes::sat_add(s_grp[wave][g][v & 15u], v & ~15u);
+                s_grp[wave][g][lane] = v;
+            }
+            s_wav[wave][lane] = v;
+        }
     }
-    // ---- 3. look-back: chain the earlier tiles' tables from entry slot 0 of the frame --------------------------
-    {
+    __syncthreads();                                           // the four wave tables are in place
+    JSP_CLOCK(1);   // lane tables + walks
+    if (tid < 9) {
+        uint32_t v = (uint32_t)tid;
+#pragma unroll
+        for (int u = 0; u < PWG / 64; ++u) {
+            v = lanes::sat_add(s_wav[u][v & 15u], v & ~15u);
+            s_wav[u][tid] = v;
+        }
+        s_root[tid] = v;
+        // the published form keeps the block count within 28 bits and the exit slot intact
+        const uint32_t pv = (v >> 4) >= BSAT ? (BSAT << 4) : v;
+        // ---- publish the tile's table (the last tile of a frame has no reader): a word is its own flag --------
+        if (!PREFIX && k + 1u < r.ntiles)
+            __hip_atomic_store(agg + (size_t)t * 9u + tid, ((unsigned long long)epoch << 32) | pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- 3. look-back --------------------------------------------------------------------------------------------
+    if (PREFIX) {
+        // the predecessor's word {launch epoch, where the chain stands after it}; this tile's own goes out as soon as it is known
+        if (tid == 0) {
+            uint32_t ent = 0;
+            bool ok = true;
+            if (k) {
+                for (int spin = 0; (uint32_t)(lv[0] >> 32) != epoch; ++spin) {
+                    if (spin > LOOKBACK_SPIN_LIMIT) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                    lv[0] = __hip_atomic_load(agg + (size_t)(t - 1u) * 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ent = (uint32_t)lv[0];
+            }
+            if (ok) {
+                const uint32_t after = lanes::sat_add(s_root[ent & 15u], ent & ~15u);
+                if (k + 1u < r.ntiles)
+                    __hip_atomic_store(agg + (size_t)t * 9u, ((unsigned long long)epoch << 32) | ((after >> 4) >= BSAT ? (BSAT << 4) : after),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                atomicOr(fault, 1u);                           // reported by jsp_staged_results / the call as an error
+            }
+            s_entry = ok ? ent : 0xFFFFFFFFu;                  // (a published value never has all its bits set)
+        }
+        __syncthreads();
+        if (s_entry == 0xFFFFFFFFu) return;
+    } else {
         uint32_t e = 0, blocks = 0;                            // thread 0 carries the chain
         // frames with more than LOOKBACK_BATCH earlier tiles: the far ones first, batch by batch (frames of more than LOOKBACK_BATCH tiles)
         for (uint32_t j0 = 0; j0 < k; j0 += LOOKBACK_BATCH) {
@@ -790,98 +818,69 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             __syncthreads();
         }
         if (tid == 0) s_entry = pack(e, blocks);
+        __syncthreads();
     }
-    __syncthreads();
-    // ---- 4. down-sweep of ONE value per node: where the chain enters the node and with which block ----------
+    // ---- 4. down-sweep: where the chain enters this lane's slots and with which block — the tile's entry taken through
+    //         the walks' running values: waves before this one, groups before this lane's, tables before this lane's ----
     const uint32_t entry = s_entry;
     JSP_CLOCK(2);   // publish + look-back
     const uint32_t tb0 = entry >> 4;
-    if (lane == 0) {                                           // where the chain enters this wave
-        uint32_t v = entry;
-        for (int u = 0; u < wave; ++u) v = compose(v, tree[tree_row(6) + u]);
-        enter[tree_row(6) + wave] = v;
+    uint32_t mine;
+    {
+        const uint32_t wv = wave == 0 ? entry : lanes::sat_add(s_wav[wave - 1][entry & 15u], entry & ~15u);
+        const uint32_t gv = grp == 0 ? wv : lanes::sat_add(s_grp[wave][grp - 1][wv & 15u], wv & ~15u);
+        const int start = grp == 0 ? 0 : 1 + 9 * grp;
+        mine = lane == start ? gv : lanes::sat_add(tabs[(tid - 1) * 9 + (gv & 15u)], gv & ~15u);
     }
-    wave_sync();
-    for (int l = 6; l >= 1; --l) {
-        const int nodes = 64 >> l, hi = tree_row(l), lo = tree_row(l - 1), base = (wave * 64) >> l;
-        if (lane < nodes) {
-            const int j = base + lane;
-            const uint32_t v = enter[hi + j];
-            enter[lo + 2 * j] = v;
-            enter[lo + 2 * j + 1] = add_blocks(tree[lo + 2 * j][v & 15u], v >> 4);
-        }
-        wave_sync();
-    }
-    const uint32_t mine = enter[tid];
-    const uint32_t whole = add_blocks(s_root[entry & 15u], tb0) >> 4;   // blocks covered once this tile is done
+    const uint32_t whole = lanes::sat_add(s_root[entry & 15u], entry & ~15u) >> 4;   // blocks covered once this tile is done
     const uint32_t span_end = whole < nblocks ? whole : nblocks;
     if (INFO && tid == 0 && k + 1u == r.ntiles && whole < nblocks) atomicOr(&info->flags, MSV1_ASYNC_SHORT);   // the stream ends early
-    __syncthreads();                                           // tree and enter are dead: the staging window takes their place
+    // the slots of this lane the chain visits
+    const uint32_t visits = lanes::visited<BITS, LS>(masks, mine & 15u);
+    const uint32_t blk0 = mine >> 4;
+    __syncthreads();                                           // the tables are dead: the staging window takes their place
     JSP_CLOCK(3);   // down-sweep
 
     uint32_t seen = 0;                                         // INFO: what this lane's codes on the chain were
     bool arrived = false;                                      // MODE 3 (uniform): this workgroup has been through the verdict
     const uint32_t* __restrict__ prev = reinterpret_cast<const uint32_t*>(r.prev);
     uint32_t* __restrict__ dstf = reinterpret_cast<uint32_t*>(r.dst);
-    for (uint32_t w0 = tb0; w0 < span_end; w0 += FSTAGE) {     // more than one window only behind long skip runs
-        const uint32_t wn = span_end - w0 < (uint32_t)FSTAGE ? span_end - w0 : (uint32_t)FSTAGE;
+    // Staging windows start on multiples of 256 blocks, whatever block the tile starts with: lane i of the workgroup then always
+    // has block (multiple of 256) + i, so a wave's row store is 1 KiB starting on a 512-byte boundary of the frame and writes whole
+    // memory lines.  (Windows that started at the tile's first block made every row store of every wave begin and end inside a
+    // line that the neighbouring wave completes: two partial-line writes per store, see profiles/r03_fused_notes.txt.)
+    for (uint32_t w0 = JSP_FUSED_ALIGN ? tb0 & ~255u : tb0; w0 < span_end; w0 += FSTAGE) {   // more than one window only behind long skip runs / in tiles of short codes
+        const uint32_t wn = span_end - w0 < (uint32_t)FSTAGE ? span_end - w0 : (uint32_t)FSTAGE;   // window entries [0, wn) ...
+        const uint32_t wlo = tb0 > w0 ? tb0 - w0 : 0u;                 // ... of which [wlo, wn) are this tile's blocks (wlo < 256)
+        const bool first_window = w0 <= tb0;
         if (MODE != 1) {
-            for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG) reinterpret_cast<uint32_t*>(stage)[i] = 0xFFFFFFFFu;
+            for (uint32_t i = tid; i < (wn + 1u) / 2u; i += PWG)
+                reinterpret_cast<uint32_t*>(stage)[i] = (2u * i < wlo ? F_NONE : F_SKIP) | ((2u * i + 1u < wlo ? F_NONE : F_SKIP) << 16);
             __syncthreads();
         }
-        if (fast) {
-            // The slots the chain visits, as a bit mask: from the entry slot, every visited code marks the slot its length
-            // further on, until nothing changes (a wave needs as many rounds as its longest lane has codes).
-            const uint32_t entry_slot = mine & 15u, blk0 = mine >> 4;
-            uint32_t V = 1u << entry_slot;                      // (entry_slot <= 8)
-            for (;;) {
-                const uint32_t V2 = V | ((V & masks.S) << 1) | ((V & masks.T) << 3) | ((V & masks.E) << 9);
-                const bool grew = V2 != V;
-                V = V2;
-                if (!__any(grew)) break;
-            }
-            if (LS < 32) V &= (1u << LS) - 1u;               // (marks past the lane's last slot belong to the next lane)
-            if (INFO && w0 == tb0) {                            // a coded block in a significant block row?
-                const uint32_t cnt = (uint32_t)__popc(V), lo = blk0 > s1_first_block ? blk0 : s1_first_block;
-                const uint32_t hi = blk0 + cnt < nblocks ? blk0 + cnt : nblocks;
-                if (lo < hi) seen |= MSV1_ASYNC_S1;
-            }
-            if (MODE != 1) {
-                uint32_t idx = blk0 - w0;                       // position in the window of the lane's next block
-                for (uint32_t left = V; left; left &= left - 1u) {
-                    const uint32_t sl = (uint32_t)__ffs((int)left) - 1u;
-                    if (idx < wn) stage[idx] = (uint16_t)(tid * (LSLOTS * 2) + 2u * sl);
-                    ++idx;
-                }
-            }
-        } else {
-            // replay the lane's slots one by one: the chain visits slot `pos`; a coded block leaves the offset of its code
-            uint32_t w[LS / 2 + 1], cls[LSLOTS];
-            const uint32_t* mine_w = arena + tid * (LSLOTS * 2 / 4);
-#pragma unroll
-            for (int i = 0; i < LS / 2 + 1; ++i) w[i] = mine_w[i];
-            {
-                uint32_t tab[9];
-                lane_table<BITS, LS>(w, p0, r.frame_end, cls, tab);   // (for its classification; the table is not used again)
-            }
-            uint32_t pos = mine & 15u, blk = mine >> 4;
-#pragma unroll
-            for (int s = 0; s < LSLOTS; ++s) {
-                if (pos == (uint32_t)s && blk < nblocks) {
-                    const uint32_t c = cls[s];
-                    if (inside || p0 + 2u * s < r.frame_end) {
-                        if (INFO && w0 == tb0)
-                            seen |= (c & 16u) ? (blk >= s1_first_block ? MSV1_ASYNC_S1 : 0u) : ((c & 32u) ? MSV1_ASYNC_END : MSV1_ASYNC_SKIPCODE);
-                        if (MODE != 1 && (c & 16u) && blk - w0 < wn) stage[blk - w0] = (uint16_t)(tid * (LSLOTS * 2) + 2 * s);
-                        const uint32_t nb = blk + (c >> 8);
-                        blk = nb > BSAT ? BSAT : nb;
+        {
+            // replay: every visited slot in order; a plain code leaves the offset of its code and is one block, a special slot
+            // (rare) is a skip code — its count comes from the word —, a slot past the data or the 8-bit end marker
+            uint32_t blk = blk0;
+            for (uint32_t left = visits; left; left &= left - 1u) {
+                const uint32_t sl = (uint32_t)lanes::first_bit(left), bit = left & (0u - left);
+                if (masks.Z & bit) {
+                    if (masks.valid & bit) {
+                        if (INFO && first_window && blk < nblocks) seen |= (masks.K & bit) ? MSV1_ASYNC_SKIPCODE : MSV1_ASYNC_END;
+                        if (masks.K & bit) {
+                            const uint32_t n = (uint32_t)reinterpret_cast<const uint16_t*>(lds_bytes)[tid * LSLOTS + sl] & 0x3FFu;
+                            blk += n ? n : lanes::REST_OF_FRAME;
+                        }
                     }
-                    pos += c & 15u;
+                } else {
+                    if (INFO && first_window && blk >= s1_first_block && blk < nblocks) seen |= MSV1_ASYNC_S1;
+                    if (MODE != 1 && blk - w0 < wn) stage[blk - w0] = (uint16_t)(tid * (LSLOTS * 2) + 2u * sl);
+                    ++blk;
                 }
             }
         }
         if (MODE == 1) break;                                  // the scout only needed the replay of the first window
-        if (MODE == 3 && w0 == tb0) {
+        if (MODE == 3 && first_window) {
             // ---- the frame's verdict: every tile's findings are in before any tile writes a pixel (all tiles of a
             //      frame this small are resident together: the launcher only takes frames of a few hundred tiles) ----
 #pragma unroll
@@ -914,16 +913,15 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             uint32_t* __restrict__ table = dstf;               // (the record's `dst` is the frame's table)
             for (uint32_t i = tid; i < wn; i += PWG) {
                 const uint32_t o = stage[i];
-                table[w0 + i] = o == F_SKIP ? MSV1_DESC_SKIP : tile_byte0 + o;
+                if (o != F_NONE) table[w0 + i] = o == F_SKIP ? MSV1_DESC_SKIP : tile_byte0 + o;
             }
         } else {
         // ---- 5. reconstruction: lane = block, raster order; block coordinates advance by PWG blocks per round ----
         // 5a. skipped blocks are copies from the previous frame: U blocks per lane at a time, all their row loads out before
         //     the first store (one at a time, every block waits a memory round trip of its own: an inter frame of a single
-        //     stream has a dozen workgroups on the whole GPU and nothing else to hide it behind).  The batch form keeps U = 1:
-        //     its launches fill the GPU, and its register budget is what the headline path runs on.
-        {
-            constexpr int U = MODE == 0 ? 1 : 4;
+        //     stream has a dozen workgroups on the whole GPU and nothing else to hide it behind).
+        if (USES_PREV) {
+            constexpr int U = 4;
             uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
             for (uint32_t i = tid; i < wn; i += PWG * (uint32_t)U) {
                 uint32_t di[U];
@@ -955,7 +953,7 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
         }
         // 5b. coded blocks
         uint32_t by = (w0 + tid) / (uint32_t)nbx, bx = (w0 + tid) - by * (uint32_t)nbx;
-        bool compare = r.cmp_row_lo != 0xFFFFFFFFu;                    // (wave-uniform) stage-2 significance still open
+        bool compare = USES_PREV && r.cmp_row_lo != 0xFFFFFFFFu;       // (wave-uniform) stage-2 significance still open
         for (uint32_t i = tid; i < wn; i += PWG) {
             const uint32_t o = stage[i];
             const uint32_t di = (by * (uint32_t)X + bx) * 4u;          // pixel index: a frame has fewer than 2^28 pixels
@@ -963,10 +961,9 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
             const uint32_t by_now = by;
             bx += PWG;
             while (bx >= (uint32_t)nbx) { bx -= (uint32_t)nbx; ++by; }
-            const bool coded = o != F_SKIP;
+            const bool coded = o < F_NONE;
             fu32x4 q[4];
-            constexpr bool EARLY = MODE != 0;                          // (the batch form keeps its register budget: loads after the stores)
-            if (EARLY && compare && coded) {                           // the previous frame's rows travel while the block is decoded
+            if (USES_PREV && compare && coded) {                       // the previous frame's rows travel while the block is decoded
                 const uint32_t* __restrict__ pv = prev + di;
 #pragma unroll
                 for (int y = 0; y < 4; ++y) q[y] = *(fcgu32x4*)(pv + (size_t)y * X);
@@ -978,24 +975,28 @@ __global__ __launch_bounds__(PWG, 4) void msv1_fused_kernel(const uint8_t* __res
 #ifdef JSP_FUSED_NOSTORE   // lab build: the decode runs, its rows are not written (parse + decode time without the store stream)
                 if ((px[0] ^ px[5] ^ px[10] ^ px[15]) == 0xDEADBEEFu) atomicOr(fault, 2u);
 #else
+                // Store throttle.  A CU's loads and stores share one in-order queue: every row store a wave leaves in flight is
+                // something the other workgroups' loads (tile bytes, look-back word) wait behind.  Keeping at most a few rows per
+                // wave in flight keeps the memory pipe full without that queue growing: profiles/r03_fused_notes.txt.
+                if (MODE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JSP_FUSED_VMCNT) : "memory");
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
                     __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
 #endif
-                if (compare) {                                         // stage-2 significance, MSVideo1.hx:195-204
-                    if (!EARLY) {
-                        const uint32_t* __restrict__ pv = prev + di;
+                if (USES_PREV && compare) {                            // stage-2 significance, MSVideo1.hx:195-204
+                    // (all four rows are looked at, rows below the first compared one masked out: no load is left pending
+                    // behind a condition, so the loop's next round need not wait for this round's stores)
+                    uint32_t d4 = 0;
 #pragma unroll
-                        for (int y = 0; y < 4; ++y) q[y] = *(fcgu32x4*)(pv + (size_t)y * X);
+                    for (int y = 0; y < 4; ++y) {
+                        const uint32_t dy = (q[y].x ^ px[y * 4]) | (q[y].y ^ px[y * 4 + 1]) | (q[y].z ^ px[y * 4 + 2]) | (q[y].w ^ px[y * 4 + 3]);
+                        d4 |= by_now * 4u + y >= r.cmp_row_lo ? dy : 0u;
                     }
-#pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        if (by_now * 4u + y >= r.cmp_row_lo)
-                            diff |= (q[y].x != px[y * 4]) | (q[y].y != px[y * 4 + 1]) | (q[y].z != px[y * 4 + 2]) | (q[y].w != px[y * 4 + 3]);
+                    diff = d4 != 0u;
                     if (diff && __hip_atomic_load(r.signif, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(r.signif, 1u);
                 }
             }
-            if (compare && __any(diff)) compare = false;               // one differing pixel settles it: no more rows of the previous frame
+            if (USES_PREV && compare && __any(diff)) compare = false;  // one differing pixel settles it: no more rows of the previous frame
         }
         }
         if (w0 + FSTAGE < span_end) __syncthreads();           // the window is refilled by the next round
@@ -1055,10 +1056,10 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 #define JSP_FUSED(BITS, MODE, LS)                                                                                            \
     hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE, LS>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
                        d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep)
-#define JSP_FUSED_LS(BITS, MODE) do { if (small_tiles) JSP_FUSED(BITS, MODE, 16); else JSP_FUSED(BITS, MODE, 32); } while (0)
+#define JSP_FUSED_LS(BITS, MODE) do { if (small_tiles) JSP_FUSED(BITS, MODE, 16); else JSP_FUSED(BITS, MODE, JSP_BATCH_LS); } while (0)
 #define JSP_FUSED_MODES(BITS)                                                                                                \
     switch (mode) { case 1: JSP_FUSED_LS(BITS, 1); break; case 2: JSP_FUSED_LS(BITS, 2); break; case 3: JSP_FUSED_LS(BITS, 3); break; \
-                    case 4: JSP_FUSED(BITS, 4, 32); break; default: JSP_FUSED(BITS, 0, 32); }
+                    case 4: JSP_FUSED(BITS, 4, JSP_BATCH_LS); break; default: JSP_FUSED(BITS, 0, JSP_BATCH_LS); }
     if (geo.bits == 16) { JSP_FUSED_MODES(16) } else { JSP_FUSED_MODES(8) }
 #undef JSP_FUSED_MODES
 #undef JSP_FUSED_LS
