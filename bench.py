@@ -90,6 +90,21 @@ def cpu_baseline(spec, clip, budget_s=12.0):
     }
 
 
+def _spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this very command as a
+    CHILD process — before anything has touched the GPU — and hand its output and exit code through."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     from jsplayer_amd import workloads as wl
     ap = argparse.ArgumentParser()
@@ -100,7 +115,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="experiments only: the JSON line then says verified: false")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the launcher, the process group (gloo) and the counter collectives only; value is null")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -109,18 +128,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run, or let bench.py do it (no WORLD_SIZE)")
+    # under torch.distributed.run the process group is set up whatever N is (N = 1 included: same code path)
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    from jsplayer_amd.sharding import gather_per_rank, reduce_counters
+    if args.dry_run:
+        # the multi-rank plumbing without a GPU: every rank "owns" its stream's frames, nothing is decoded
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.barrier()
+        spec = wl.WORKLOADS[args.workload]
+        nfr = (spec["frames"] - (1 if spec.get("mode") == "inter" else 0)) * spec.get("clips", 1)
+        tf, tp, _ = reduce_counters(nfr * args.steps, nfr * args.steps * wl.W * wl.H, 0.0)
+        per_rank = gather_per_rank(nfr * args.steps)
+        if rank == 0:
+            print(json.dumps({"metric": "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs", "value": None,
+                              "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "config": {"workload": args.workload, "streams": args.gpus}, "total_frames": tf, "total_pixels": tp,
+                              "per_rank_frames": per_rank}), flush=True)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    # under torch.distributed.run the RCCL group is set up whatever N is (N = 1 included: same code path)
-    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from jsplayer_amd.sharding import gather_per_rank, reduce_counters
 
     name = args.workload
     spec = dict(wl.WORKLOADS[name])
@@ -180,34 +217,53 @@ def main():
     #      kernels of frame n), by examples/jsp_play — C++ over the C ABI only — for one stream and for one stream per host
     #      thread (independent codec instances, the way streams shard) ------------------------------------
     e2e = None
-    if not args.no_e2e and args.gpus == 1:
+    if not args.no_e2e:
         import subprocess
         import tempfile
         from jsplayer_amd import avi
         exe = os.path.join(ROOT, "examples", "jsp_play")
+        threads = max(1, min(16, (os.cpu_count() or 1) // max(1, args.gpus)))
         ncap = min(len(clips[0].frames), 256 if spec["codec"] == "msv1" else (64 if not inter else 150))   # a bounded sample of the first clip
-        fr = clips[0].frames[:ncap]
-        blob = avi.write_avi(W, H, fr, fourcc=b"SCPR" if spec["codec"] == "sp" else b"CRAM",
-                             bpp=24 if spec["codec"] == "sp" else spec["bits"], palette=clips[0].palette, key_flags=clips[0].keys[:ncap])
-        with tempfile.NamedTemporaryFile(suffix=".avi", dir=os.environ.get("TMPDIR", "/tmp")) as tf:
-            tf.write(blob)
-            tf.flush()
-            threads = max(1, min(16, (os.cpu_count() or 1) // max(1, args.gpus)))
+        # one file per stream: stream 0 plays the first `ncap` frames of this rank's first clip, streams 1.. play clips of their
+        # own (seeds of ranks rank*16 + 1 ...: independent inputs), shorter ones — what matters is that no two streams read the
+        # same bytes
+        nshort = max(8, ncap // 8) if not inter else ncap
+        def avi_of(frames, keys, palette):
+            return avi.write_avi(W, H, frames, fourcc=b"SCPR" if spec["codec"] == "sp" else b"CRAM",
+                                 bpp=24 if spec["codec"] == "sp" else spec["bits"], palette=palette, key_flags=keys)
+        blobs = [avi_of(clips[0].frames[:ncap], clips[0].keys[:ncap], clips[0].palette)]
+        for s_ in range(1, threads):
+            c = wl.build_clips(name, 1000 + rank * 16 + s_, nshort)[0]
+            blobs.append(avi_of(c.frames, c.keys, c.palette))
+        files = []
+        try:
+            for blob in blobs:
+                tf = tempfile.NamedTemporaryFile(suffix=".avi", dir=os.environ.get("TMPDIR", "/tmp"))
+                tf.write(blob)
+                tf.flush()
+                files.append(tf)
 
             def run(streams, repeat):
-                res = subprocess.run([exe, tf.name, "--pipelined", "--quiet", "--depth", "8", "--streams", str(streams), "--repeat", str(repeat)],
-                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                names = ",".join(f.name for f in files[:streams])
+                res = subprocess.run([exe, names, "--pipelined", "--quiet", "--depth", "8", "--streams", str(streams), "--repeat", str(repeat),
+                                      "--device", str(local_rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
                 if res.returncode != 0:
                     raise SystemExit("examples/jsp_play failed: " + res.stderr.decode()[-500:])
                 return json.loads(res.stdout.decode().strip().splitlines()[-1])
             rep = 8 if spec["codec"] == "msv1" else 1
-            one, many = run(1, rep), run(threads, rep)
+            barrier()                                 # all ranks play at the same time
+            one = run(1, rep)
+            barrier()
+            many = run(threads, rep * (ncap // nshort if not inter else 1))
+        finally:
+            for tf in files:
+                tf.close()
         batch_api = None
-        if spec["codec"] == "sp" and not inter:
+        if spec["codec"] == "sp" and not inter and args.gpus == 1:
             # the same sample through the batch calls: jsp_stage_batch (host stage of the whole batch: groups of pictures side by
             # side on host threads) + jsp_staged_decode, wall clock from host bytes to frames in HBM — one stream, but not one
             # frame per call
-            import torch
+            fr = clips[0].frames[:ncap]
             codec = wl.make_codec(args.workload, clips[0].palette, device=local_rank)
             dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in fr]
             torch.cuda.synchronize()
@@ -222,13 +278,22 @@ def main():
                                  "batch's groups of pictures side by side (option sp_host_threads, auto = up to 8 threads)"}
             st.close()
             del dsts
-        e2e = {"value": one["mpixels_per_s"], "unit": "Mpixels/s", "streams": 1, "frames": one["frames"],
+        # job-wide: the ranks played at the same time, each on its own GPU; rates add up
+        tot = torch.tensor([one["mpixels_per_s"], many["mpixels_per_s"], one["uploaded_bytes_per_s"], many["uploaded_bytes_per_s"]],
+                           dtype=torch.float64, device="cuda")
+        if distributed:
+            dist.all_reduce(tot)
+        e2e = {"value": round(float(tot[0]), 1), "unit": "Mpixels/s", "streams": args.gpus, "frames": one["frames"],
                "ms_per_frame": round(one["seconds"] * 1e3 / one["frames"], 4),
-               "all_threads": {"value": many["mpixels_per_s"], "unit": "Mpixels/s", "streams": threads, "frames": many["frames"],
-                               "note": f"{threads} independent streams (host threads, a codec instance each) playing the same file, one GPU"},
+               "uploaded_bytes_per_s": round(float(tot[2])),
+               "all_threads": {"value": round(float(tot[1]), 1), "unit": "Mpixels/s", "streams": threads * args.gpus, "frames": many["frames"],
+                               "uploaded_bytes_per_s": round(float(tot[3])),
+                               "note": f"{threads} independent streams per GPU (host threads, a codec instance and a FILE OF ITS OWN each: "
+                                       f"stream 0 the {ncap}-frame sample, the others {nshort}-frame clips of other seeds)"},
                "includes": "AVI bytes in pinned host memory -> chunk walk + host stage + H2D + kernels, one frame per call "
                            "(jsp_decompress_*_async / jsp_wait, 8 frames in flight per stream), examples/jsp_play over the C ABI; "
-                           "one untimed pass over the file first (codec and buffers set up), all streams start the timed passes together"}
+                           "one untimed pass over the file first (codec and buffers set up), all streams start the timed passes together; "
+                           "uploaded_bytes_per_s = compressed bytes handed to the decoders per second (what crosses the bus)"}
         if batch_api:
             e2e["batch_api"] = batch_api
 

@@ -130,9 +130,9 @@ bool frame_is_key(const Clip& c, jsp_codec* dec, size_t i) {
 struct Gate { std::atomic<int> waiting{0}; int parties = 1; };
 using Clock = std::chrono::steady_clock;
 long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int warmup = 0, Gate* gate = nullptr, Clock::time_point* t0 = nullptr,
-                    Clock::time_point* t1 = nullptr) {
+                    Clock::time_point* t1 = nullptr, int device = 0) {
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
-                                      (int)clip.palette.size(), 0);
+                                      (int)clip.palette.size(), device);
     if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return -1; }
     jsp_preinit(dec, kInsignificantLines);
     if (clip.kind != JSP_CODEC_SCREENPRESSOR) {
@@ -142,7 +142,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
     char dbuf[16];
     std::snprintf(dbuf, sizeof dbuf, "%d", depth);
     jsp_set_option(dec, "async_depth", dbuf);
-    jsp_pool* pool = jsp_pool_create(0, clip.X, clip.Y, kNumBuffers + 1 + depth);
+    jsp_pool* pool = jsp_pool_create(device, clip.X, clip.Y, kNumBuffers + 1 + depth);
     if (!pool) { std::fprintf(stderr, "jsp_pool_create: %s\n", jsp_last_error()); jsp_codec_destroy(dec); return -1; }
     const int nbuf = jsp_pool_count(pool);
     const size_t npx = (size_t)clip.X * clip.Y;
@@ -296,10 +296,23 @@ long play_batched(const Clip& clip, int batch, int repeat, bool quiet, int warmu
 
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R] [--warmup W]]] | --batch B [--quiet [--repeat R]]\n", argv[0]); return 2; }
-    Clip clip;
-    if (!load(argv[1], clip)) { std::fprintf(stderr, "%s: not a RIFF/AVI file this player understands\n", argv[1]); return 2; }
+    // (throughput runs: several files, separated by commas — stream s plays file s modulo their number, so that the streams of a
+    // multi-stream run are independent inputs)
+    std::vector<Clip> clips;
+    {
+        std::string list = argv[1];
+        for (size_t at = 0; at <= list.size();) {
+            const size_t comma = list.find(',', at);
+            const std::string name = list.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+            clips.emplace_back();
+            if (!load(name.c_str(), clips.back())) { std::fprintf(stderr, "%s: not a RIFF/AVI file this player understands\n", name.c_str()); return 2; }
+            if (comma == std::string::npos) break;
+            at = comma + 1;
+        }
+    }
+    const Clip& clip = clips[0];
     bool pipelined = false, quiet = false;
-    int depth = 4, streams = 1, repeat = 1, warmup = 1, batch = 0;
+    int depth = 4, streams = 1, repeat = 1, warmup = 1, batch = 0, device = 0;
     for (int a = 2; a < argc; ++a) {
         const std::string o = argv[a];
         if (o == "--pipelined") pipelined = true;
@@ -309,6 +322,7 @@ int main(int argc, char** argv) {
         else if (o == "--repeat" && a + 1 < argc) repeat = std::atoi(argv[++a]);
         else if (o == "--warmup" && a + 1 < argc) warmup = std::atoi(argv[++a]);
         else if (o == "--batch" && a + 1 < argc) batch = std::atoi(argv[++a]);
+        else if (o == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
     }
     if (batch > 0) {
@@ -330,15 +344,25 @@ int main(int argc, char** argv) {
         std::vector<std::thread> pool;
         Gate gate;
         gate.parties = streams;
-        for (int s = 0; s < streams; ++s) pool.emplace_back([&, s] { done[s] = play_pipelined(clip, depth, repeat, true, warmup, &gate, &begin[s], &end[s]); });
+        for (int s = 0; s < streams; ++s)
+            pool.emplace_back([&, s] { done[s] = play_pipelined(clips[(size_t)s % clips.size()], depth, repeat, true, warmup, &gate, &begin[s], &end[s], device); });
         for (auto& t : pool) t.join();
         Clock::time_point first = begin[0], last = end[0];
         for (int s = 1; s < streams; ++s) { if (begin[s] < first) first = begin[s]; if (end[s] > last) last = end[s]; }
         const double sec = std::chrono::duration<double>(last - first).count();
         long frames = 0;
-        for (long d : done) { if (d < 0) return 1; frames += d; }
-        std::printf("{\"streams\": %d, \"depth\": %d, \"frames\": %ld, \"warmup_passes\": %d, \"seconds\": %.6f, \"mpixels_per_s\": %.1f}\n", streams, depth, frames,
-                    warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6);
+        double compressed = 0;                                   // bytes handed to the decoders in the timed passes (what crosses the bus)
+        for (int s = 0; s < streams; ++s) {
+            if (done[s] < 0) return 1;
+            frames += done[s];
+            const Clip& c = clips[(size_t)s % clips.size()];
+            double per_pass = 0;
+            for (const auto& fr : c.frames) per_pass += (double)fr.second;
+            compressed += per_pass * (c.frames.empty() ? 0.0 : (double)done[s] / (double)c.frames.size());
+        }
+        std::printf("{\"streams\": %d, \"files\": %zu, \"depth\": %d, \"frames\": %ld, \"warmup_passes\": %d, \"seconds\": %.6f, \"mpixels_per_s\": %.1f, "
+                    "\"compressed_bytes\": %.0f, \"uploaded_bytes_per_s\": %.0f}\n", streams, clips.size(), depth, frames,
+                    warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6, compressed, compressed / sec);
         return 0;
     }
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),

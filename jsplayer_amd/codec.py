@@ -163,9 +163,13 @@ class _NativeCodec:
         where DecompressP raises)."""
         if ticket not in self._inflight:
             raise CodecError(f"no frame in flight under ticket {ticket}")
+        if ticket != next(iter(self._inflight)):
+            # (checked here as well: jsp_wait refuses it without consuming anything, and the frame's bytes and buffer must stay
+            # alive for as long as the native job holds them)
+            raise CodecError("tickets are waited for in submission order")
         out_ptr, signif = C.c_void_p(), C.c_int(0)
         rc = self._lib.jsp_wait(self._h, ticket, C.byref(out_ptr), C.byref(signif))
-        _, _, key = self._inflight.pop(ticket)
+        _, _, key = self._inflight.pop(ticket)   # jsp_wait consumes the oldest ticket whatever its result
         self._track_prev()
         if key:
             return DecoderState(rc)
@@ -178,8 +182,9 @@ class _NativeCodec:
 
     def StopAndClean(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.jsp_codec_destroy(self._h)
+            self._lib.jsp_codec_destroy(self._h)   # waits for whatever is still in flight
             self._h = None
+        self._inflight = {}                        # ... only then are the frames' bytes and buffers let go
         self._bufs = weakref.WeakValueDictionary()
         self._prev = None
 

@@ -163,6 +163,9 @@ void jsp_codec_destroy(jsp_codec* c) {
     try {
         c->activate();
         (void)hipStreamSynchronize(c->stream);
+        // frames still in flight (never waited for) on other streams of this codec: their kernels write buffers that the
+        // derived class's members own — wait here, before any destructor runs
+        if (c->next_ticket != c->oldest_ticket) (void)hipDeviceSynchronize();
     } catch (...) {
     }
     delete c;
@@ -320,7 +323,9 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
     if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
     c->ptr_mode = 1;
     if ((int)(c->next_ticket - c->oldest_ticket) >= c->async_depth) throw std::runtime_error("too many frames in flight: jsp_wait for the oldest first");
-    if ((int)c->jobs.size() != c->async_depth) c->jobs.resize(c->async_depth);
+    // (the ring only ever grows: a smaller `async_depth` changes the modulus, not the vector — the jobs beyond it keep their
+    // event and their staged object, whose device buffers the codec may still refer to: Msv1Codec::last_full_dev)
+    if ((int)c->jobs.size() < c->async_depth) c->jobs.resize(c->async_depth);
     jsp_async_job& j = c->jobs[c->next_ticket % c->async_depth];
     if (!j.done) JSP_HIP(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
     j.frame = jsp_frame_in{src, n, key, dst};
@@ -357,7 +362,15 @@ int wait_ticket(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* signific
     if (ticket != c->oldest_ticket || ticket >= c->next_ticket) throw std::runtime_error("tickets are waited for in submission order");
     c->activate();
     jsp_async_job& j = c->jobs[ticket % c->async_depth];
-    settle(c, ticket);
+    // from here on the ticket is consumed whatever happens: a caller may let go of the frame's `src` / `dst` exactly when
+    // jsp_wait was given the oldest ticket (anything that fails while settling the frame becomes the frame's error)
+    try {
+        settle(c, ticket);
+    } catch (const std::exception& e) {
+        j.status = JSP_ERROR_OCCURED;
+        j.why = e.what();
+        j.settled = true;
+    }
     if (j.status != JSP_ZERO_STATE) set_error("%s", j.why.c_str());
     ++c->oldest_ticket;
     j.ticket = 0;

@@ -8,7 +8,11 @@
 //
 // Reference semantics reproduced per block: MSVideo1.hx:124-181 (16-bit), :307-364 (8-bit),
 // copy_block :74-84, fromRGB15 :211-214, stage-2 significance compare :195-204.
+#include <cstdlib>
+#include <mutex>
+
 #include "msv1.h"
+#include "msv1_decode.h"
 
 namespace jsp {
 namespace {
@@ -394,6 +398,255 @@ __global__ __launch_bounds__(WG) void msv1_edge_compare_kernel(const Msv1FrameAr
         atomicOr(fa.signif, 1u);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Inter-frame groups, second form: a LOADER wave next to the four worker waves.
+//
+// A workgroup owns 256 blocks and walks the group's frames with their pixels in registers, as above.  What bounds
+// that walk is not bandwidth but latency: a CU's loads and stores share one in-order queue (and a wave's vmcnt counts
+// both), so the per-frame fetches — block table entry, then the code bytes it points at — each waited behind the row
+// stores of the frame before: ~3 us per frame, 1.5 ms per 512 frames at 0.37 of peak.  Here the worker waves never
+// issue a load inside the frame loop: a fifth wave fetches, CHUNK frames at a time, the tile's table entries and the
+// slice of the code stream they point into straight into LDS (global_load_lds: no registers), a whole chunk ahead of
+// the workers (two chunk buffers), and its own vmcnt only ever holds loads.  Chunks are handed over through two LDS
+// counters (`ready`, `consumed`); nobody waits at a workgroup barrier inside the loop.
+constexpr int TW = 4;                        // worker waves (lane = block)
+constexpr int TWG = (TW + 1) * 64;
+constexpr int T_NF = 16;                     // frames per chunk, at most
+constexpr int T_CODE = 14 * 1024;            // bytes of code stream per chunk (a frame needs at most 256 * 18 + 32)
+constexpr int T_SPIN = 1 << 24;              // polls before a wait gives up
+constexpr int T_SLACK = 64;                  // readable bytes behind a chunk's code bytes (a block reads 20 bytes from its code)
+struct TFrame {                              // what the workers need to know about one frame of a chunk
+    uint32_t* dst;
+    uint32_t code_at;                        // LDS byte offset (within the chunk's code area) of stream byte `lo`
+    uint32_t lo;                             // first stream byte held
+    uint32_t end;                            // end of the frame's readable stream bytes (16-bit: whole words only)
+    uint32_t cmp_row_lo;
+    uint32_t flags;                          // bit 0: the block's pixels come from `prev` first; bits 8..15: the odd last byte of a 16-bit stream
+    uint32_t index;                          // frame number within the group (significance bit)
+    uint32_t span;                           // stream bytes held (a multiple of 16)
+};
+struct TChunk {
+    uint32_t desc[T_NF][WG];
+    __attribute__((aligned(16))) uint8_t code[T_CODE + T_SLACK];
+    TFrame fr[T_NF];
+    int fidx[T_NF];                          // (loader) the frames whose table rows were fetched
+    const uint32_t* prev;                    // (chunk 0) the frame before the group
+    int nf;                                  // frames in this chunk
+    int next;                                // first frame of the group not yet in a chunk (== nframes: this is the last chunk)
+};
+
+typedef __attribute__((address_space(1))) const void t_gvoid;
+typedef __attribute__((address_space(3))) void t_lvoid;
+
+template <int BITS>
+__global__ __launch_bounds__(TWG) void msv1_blocks_temporal2_kernel(
+    const uint8_t* __restrict__ stream, const uint32_t* __restrict__ desc,
+    const Msv1FrameArgs* __restrict__ frames, int nframes, const int32_t* __restrict__ palette, int nblocks,
+    int nbx, int X) {
+    extern __shared__ __align__(16) uint8_t t_lds[];
+    TChunk* chunks = reinterpret_cast<TChunk*>(t_lds);                          // [2]
+    uint32_t* s_pal = reinterpret_cast<uint32_t*>(t_lds + 2 * sizeof(TChunk));  // [256]
+    uint32_t* s_sig = s_pal + 256;                                              // [(nframes + 31) / 32] stage-2 significance bits
+    // (LDS address space spelled out: through generic pointers the polls would be FLAT loads, which count on vmcnt too — a poll
+    // would then wait for the wave's row stores)
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* s_ready = (lds_vu32*)(s_sig + ((nframes + 31) >> 5));             // chunks handed over by the loader
+    lds_vu32* s_consumed = s_ready + 1;                                         // worker waves done, summed over chunks
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (provably uniform: the loader's loops then run on the scalar unit, its frame records are scalar loads)
+    if (BITS == 8 && tid < 256) s_pal[tid] = (uint32_t)palette[tid];
+    for (int i = tid; i < ((nframes + 31) >> 5) + 2; i += TWG) s_sig[i] = 0u;   // (+ ready, consumed)
+    __syncthreads();
+    const int blk0 = blockIdx.x * WG;
+
+    if (wave == TW) {
+        // ---------------------------------------- loader ----------------------------------------
+        const int live_blocks = nblocks - blk0 < WG ? nblocks - blk0 : WG;      // (the last tile is partial)
+        int f = 0, c = 0;
+        bool first = true;
+        while (f < nframes) {
+            TChunk& ck = chunks[c & 1];
+            // the buffer was chunk c - 2's: all its readers must be through
+            if (c >= 2)
+                for (int spin = 0; (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_consumed) < (uint32_t)(TW * (c - 1)) && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(2);
+            // 1. table entries of up to T_NF frames (frames that write nothing are left out), one 1 KiB row each
+            int nf = 0, scan = f;
+#pragma unroll 1
+            for (; scan < nframes && nf < T_NF; ++scan) {
+                const Msv1FrameArgs fa = frames[scan];
+                if (fa.pad & MSV1_FRAME_NOOP) continue;
+                if (lane * 4 < live_blocks)
+                    __builtin_amdgcn_global_load_lds((t_gvoid*)(desc + fa.desc_base + blk0 + lane * 4), (t_lvoid*)&ck.desc[nf][0], 16, 0, 0);
+                if (lane == 0) ck.fidx[nf] = scan;
+                ++nf;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // 2. per frame: which stream bytes its coded blocks point into, as long as the chunk's code area has room.  (The
+            //    extents are parked in the lanes of three registers: an LDS read issued after an LDS-DMA is made to wait for it,
+            //    and the requests of step 3 must all go out before any is waited for.)
+            uint32_t used = 0, v_lo = 0, v_need = 0, v_at = 0;
+            int kept = 0;
+#pragma unroll 1
+            for (int i = 0; i < nf; ++i) {
+                const int fi = __builtin_amdgcn_readfirstlane(ck.fidx[i]);
+                const Msv1FrameArgs fa = frames[fi];
+                uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+                if (lane * 4 < live_blocks) {
+                    const uint4 d4 = *reinterpret_cast<const uint4*>(&ck.desc[i][lane * 4]);
+                    const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (lane * 4 + k < live_blocks && dd[k] < MSV1_DESC_UNTOUCHED) { lo = min(lo, dd[k]); hi = max(hi, dd[k] + 18u); }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+                    hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+                }
+                lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo) & ~15u;       // (uniform by construction; said so: the loop stays scalar)
+                hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+                hi = hi < fa.stream_end ? hi : fa.stream_end;
+                const uint32_t len = hi > lo ? hi - lo : 0u, need = (len + 15u) & ~15u;
+                if (used + need > (uint32_t)T_CODE && kept > 0) break;          // this frame opens the next chunk
+                if (lane == 0) {
+                    TFrame tf;
+                    tf.dst = reinterpret_cast<uint32_t*>(fa.dst);
+                    tf.code_at = used;
+                    tf.lo = lo;
+                    tf.end = BITS == 16 ? (fa.stream_end & ~1u) : fa.stream_end;
+                    tf.cmp_row_lo = fa.cmp_row_lo;
+                    tf.flags = (first && (fa.pad & MSV1_FRAME_USES_PREV)) ? 1u : 0u;
+                    tf.index = (uint32_t)fi;
+                    tf.span = need;
+                    ck.fr[kept] = tf;
+                    if (first) ck.prev = reinterpret_cast<const uint32_t*>(fa.prev);
+                }
+                v_lo = lane == kept ? lo : v_lo;
+                v_need = lane == kept ? need : v_need;
+                v_at = lane == kept ? used : v_at;
+                first = false;
+                used = (used + need + T_SLACK + 15u) & ~15u;
+                ++kept;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // 3. ask for them
+#pragma unroll 1
+            for (int i = 0; i < kept; ++i) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v_lo, i), need = (uint32_t)__builtin_amdgcn_readlane((int)v_need, i),
+                               at = (uint32_t)__builtin_amdgcn_readlane((int)v_at, i);
+                for (uint32_t k = lane * 16u; k < need; k += 1024u)
+                    __builtin_amdgcn_global_load_lds((t_gvoid*)(stream + lo + k), (t_lvoid*)(ck.code + at + (k & ~1023u)), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // 4. bytes past the end of a frame's data read as zero (MSVideo1.hx: a missing byte is NaN, and every later expression
+            //    turns that into 0): zero [end, lo + span + T_SLACK) where it lies inside what a block may read; the odd last byte
+            //    of a 16-bit stream — half a word — is kept aside for the one case that reads it (a code word cut in two)
+#pragma unroll 1
+            for (int i = 0; i < kept; ++i) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck.fr[i].lo), end = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck.fr[i].end),
+                               span = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck.fr[i].span), at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck.fr[i].code_at);
+                if (span && lo + span + T_SLACK > end) {
+                    const uint32_t z0 = end > lo ? end - lo : 0u;
+                    if (BITS == 16 && lane == 0) {
+                        const uint32_t true_end = frames[ck.fr[i].index].stream_end;
+                        if ((true_end & 1u) && true_end > lo && true_end - 1u - lo < span) ck.fr[i].flags |= (uint32_t)ck.code[at + (true_end - 1u - lo)] << 8;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (uint32_t k = z0 + lane; k < span + T_SLACK; k += 64u) ck.code[at + k] = 0;
+                }
+            }
+            f = kept < nf ? __builtin_amdgcn_readfirstlane(ck.fidx[kept]) : scan;
+            if (lane == 0) { ck.nf = kept; ck.next = f; }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *s_ready = (uint32_t)(c + 1);
+            ++c;
+        }
+        return;
+    }
+
+    // ---------------------------------------- workers ----------------------------------------
+    const int blk = blk0 + tid;
+    const bool live = blk < nblocks;
+    const int by = blk / nbx;
+    const int bx = blk - by * nbx;
+    const size_t di = (size_t)by * 4u * (size_t)X + (size_t)bx * 4u;
+    uint32_t px[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) px[i] = 0;
+    // the first written frame of the group may need the frame before the group: fetched here, once, so that the frame loop
+    // below holds no load at all (a load inside it would make every round wait for the row stores in flight)
+    for (int spin = 0; *s_ready < 1u && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (chunks[0].nf > 0 && (chunks[0].fr[0].flags & 1u) && live) {
+        const uint32_t* __restrict__ prev = chunks[0].prev + di;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const uint4 r = load_row(prev + (size_t)y * X);
+            px[y * 4] = r.x; px[y * 4 + 1] = r.y; px[y * 4 + 2] = r.z; px[y * 4 + 3] = r.w;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int c = 0;; ++c) {
+        int spin = 0;
+        for (; *s_ready < (uint32_t)(c + 1) && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
+        if (spin >= T_SPIN) return;               // (cannot happen: every wait in this kernel is bounded so that a mistake ends the launch)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const TChunk& ck = chunks[c & 1];
+        const int nf = ck.nf, next = ck.next;
+        for (int i = 0; i < nf; ++i) {
+            const TFrame tf = ck.fr[i];
+            const uint32_t o = live ? ck.desc[i][tid] : MSV1_DESC_UNTOUCHED;
+            bool diff = false;
+            if (o < MSV1_DESC_UNTOUCHED) {
+                uint32_t nx[16];
+                const uint32_t avail = tf.end > o ? tf.end - o : 0u;
+                const uint32_t tail = (tf.flags >> 8) & 0xFFu;
+                // (16-bit: `end` counts whole words, the odd last byte is in flags; 8-bit: `end` is exact)
+                if (BITS == 16 ? (tail != 0u && o == tf.end) : avail == 1u) {
+                    // only the first byte of the code word exists: neither a skip nor a pattern test holds, the reference paints it solid
+                    const uint32_t a = BITS == 16 ? tail : (uint32_t)ck.code[tf.code_at + (o - tf.lo)];
+                    const uint32_t v = BITS == 16 ? rgb555_to_rgb32(a) : s_pal[a];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) nx[k] = v;
+                } else if (avail == 0u) {
+                    // the whole code lies past the end of the data (the table of a truncated frame): every byte reads as
+                    // missing, which the reference paints as colour 0 — and nothing of it is in LDS
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) nx[k] = 0u;
+                } else {
+                    decode_block<BITS>(ck.code + tf.code_at + (o - tf.lo), avail, s_pal, nx);
+                }
+                if (tf.cmp_row_lo != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        if ((uint32_t)(by * 4 + y) >= tf.cmp_row_lo)
+                            diff |= (nx[y * 4] != px[y * 4]) | (nx[y * 4 + 1] != px[y * 4 + 1]) | (nx[y * 4 + 2] != px[y * 4 + 2]) | (nx[y * 4 + 3] != px[y * 4 + 3]);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) px[k] = nx[k];
+            }
+            if (o != MSV1_DESC_UNTOUCHED) {       // coded or skipped: the block is (re)written in this frame's buffer
+                uint32_t* __restrict__ dst = tf.dst + di;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) store_row(dst + (size_t)y * X, px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]);
+            }
+            if (tf.cmp_row_lo != 0xFFFFFFFFu && __ballot(diff) != 0ull && lane == 0)
+                __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)&s_sig[tf.index >> 5], 1u << (tf.index & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)s_consumed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (next >= nframes) break;
+    }
+    // significance bits -> the frames' words (MSVideo1.hx:195-204), once the four worker waves are through
+    for (int spin = 0; *s_consumed < (uint32_t)(TW * (int)*s_ready) && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
+    for (int fi = tid; fi < nframes; fi += TW * 64)
+        if ((s_sig[fi >> 5] >> (fi & 31)) & 1u) {
+            gu32* sg = (gu32*)frames[fi].signif;
+            if (__hip_atomic_load(sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __hip_atomic_fetch_or(sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+
 }  // namespace
 
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
@@ -422,12 +675,29 @@ void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_strea
                                  const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
                                  hipStream_t stream) {
     if (geo.nblocks <= 0 || nframes <= 0) return;
-    dim3 grid((geo.nblocks + WG - 1) / WG), block(WG);
+    static const bool old_form = std::getenv("JSP_MSV1_TEMPORAL_OLD") != nullptr;   // lab: the frame-at-a-time kernel
+    if (old_form) {
+        dim3 grid((geo.nblocks + WG - 1) / WG), block(WG);
+        if (geo.bits == 16)
+            hipLaunchKernelGGL((msv1_blocks_temporal_kernel<16>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+                               d_palette, geo.nblocks, geo.nbx, geo.X);
+        else
+            hipLaunchKernelGGL((msv1_blocks_temporal_kernel<8>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+                               d_palette, geo.nblocks, geo.nbx, geo.X);
+        return;
+    }
+    const size_t lds = 2 * sizeof(TChunk) + 256 * 4 + (((size_t)nframes + 31) / 32 + 2) * 4;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    dim3 grid((geo.nblocks + WG - 1) / WG), block(TWG);
     if (geo.bits == 16)
-        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<16>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+        hipLaunchKernelGGL((msv1_blocks_temporal2_kernel<16>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
                            d_palette, geo.nblocks, geo.nbx, geo.X);
     else
-        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<8>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+        hipLaunchKernelGGL((msv1_blocks_temporal2_kernel<8>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
                            d_palette, geo.nblocks, geo.nbx, geo.X);
 }
 

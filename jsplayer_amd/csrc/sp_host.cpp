@@ -4,6 +4,7 @@
 #include "sp.h"
 
 #include <cstring>
+#include <exception>
 #include <thread>
 
 namespace jsp::sp {
@@ -530,11 +531,25 @@ void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<Host
     };
     {   // groups are dealt to the threads round robin; the calling thread takes its share
         const int nthreads = threads < ngroups ? threads : ngroups;
+        // (whatever is thrown on this thread — group 0's failure, or a thread that cannot be started — is kept until every
+        // thread that did start has been joined: unwinding past a joinable std::thread would end the process)
         std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; ++t)
-            pool.emplace_back([&, t] { for (int grp = t; grp < ngroups; grp += nthreads) run_group(grp); });
-        for (int grp = 0; grp < ngroups; grp += nthreads) run_group(grp);
+        std::exception_ptr failed;
+        int started = 1;
+        try {
+            for (int t = 1; t < nthreads; ++t, ++started)
+                pool.emplace_back([&, t] { for (int grp = t; grp < ngroups; grp += nthreads) run_group(grp); });
+        } catch (...) {
+            for (int t = started; t < nthreads; ++t)           // the shares of the threads that never started: not decoded side by side
+                for (int grp = t; grp < ngroups; grp += nthreads) usable[grp] = 0;
+        }
+        try {
+            for (int grp = 0; grp < ngroups; grp += nthreads) run_group(grp);
+        } catch (...) {
+            failed = std::current_exception();
+        }
         for (auto& th : pool) th.join();
+        if (failed) std::rethrow_exception(failed);
     }
     // A group stands if its key frame decoded (then nothing older shows through it).  The first that does not — and
     // everything behind it — is decoded again in order, by the decoder holding the state in front of it.

@@ -11,11 +11,14 @@ pytestmark = pytest.mark.gpu
 
 CASES = [
     # workload, kernels the staged decode must launch
-    ("msvideo1_16_1080p_keyframes_m1", ["msv1_fused_kernel"]),           # 512 M1 key frames from raw stream bytes
+    ("msvideo1_16_1080p_keyframes_m1", ["msv1_fused_kernel"]),           # 3 x 512 M1 key frames from raw stream bytes
     ("msvideo1_16_1080p_keyframes_m1_hostdesc", ["msv1_blocks_kernel"]),  # host-built descriptor table
     ("msvideo1_8_1080p_keyframes_m1", ["msv1_fused_kernel"]),
+    ("msvideo1_16_1080p_keyframes_solid", ["msv1_fused_kernel"]),         # one-slot codes only: 8192 blocks per 16 KiB tile, two staging windows
+    ("msvideo1_16_1080p_keyframes_eight", ["msv1_fused_kernel"]),         # nine-slot codes only
     ("msvideo1_16_1080p_inter70", ["msv1_fused_kernel", "msv1_blocks_temporal_kernel"]),   # 511 inter frames: descriptor form of the fused parse + one temporal launch
     ("screenpressor_v4_1080p_iframes", ["sp_iframe_tile_kernel"]),        # 256 key frames, wave-per-tile kernel
+    ("screenpressor_v2_1080p_iframes", ["sp_iframe_tile_kernel"]),        # the same through the version-2 range decoder
     ("screenpressor_v4_1080p_pclip300", ["sp_pframe_group_kernel"]),      # 2 x 299 inter frames, group kernel
 ]
 

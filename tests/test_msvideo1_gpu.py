@@ -242,6 +242,41 @@ def test_batch_with_inter_frames_matches_oracle():
 
 
 @pytest.mark.parametrize("bits", [16, 8])
+def test_look_back_fault_falls_back_to_the_descriptor_kernels(bits):
+    """A tile that gives up waiting for its predecessor (GPU shared with other work, profiler serialisation) is a matter of
+    timing, not of the stream: the batch must then come out right through the three-kernel parse + block kernels, not as an
+    error.  (The give-up itself cannot be provoked on demand: option msv1_inject_fault makes the batch's next check behave
+    as if it had happened.)"""
+    if PARSE_MODE != "gpu":
+        pytest.skip("on-GPU parse only")
+    w, h, n = 320, 240, 12
+    frames, keys, pal = sg.msv1_clip(7, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.6, 30.0), key_every=5)
+    gpu = make_gpu(bits, w, h, pal)
+    gpu.Preinit(36)
+    gpu.set_option("msv1_inject_fault", "1")
+    dsts = [dev_buf(w * h, 3) for _ in range(n)]
+    st = gpu.stage_batch(frames, dsts, is_key=keys)
+    assert "fallback" not in st.kernels()
+    st.decode()
+    gpu.sync()
+    status, adopted, signif = st.results()
+    assert "look-back fallback" in st.kernels()
+    assert status == [0] * n
+    orc = OracleMSVideo1(bits, w, h, pal)
+    orc.Preinit(36)
+    obufs = [np.full(w * h, 3, dtype=np.int32) for _ in range(n)]
+    for i in range(n):
+        if keys[i]:
+            orc.DecompressI(frames[i], obufs[i])
+        else:
+            data, sig = orc.DecompressP(frames[i], obufs[i])
+            assert bool(signif[i]) == sig
+            assert bool(adopted[i]) == (data is obufs[i])
+        assert np.array_equal(obufs[i], to_np(dsts[i])), i
+    st.close()
+
+
+@pytest.mark.parametrize("bits", [16, 8])
 def test_fuzz_many_random_streams(bits):
     """A few thousand short random / mutated streams at random small sizes: oracle and HIP path must
     agree on every pixel, every significant_changes flag and every buffer identity."""
