@@ -319,6 +319,18 @@ def main():
                     traffic, traffic_source = ent["hbm_bytes"], ent["source"]
             except Exception:
                 pass
+        # the measured ceiling of this box's HBM for streaming stores / copies (tools/hbm_ceiling.hip, kept under profiles/):
+        # SURVEY.md 8(d) asks for the fraction of that beside the fraction of the 8 TB/s on the data sheet
+        ceiling = None
+        cpath = os.path.join(ROOT, "profiles", "hbm_ceiling.json")
+        if os.path.exists(cpath):
+            try:
+                cj = json.load(open(cpath))
+                write_share = sum(i["pixels"] for i in infos) * 4 / max(counted, 1)      # the frames written, of all bytes counted
+                kind = "fill" if write_share >= 0.8 else "copy"
+                ceiling = {"value": cj[kind + "_GBs"], "unit": "GB/s", "kind": kind, "shape": cj[kind + "_shape"], "source": cj["source"]}
+            except Exception:
+                ceiling = None
         out = {
             "metric": "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs",
             "value": round(total_pixels / elapsed / 1e6, 1),
@@ -352,6 +364,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "measured_ceiling": ceiling,
+                "frac_of_measured": round(achieved / ceiling["value"], 4) if ceiling else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_step": alg,

@@ -59,6 +59,9 @@ struct Clip {
         const uint8_t* data() const { return p; }
         size_t size() const { return n; }
         ~Bytes() { jsp_host_free(p); }
+        Bytes() = default;
+        Bytes(const Bytes&) = delete;             // (owns pinned memory: a Clip is never copied)
+        Bytes& operator=(const Bytes&) = delete;
     } bytes;
 };
 
@@ -298,7 +301,7 @@ int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: %s clip.avi [--pipelined [--depth D] [--quiet [--streams T] [--repeat R] [--warmup W]]] | --batch B [--quiet [--repeat R]]\n", argv[0]); return 2; }
     // (throughput runs: several files, separated by commas — stream s plays file s modulo their number, so that the streams of a
     // multi-stream run are independent inputs)
-    std::vector<Clip> clips;
+    std::deque<Clip> clips;                                   // (a deque: elements never move)
     {
         std::string list = argv[1];
         for (size_t at = 0; at <= list.size();) {

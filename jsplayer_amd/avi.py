@@ -253,104 +253,3 @@ def read_avi(data: bytes) -> Tuple[VideoInfo, List[bytes]]:
     walk(12, min(len(data), 8 + riff_size), False)
     vi = VideoInfo(riff_size=riff_size, **info)
     return vi, frames
-
-
-class AviStream:
-    """Incremental reader: bytes arrive in arbitrary pieces (the reference parses while an XHR download trickles in,
-    AVIParser.hx:142-171 over ParserUtils' buffered combinators) and frames come out as soon as their chunk is complete.
-
-        rd = AviStream()
-        for piece in pieces:
-            for blob in rd.feed(piece):      # blobs exactly as read_avi() returns them (payload + pad byte)
-                ...
-        rd.info                              # VideoInfo once the stream format has been seen, else None
-
-    Only complete chunks are consumed; a LIST is entered as soon as its 12-byte head is there, so `movi` frames do not
-    wait for the end of the list."""
-
-    def __init__(self):
-        self._buf = bytearray()
-        self._base = 0                 # file offset of _buf[0]
-        self._pos = 0                  # file offset of the next unparsed byte
-        self._ends: List[Tuple[int, bool]] = []   # open LISTs: (end offset, inside movi)
-        self._riff_end = None
-        self._fields = dict(X=0, Y=0, bpp=32, fps=15.0, nframes=0, codec=CODEC_SCREENPRESSOR, palette=None)
-        self._fourcc = None
-        self._is_video = False
-        self._have_video = False
-        self._riff_size = 0
-        self.info: Optional[VideoInfo] = None
-        self.frames_seen = 0
-
-    def _have(self, upto: int) -> bool:
-        return upto <= self._base + len(self._buf)
-
-    def _get(self, lo: int, hi: int) -> bytes:
-        return bytes(self._buf[lo - self._base:hi - self._base])
-
-    def feed(self, piece: bytes) -> List[bytes]:
-        self._buf += piece
-        out: List[bytes] = []
-        while True:
-            if self._riff_end is None:
-                if not self._have(12):
-                    break
-                head = self._get(0, 12)
-                if head[:4] != b"RIFF" or head[8:12] != b"AVI ":
-                    raise ValueError("not a RIFF/AVI file")
-                self._riff_size = struct.unpack_from("<I", head, 4)[0]
-                self._riff_end = 8 + self._riff_size
-                self._pos = 12
-                continue
-            while self._ends and self._pos >= self._ends[-1][0]:
-                self._ends.pop()
-            limit = self._ends[-1][0] if self._ends else self._riff_end
-            if self._pos + 8 > limit or not self._have(self._pos + 8):
-                break
-            tag = self._get(self._pos, self._pos + 4)
-            size = struct.unpack_from("<I", self._get(self._pos + 4, self._pos + 8))[0]
-            body, padded = self._pos + 8, (size + 1) & ~1
-            if tag == b"LIST":
-                if not self._have(body + 4):
-                    break
-                kind = self._get(body, body + 4)
-                in_movi = (self._ends[-1][1] if self._ends else False) or kind == b"movi"
-                self._ends.append((min(body + size, limit), in_movi))
-                self._pos = body + 4
-                continue
-            # the last chunk of a file may lack its pad byte: read_avi slices what is there, so wait only for what exists
-            want = min(body + padded, limit)
-            if not self._have(want):
-                break
-            data = self._get(body, want)
-            in_movi = self._ends[-1][1] if self._ends else False
-            if tag == b"avih":
-                usec, _, _, _, total = struct.unpack_from("<5I", data, 0)
-                w, h = struct.unpack_from("<2I", data, 32)
-                self._fields.update(X=w, Y=h, nframes=total, fps=1e6 / (usec if usec else 66666))
-            elif tag == b"strh":
-                self._is_video = data[:4] == b"vids" and not self._have_video
-                if self._is_video:
-                    self._fourcc = data[4:8]
-                    self._fields["nframes"] = struct.unpack_from("<I", data, 32)[0]
-            elif tag == b"strf" and self._is_video:
-                bits = struct.unpack_from("<H", data, 14)[0]
-                self._fields["bpp"] = bits
-                fourcc = data[16:20] if self._fourcc == b"\0\0\0\0" else self._fourcc
-                if fourcc in _MSVC_FOURCCS:
-                    self._fields["codec"] = CODEC_MSVC8 if bits == 8 else CODEC_MSVC16
-                if bits == 8 and len(data) > 40:
-                    self._fields["palette"] = data[40:]
-                self._is_video, self._have_video = False, True
-                self.info = VideoInfo(riff_size=self._riff_size, **self._fields)
-            elif in_movi and tag in (b"00dc", b"00db"):
-                out.append(data)
-                self.frames_seen += 1
-            self._pos = body + padded
-            # forget what has been parsed
-            drop = self._pos - self._base
-            if drop > 1 << 16:
-                del self._buf[:drop]
-                self._base += drop
-        return out
-

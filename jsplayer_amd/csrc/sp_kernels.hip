@@ -250,6 +250,13 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     int y_end = yb, wn = 0;
     bool direct = false;
     uint2 wv[WMAX];                                            // the window's records on their way from memory
+    // The window's loads are written as asm and waited for BY COUNT.  A wave's loads and stores share one in-order counter
+    // (vmcnt): the compiler, seeing loads whose results are used after a loop of row stores, waits for vmcnt(0) — every window
+    // then also waited for the acknowledgement of all its own row stores, 2-3 us a dozen times per tile.  Issued as asm the
+    // loads are invisible to that bookkeeping; exactly WMAX load instructions go out per window (lanes past the window's end
+    // re-read its last record) and every row issues exactly one row store, so after R rows `s_waitcnt vmcnt(R)` says precisely
+    // "the window's records have landed" while the R stores behind them stay in flight.
+    unsigned long long wva[WMAX];
     auto plan_and_fetch = [&](int from) {
         w0 = idx[from - yb] & OFF;
         y_end = from + 1;
@@ -259,12 +266,28 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         if (direct) wn = 0;
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
-            const int k = lane + 64 * q;
-            wv[q] = make_uint2(0, 0);
-            if (k < wn) wv[q] = load2_global(gruns + w0 + k);
+            const int k = lane + 64 * q, kk = k < wn ? k : (wn > 0 ? wn - 1 : 0);
+            const uint2* src = gruns + w0 + kk;                // (always a record of this tile)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wva[q]) : "v"(src) : "memory");
+        }
+    };
+    // wait until at most `stores_behind` vector-memory operations of this wave are outstanding (the newest ones), then hand the
+    // window's registers over to the compiler
+    auto settle_window = [&](int stores_behind) {
+        switch (stores_behind < 16 ? stores_behind : 16) {     // (more than 16 rows per window: waiting down to 16 is just as exact)
+#define JSP_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+            JSP_VM(0) JSP_VM(1) JSP_VM(2) JSP_VM(3) JSP_VM(4) JSP_VM(5) JSP_VM(6) JSP_VM(7) JSP_VM(8)
+            JSP_VM(9) JSP_VM(10) JSP_VM(11) JSP_VM(12) JSP_VM(13) JSP_VM(14) JSP_VM(15) JSP_VM(16)
+#undef JSP_VM
+        }
+#pragma unroll
+        for (int q = 0; q < WMAX; ++q) {
+            asm volatile("" : "+v"(wva[q]));                   // (the value is defined from here on)
+            wv[q] = make_uint2((uint32_t)wva[q], (uint32_t)(wva[q] >> 32));
         }
     };
     plan_and_fetch(yb);
+    int rows_since_fetch = 0;                                  // row stores issued after the loads in flight
     while (y < ye) {
         // The window's records were asked for a window ago — all of them at once, and BEFORE the rows of the window in
         // between were stored: in a load -> wait -> LDS-write loop each 64 records cost a memory round trip of their own, and
@@ -273,12 +296,14 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         const uint32_t cw0 = w0;
         const int cy_end = y_end, cwn = wn;
         const bool cdirect = direct;
+        settle_window(rows_since_fetch);
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
             const int k = lane + 64 * q;
             if (k < cwn) win[k] = wv[q];
         }
         if (cy_end < ye) plan_and_fetch(cy_end);               // the next window's records start travelling now
+        rows_since_fetch = 0;
         {
             const uint32_t r0 = cw0, r1 = idx[y + 1 - yb] & OFF, origin = (uint32_t)((size_t)y * X + xs);
             if (cdirect) {
@@ -355,6 +380,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) p[j] = q[j];
             }
+            rows_since_fetch += V;                             // (one row store per 4 pixels of the lane, issued by every wave with an active lane)
             const uint32_t origin_next = row0 + (uint32_t)X + (uint32_t)xs;
             if (lane < n_next) head[nrec.x - origin_next] = nrec.y | HEAD_PRESENT;
             for (int r = lane + 64; r < n_next; r += 64) {   // rows with more records than lanes

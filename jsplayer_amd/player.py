@@ -210,29 +210,3 @@ class Manager:
         while flying:
             collect()
         return self.log
-
-
-def play_incremental(pieces, classes, alloc: Callable[[int], object],
-                     on_frame: Optional[Callable[[DecodedFrame, object], None]] = None) -> Optional[Manager]:
-    """Decode while the file is still arriving: `pieces` is any iterable of byte strings (the reference feeds its parser
-    from XHR progress events, DataLoaderAVISeq.hx).  The decoder is built as soon as the stream format has been seen
-    (Manager.video_info_cb, Manager.hx:103-142); every frame is decoded the moment its chunk is complete."""
-    from .avi import AviStream
-    rd = AviStream()
-    mgr: Optional[Manager] = None
-    index, prev_key, last_was_key = 0, None, False
-    for piece in pieces:
-        for blob in rd.feed(piece):
-            if mgr is None:
-                if rd.info is None:
-                    raise ValueError("frame data before the stream format")
-                mgr = Manager(rd.info, make_decoder(rd.info, classes), alloc)
-            was_key = index == 0 or mgr.decoder.IsKeyFrame(blob)
-            d = mgr.worker(blob, index, prev_key if was_key and index > 0 and last_was_key else None, was_key)
-            last_was_key = was_key
-            prev_key = blob if was_key else prev_key
-            if on_frame:
-                on_frame(d, mgr.buffers[d.buffer_index])
-            index += 1
-    return mgr
-

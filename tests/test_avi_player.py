@@ -329,51 +329,3 @@ def test_cpp_player_pipelined_shows_the_same_pictures(what, tmp_path):
     assert res.returncode == 0, res.stderr.decode()
     rate = json.loads(res.stdout.decode())
     assert rate["streams"] == 3 and rate["frames"] == 3 * 2 * len(outs[0]) and rate["mpixels_per_s"] > 0
-
-
-@pytest.mark.parametrize("per_ix", [0, 4])
-def test_incremental_reader_yields_the_same_frames_however_the_bytes_arrive(per_ix):
-    """AviStream: the file fed in pieces of random size (down to one byte) gives the blobs and the VideoInfo of the
-    one-shot reader; a frame is available as soon as its chunk is complete, before the movi list ends."""
-    rng = np.random.default_rng(4)
-    frames = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in (10, 33, 0, 64, 7, 7, 128, 1, 90000, 2, 31)]
-    pal = bytes(rng.integers(0, 256, size=1024, dtype=np.uint8))
-    blob = avi.write_avi(64, 48, frames, fourcc=b"CRAM", bpp=8, palette=pal, opendml_frames_per_ix=per_ix)
-    vi, ref = avi.read_avi(blob)
-    for trial in range(25):
-        rd, got, pos, first_at = avi.AviStream(), [], 0, None
-        top = 1 if trial == 0 else int(rng.choice([3, 50, 700, 5000, 200000]))
-        while pos < len(blob):
-            n = int(rng.integers(1, top + 1))
-            got += rd.feed(blob[pos:pos + n])
-            pos += n
-            if got and first_at is None:
-                first_at = pos
-        assert got == ref and rd.info == vi and rd.frames_seen == len(ref)
-        if top <= 700:
-            assert first_at < len(blob) // 2           # frames did not wait for the end of the file
-    with pytest.raises(ValueError):
-        avi.AviStream().feed(b"RIFX" + blob[4:16])
-    # a file cut off before the pad byte of its last chunk: still every complete chunk
-    blob2 = avi.write_avi(16, 8, [b"\x01\x02\x03"])
-    cut = blob2[:blob2.index(b"idx1")]
-    cut = cut[:4] + (len(cut) - 9).to_bytes(4, "little") + cut[8:-1]
-    assert avi.AviStream().feed(cut) == avi.read_avi(cut)[1]
-
-
-def test_decode_while_the_file_is_still_arriving():
-    """play_incremental: pieces of the file in, pictures out — the same pictures, slots and flags as playing the
-    complete file."""
-    chunks, keys, frames = sg.sp_clip(7, 64, 48, 8, version=2, key_every=4, unchanged_at=(2,))
-    blob = avi.write_avi(64, 48, chunks, fourcc=b"SCPR", bpp=24)
-    vi, got = avi.read_avi(blob)
-    ref = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
-    ref_pics = []
-    ref.play(got, on_frame=lambda d, buf: ref_pics.append((d.index, d.key, d.buffer_index, d.significant_changes, buf.copy())))
-    pieces = [blob[i:i + 997] for i in range(0, len(blob), 997)]
-    pics = []
-    mgr = player.play_incremental(pieces, ORACLE_CLASSES, lambda n: np.zeros(n, dtype=np.int32),
-                                  on_frame=lambda d, buf: pics.append((d.index, d.key, d.buffer_index, d.significant_changes, buf.copy())))
-    assert mgr is not None and len(pics) == len(ref_pics) == 8
-    for a, b in zip(pics, ref_pics):
-        assert a[:4] == b[:4] and np.array_equal(a[4], b[4])

@@ -12,12 +12,16 @@ from oracle_binding import OracleMSVideo1, OracleScreenPressor
 DOC = json.load(open(wl.GOLDEN))
 
 
-def test_default_workload_is_recorded_for_all_eight_ranks():
+@pytest.mark.parametrize("name", [wl.DEFAULT, "screenpressor_v4_1080p_pclip300"])
+def test_eight_stream_workloads_are_recorded_for_all_eight_ranks(name):
+    """the 8-stream configuration is 8 copies (seeds +0..+7) of the MSVideo1 key-frame workload and
+    of the ScreenPressor inter-frame clip."""
+    spec = wl.WORKLOADS[name]
     for r in range(8):
-        d = DOC["digests"][f"{wl.DEFAULT}/rank{r}"]
-        assert len(d) == 1 and len(d[0]) == wl.WORKLOADS[wl.DEFAULT]["frames"]
-    firsts = {DOC["digests"][f"{wl.DEFAULT}/rank{r}"][0][0] for r in range(8)}
-    assert len(firsts) == 8, "ranks decode distinct streams"
+        d = DOC["digests"][f"{name}/rank{r}"]
+        assert len(d) == spec.get("clips", 1) and all(len(c) == spec["frames"] for c in d)
+    firsts = {DOC["digests"][f"{name}/rank{r}"][c][0] for r in range(8) for c in range(spec.get("clips", 1))}
+    assert len(firsts) == 8 * spec.get("clips", 1), "ranks and clips decode distinct streams"
 
 
 @pytest.mark.parametrize("key", sorted(k for k in DOC["digests"] if k.endswith("/rank0")))

@@ -64,3 +64,21 @@ def test_two_rank_counter_reduce_over_gloo():
 def test_single_process_passthrough():
     assert reduce_counters(3, 30, 0.25) == (3, 30, 0.25)
     assert gather_per_rank(7) == [7]
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it starts torch.distributed.run as a child process (before anything
+    touches a GPU) and the ranks meet in the counter collectives; --dry-run: gloo, nothing decoded (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr.decode()[-800:]
+    line = [l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1]
+    doc = json.loads(line)
+    assert doc["n_gpus"] == 2 and doc["dry_run"] is True and doc["value"] is None
+    assert len(doc["per_rank_frames"]) == 2 and doc["per_rank_frames"][0] == doc["per_rank_frames"][1] > 0
+    assert doc["total_frames"] == sum(doc["per_rank_frames"])
