@@ -259,23 +259,27 @@ def main():
             for tf in files:
                 tf.close()
         batch_api = None
-        if spec["codec"] == "sp" and not inter and args.gpus == 1:
-            # the same sample through the batch calls: jsp_stage_batch (host stage of the whole batch: groups of pictures side by
-            # side on host threads) + jsp_staged_decode, wall clock from host bytes to frames in HBM — one stream, but not one
-            # frame per call
+        if not inter and "inter" not in spec and args.gpus == 1:
+            # the same sample through the batch calls, from HOST bytes, wall clock to frames in HBM: jsp_stage_batch (ScreenPressor:
+            # the host entropy stage takes the batch's groups of pictures side by side; MSVideo1: the bytes are gathered on several
+            # threads — or uploaded from where they are when the caller keeps them in pinned memory — and parsed on the GPU) +
+            # jsp_staged_decode; one stream, but not one frame per call.  First call (buffers allocated) and re-staging.
             fr = clips[0].frames[:ncap]
             codec = wl.make_codec(args.workload, clips[0].palette, device=local_rank)
             dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in fr]
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            st = codec.stage_batch(fr, dsts, is_key=clips[0].keys[:ncap])
-            st.decode()
-            codec.sync()
-            dt = time.perf_counter() - t0
-            batch_api = {"value": round(len(fr) * W * H / dt / 1e6, 1), "unit": "Mpixels/s", "frames": len(fr),
+            st, times = None, []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                st = codec.stage_batch(fr, dsts, is_key=clips[0].keys[:ncap], reuse=st)
+                st.decode()
+                codec.sync()
+                times.append(time.perf_counter() - t0)
+            batch_api = {"value": round(len(fr) * W * H / min(times[1:]) / 1e6, 1), "unit": "Mpixels/s", "frames": len(fr),
+                         "first_call": round(len(fr) * W * H / times[0] / 1e6, 1),
                          "host_stage_ms": round(st.info()["host_stage_ms"], 1),
-                         "note": "jsp_stage_batch + jsp_staged_decode of the same frames from host bytes, one stream; the host stage takes the "
-                                 "batch's groups of pictures side by side (option sp_host_threads, auto = up to 8 threads)"}
+                         "note": "jsp_stage_batch + jsp_staged_decode of the same frames from host bytes (pageable memory), one stream, wall "
+                                 "clock; value = re-staging into the same batch object, first_call = including its buffer allocations"}
             st.close()
             del dsts
         # job-wide: the ranks played at the same time, each on its own GPU; rates add up

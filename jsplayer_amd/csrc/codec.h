@@ -52,6 +52,7 @@ struct jsp_async_job {
     bool settled = false;                // results already final (its kernels were waited for ahead of its jsp_wait)
     int status = 0, significant = 0;
     std::string why;                     // error text of a final non-zero status
+    bool by_worker = false;              // the frame's host stage and launches run on a worker thread of the codec (async_by_workers)
 };
 
 struct jsp_codec {
@@ -104,6 +105,18 @@ struct jsp_codec {
     // Called (stream idle) before frames are re-run through the synchronous path: undo whatever made the frames in
     // flight behind the failed one stand still.
     virtual void async_reset() {}
+    // Asynchronous path served by worker threads of the codec's own (ScreenPressor: a coded key frame renews every bit of
+    // decoder state, so the host entropy stage of the frames from one coded key frame to the next runs on a thread and a
+    // decoder of its own, beside the groups of pictures before it).  worker_submit() returns at once — it hands the frame to
+    // a worker and PREDICTS what the frame does to the previous frame (prev_caller / prev_dev; decidable from the frame's
+    // first byte for every stream that decodes) —, worker_wait() blocks until the frame's host stage and launches are
+    // through (its event is recorded), worker_drain() until every submitted frame is and puts the stream's state back where
+    // the synchronous entry points expect it.
+    virtual bool async_by_workers() { return false; }
+    virtual void worker_submit(jsp_async_job&) {}
+    virtual void worker_wait(jsp_async_job&) {}
+    virtual void worker_drain() {}
+    int32_t* settled_prev = nullptr;     // (worker path) the previous frame as the frames waited for so far really left it
 
     void init_device(int device_id);
     void activate();

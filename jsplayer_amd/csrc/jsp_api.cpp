@@ -97,6 +97,7 @@ int decompress_one(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, boo
         return JSP_ERROR_OCCURED;
     }
     c->activate();
+    c->worker_drain();
     const int mode = classify_pointer(dst);
     if (c->ptr_mode == 0) c->ptr_mode = mode;
     if (c->ptr_mode != mode) {
@@ -162,6 +163,7 @@ void jsp_codec_destroy(jsp_codec* c) {
     if (!c) return;
     try {
         c->activate();
+        c->worker_drain();
         (void)hipStreamSynchronize(c->stream);
         // frames still in flight (never waited for) on other streams of this codec: their kernels write buffers that the
         // derived class's members own — wait here, before any destructor runs
@@ -306,6 +308,21 @@ void redo_from(jsp_codec* c, uint64_t from) {
 void settle(jsp_codec* c, uint64_t t) {
     jsp_async_job& j = c->jobs[t % c->async_depth];
     if (j.redone || j.settled) return;
+    if (j.by_worker) {
+        c->worker_wait(j);                               // host stage done, uploads and kernels queued, the event recorded
+        JSP_HIP(hipEventSynchronize(j.done));
+        j.st->finish_results();
+        j.status = j.st->status[0];
+        j.significant = j.st->significant[0] < 0 ? 0 : j.st->significant[0];
+        if (j.status != JSP_ZERO_STATE) j.why = j.st->why.empty() ? "decode aborted: the reference raises on this stream" : j.st->why;
+        // what the frame really did to the previous frame (frames are settled in submission order)
+        if (!j.st->cleared.empty() && j.st->cleared[0]) c->settled_prev = nullptr;
+        if (j.st->adopted[0]) c->settled_prev = j.frame.dst;
+        j.prev_caller_after = c->settled_prev;
+        if (t + 1 == c->next_ticket) c->prev_caller = c->settled_prev;   // (nothing submitted behind it: the prediction gives way)
+        j.settled = true;
+        return;
+    }
     JSP_HIP(hipEventSynchronize(j.done));
     j.st->finish_results();
     if (!c->async_finish(j.st.get())) { redo_from(c, t); return; }
@@ -329,6 +346,20 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
     jsp_async_job& j = c->jobs[c->next_ticket % c->async_depth];
     if (!j.done) JSP_HIP(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
     j.frame = jsp_frame_in{src, n, key, dst};
+    if (c->async_by_workers()) {
+        if (c->next_ticket == c->oldest_ticket) c->settled_prev = c->prev_caller;   // nothing in flight: predictions start from the facts
+        j.prev_caller_before = c->prev_caller;
+        j.prev_dev_before = c->prev_dev;
+        j.redone = j.settled = false;
+        j.by_worker = true;
+        j.why.clear();
+        c->worker_submit(j);
+        j.prev_caller_after = c->prev_caller;
+        j.ticket = c->next_ticket++;
+        *ticket = j.ticket;
+        return JSP_ZERO_STATE;
+    }
+    j.by_worker = false;
     if (c->async_settle_first(j.frame))
         for (uint64_t t = c->oldest_ticket; t < c->next_ticket; ++t)
             if (c->jobs[t % c->async_depth].st->verdict_pending) settle(c, t);   // the others were settled when they were staged
@@ -407,6 +438,7 @@ int jsp_sync(jsp_codec* c) {
     if (!c) { set_error("null codec"); return JSP_ERROR_OCCURED; }
     return guarded([&] {
         c->activate();
+        c->worker_drain();
         JSP_HIP(hipStreamSynchronize(c->stream));
         return 0;
     });
@@ -438,6 +470,7 @@ jsp_staged* stage_batch_into(jsp_codec* c, jsp_staged* reuse, int nframes, const
         }
         if (c->ptr_mode == 2) throw std::runtime_error("codec is in host-pointer mode");
         if (nframes) c->ptr_mode = 1;
+        c->worker_drain();
         jsp_staged* st = c->stage(frames, reuse);
         if (reuse && st != reuse) delete reuse;       // (a batch object of another kind: replaced)
         for (int i = 0; i < nframes; ++i) {

@@ -158,6 +158,7 @@ private:
 // most a quarter of their pixels get literalise_motion() applied (what the staged batch's group launches need).
 struct HostFrame { const uint8_t* src; size_t n; bool key; };
 bool starts_group(const HostFrame& f);   // a coded key frame
+void decode_single(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise);   // one frame through decoder `d` (what decode_frames does per frame)
 void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<HostDecoder>>& spare, const HostFrame* frames,
                    int count, FrameOut* outs, int threads, bool literalise);
 

@@ -1,8 +1,13 @@
 // ScreenPressor behind the IVideoCodec-shaped C ABI: host entropy stage (sp_host.cpp) + HIP
 // reconstruction (sp_kernels.hip).
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_set>
 
@@ -54,6 +59,8 @@ struct SpStaged : jsp_staged {
     }
 };
 
+std::atomic<int> g_sp_async_streams{0};   // ScreenPressor codec instances of this process whose asynchronous calls run on worker threads
+
 struct SpCodec : jsp_codec {
     HostDecoder host;
     std::vector<FrameOut> outs;                          // what the host stage says about the frames in hand (their tables keep their memory)
@@ -66,7 +73,229 @@ struct SpCodec : jsp_codec {
         if (w > kMaxIntraWidth) throw std::runtime_error("ScreenPressor frames wider than 8192 pixels are not supported");
         if (iframe_lds_bytes(host.geo()) > 160 * 1024) throw std::runtime_error("ScreenPressor frame too large for the LDS plan of the I-frame kernel");
     }
-    int preinit(int lines) override { host.preinit(lines); return JSP_ZERO_STATE; }
+    int preinit(int lines) override { worker_drain(); host.preinit(lines); return JSP_ZERO_STATE; }
+
+    // ---- asynchronous path on worker threads: groups of pictures side by side ------------------------------------------------
+    // A group = the frames from one coded key frame up to the next.  The frames handed to the asynchronous calls since the
+    // last drain form groups in submission order; the first continues whatever the stream's decoder (`host`) holds, every
+    // later one gets a decoder of its own (kept in `spare` between uses).  A group is run from start to finish by ONE worker
+    // thread: host entropy stage of a frame, its tables packed and uploaded, its kernels queued on the codec's stream, the
+    // job's event recorded — frame after frame, as they are submitted.  Frames of different groups depend on nothing of each
+    // other (neither decoder state nor pixels), so their host stages overlap; inside a group everything stays in order.
+    // If a group's key frame does not decode, older state shows through in the reference (the models are only renewed by a
+    // key frame that decodes): the group then waits for the group before it and goes on with THAT group's decoder.
+    struct Group {
+        std::unique_ptr<HostDecoder> own;        // null: the stream's decoder
+        HostDecoder* dec = nullptr;
+        std::shared_ptr<Group> before;           // the group in front, until this group's first frame has decoded
+        std::deque<jsp_async_job*> tasks;
+        bool closed = false, finished = false, first_done = false, successor_settled = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::shared_ptr<Group>> ready;     // groups no worker has taken yet
+    std::vector<std::shared_ptr<Group>> groups;   // every group since the last drain, in order
+    std::vector<std::thread> workers;
+    bool quitting = false;
+    int opt_async_threads = 0;                    // 0 = auto; 1 = the calling thread does everything (no workers)
+    int stream_version = 0;                       // entropy coder the stream is pinned to (0: none yet), as far as submission has got
+    bool seen_key = false;                        // (prediction) a key frame has been decoded
+    int32_t* pred_prev_dev = nullptr;             // (prediction) device pointer of the previous frame after the last submitted frame
+    struct JobExtra { bool done = false; };
+    std::vector<JobExtra> extra;                  // per ring slot: the worker is through with the slot's job
+
+    // auto: the host's threads are shared by the ScreenPressor streams of the process that use the asynchronous calls — one
+    // stream gets up to 8 workers, sixteen streams on sixteen cores get none (each then runs its host stage inside the call,
+    // as before: sixteen streams already keep sixteen cores busy)
+    int async_threads() const {
+        if (opt_async_threads > 0) return opt_async_threads;
+        const int streams = std::max(1, g_sp_async_streams.load());
+        int t = (int)std::thread::hardware_concurrency() / streams;
+        return t < 2 ? 1 : (t > 8 ? 8 : t);
+    }
+    bool async_by_workers() override {
+        if (!counted_async) { counted_async = true; g_sp_async_streams.fetch_add(1); }   // (a stream that uses the asynchronous calls)
+        if (async_threads() > 1) return true;
+        worker_drain();                            // (the budget changed under a stream that had workers: back to the calling thread)
+        return false;
+    }
+    bool counted_async = false;
+
+    ~SpCodec() override {
+        try { worker_drain(); } catch (...) {}
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quitting = true;
+        }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+        if (counted_async) g_sp_async_streams.fetch_sub(1);
+    }
+
+    void worker_main() {
+        (void)hipSetDevice(device);
+        std::vector<FrameOut> outs_local(1);
+        for (;;) {
+            std::shared_ptr<Group> g;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return quitting || !ready.empty(); });
+                if (ready.empty()) return;        // quitting
+                g = ready.front();
+                ready.pop_front();
+            }
+            for (;;) {
+                jsp_async_job* j = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_work.wait(lk, [&] { return !g->tasks.empty() || g->closed; });
+                    if (g->tasks.empty()) {
+                        g->finished = true;
+                        cv_done.notify_all();
+                        break;
+                    }
+                    j = g->tasks.front();
+                    g->tasks.pop_front();
+                }
+                run_job(*g, *j, outs_local);
+            }
+        }
+    }
+
+    // (worker thread) one frame: host stage on the group's decoder, tables up, kernels queued, event recorded
+    void run_job(Group& g, jsp_async_job& j, std::vector<FrameOut>& outs_local) {
+        SpStaged* st = dynamic_cast<SpStaged*>(j.st.get());
+        std::string failed;
+        try {
+            int32_t* prev = j.prev_dev_before;
+            jsp_staged* got = stage_impl(std::vector<jsp_frame_in>{j.frame}, st, g.dec, &prev, &outs_local);
+            if (got != j.st.get()) j.st.reset(got);
+            if (!g.first_done && g.own && j.st->status[0] != JSP_ZERO_STATE) {
+                // the group's key frame did not decode: what the stream held before shows through — go on with the decoder
+                // of the group in front, once that group is through
+                std::shared_ptr<Group> b = g.before;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_done.wait(lk, [&] { return b->finished; });
+                }
+                g.dec = b->dec;
+                prev = j.prev_dev_before;
+                got = stage_impl(std::vector<jsp_frame_in>{j.frame}, j.st.get(), g.dec, &prev, &outs_local);
+                if (got != j.st.get()) j.st.reset(got);
+            } else if (!g.first_done && g.before) {
+                std::lock_guard<std::mutex> lk(mu);
+                g.before->successor_settled = true;     // its decoder will not be asked for again
+                g.before.reset();
+            }
+            g.first_done = true;
+            j.st->decode(stream);
+            JSP_HIP(hipEventRecord(j.done, stream));
+        } catch (const std::exception& e) {
+            failed = e.what();
+        }
+        if (!failed.empty()) {                     // (out of memory, a HIP error: the frame reports it; nothing is left half-queued that a wait could hang on)
+            if (!j.st) j.st.reset(new SpStaged());
+            j.st->status.assign(1, JSP_ERROR_OCCURED);
+            j.st->adopted.assign(1, 0);
+            j.st->significant.assign(1, 0);
+            j.st->cleared.assign(1, 0);
+            j.st->why = failed;
+            (void)hipEventRecord(j.done, stream);
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            extra[&j - jobs.data()].done = true;
+        }
+        cv_done.notify_all();
+    }
+
+    void worker_submit(jsp_async_job& j) override {
+        if (extra.size() < jobs.size()) extra.resize(jobs.size());
+        const HostFrame hf{j.frame.src, j.frame.n, j.frame.key};
+        std::shared_ptr<Group> cur = groups.empty() ? nullptr : groups.back();
+        if (!cur) {                                 // first frame since the last drain: predictions start from the codec's state
+            stream_version = host.pinned_version();
+            seen_key = host.has_prev() || stream_version != 0;
+            pred_prev_dev = prev_dev;
+        }
+        const bool opens = starts_group(hf);
+        const int version = opens ? (j.frame.src[0] >> 4) + 1 : 0;
+        // a new group of its own needs the stream's entropy coder to be known (pinned by the first coded key frame, which
+        // therefore always runs in the group in hand)
+        bool new_group = !cur;
+        std::unique_ptr<HostDecoder> fresh;
+        if (cur && opens && stream_version >= 2 && stream_version <= 4) {
+            const Geometry g = host.geo();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                // decoders of groups that are through and whose successor has started well go back to the shelf
+                for (auto& old : groups)
+                    if (old != cur && old->finished && old->successor_settled && old->own) spare.push_back(std::move(old->own));
+            }
+            if (!spare.empty()) { fresh = std::move(spare.back()); spare.pop_back(); }
+            if (fresh && fresh->pinned_version() != 0 && fresh->pinned_version() != stream_version) fresh.reset();   // it served another coder
+            if (!fresh) fresh = std::make_unique<HostDecoder>(g.X, g.Y, g.bpp);
+            fresh->adopt_settings(host_settings());
+            new_group = fresh->pin_version(stream_version);
+            if (!new_group) spare.push_back(std::move(fresh));
+        }
+        if (opens && stream_version == 0) stream_version = version;   // (the coder is chosen before the frame is decoded: ScreenPressor.hx:130-131)
+        if (new_group) {
+            auto g = std::make_shared<Group>();
+            if (cur) {
+                g->own = std::move(fresh);
+                g->dec = g->own.get();
+                g->before = cur;
+            } else {
+                g->dec = &host;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (cur) cur->closed = true;
+            groups.push_back(g);
+            ready.push_back(g);
+            cur = g;
+        }
+        // what the frame will do to the previous frame, from its first byte (ScreenPressor.hx:130-159, 308-313)
+        bool adopts;
+        if (j.frame.key) adopts = j.frame.n > 0 && ((j.frame.src[0] & 0xF) == 1 || (j.frame.src[0] & 0xF) == 2);
+        else adopts = j.frame.n > 0 && seen_key && j.frame.src[0] != 0;
+        if (j.frame.key && adopts) seen_key = true;
+        j.prev_dev_before = pred_prev_dev;
+        if (adopts) { pred_prev_dev = j.frame.dst; prev_caller = j.frame.dst; prev_dev = j.frame.dst; }
+        if ((int)workers.size() < async_threads()) workers.emplace_back([this] { worker_main(); });
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            extra[&j - jobs.data()].done = false;
+            cur->tasks.push_back(&j);
+        }
+        cv_work.notify_all();
+    }
+    const HostDecoder& host_settings() const { return host; }   // Preinit and key-frame layout: only ever changed with nothing in flight
+
+    void worker_wait(jsp_async_job& j) override {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return extra[&j - jobs.data()].done; });
+    }
+
+    void worker_drain() override {
+        if (groups.empty()) return;
+        std::shared_ptr<Group> last = groups.back();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            last->closed = true;
+            cv_work.notify_all();
+            cv_done.wait(lk, [&] {
+                for (auto& g : groups) if (!g->finished) return false;
+                return true;
+            });
+        }
+        // the stream goes on from the decoder the last group ended on
+        if (last->dec != &host) std::swap(host, *last->dec);
+        for (auto& g : groups)
+            if (g->own) spare.push_back(std::move(g->own));
+        groups.clear();
+        prev_dev = pred_prev_dev;      // (as predicted; jsp_wait reports what the frames really did)
+    }
     int is_key_frame(const uint8_t* src, size_t n) override { return HostDecoder::is_key_frame(src, n) ? 1 : 0; }
     int needs_index() override { return 0; }
     bool may_leave_pixels(const jsp_frame_in&) override { return false; }
@@ -79,6 +308,16 @@ struct SpCodec : jsp_codec {
             const long v = std::strtol(value, &end, 10);
             if (end == value || *end || v < 1 || v > 64) return -1;
             opt_host_threads = (int)v;
+            return 0;
+        }
+        if (std::strcmp(key, "sp_async_threads") == 0) {   // worker threads of the asynchronous per-frame calls (1: none)
+            if (next_ticket != oldest_ticket) return -1;
+            worker_drain();
+            if (std::strcmp(value, "auto") == 0) { opt_async_threads = 0; return 0; }
+            char* end = nullptr;
+            const long v = std::strtol(value, &end, 10);
+            if (end == value || *end || v < 1 || v > 64) return -1;
+            opt_async_threads = (int)v;
             return 0;
         }
         if (std::strcmp(key, "sp_inter_fusion") == 0) {
@@ -98,7 +337,17 @@ struct SpCodec : jsp_codec {
     }
 
     jsp_staged* stage(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse) override {
+        return stage_impl(frames, reuse, nullptr, nullptr, nullptr);
+    }
+    // `one` (worker threads of the asynchronous path): the single frame of `frames` goes through THAT decoder, the previous
+    // frame's device pointer comes from / goes to *prev_io and the frame's tables are built in *outs_one — nothing of the
+    // codec that another thread may be using is touched.
+    jsp_staged* stage_impl(const std::vector<jsp_frame_in>& frames, jsp_staged* reuse, HostDecoder* one, int32_t** prev_io,
+                           std::vector<FrameOut>* outs_one) {
         activate();
+        HostDecoder& host = one ? *one : this->host;
+        int32_t*& prev_dev = prev_io ? *prev_io : this->prev_dev;
+        std::vector<FrameOut>& outs = outs_one ? *outs_one : this->outs;
         const double t0 = now_ms();
         auto* st = dynamic_cast<SpStaged*>(reuse);
         std::unique_ptr<SpStaged> guard;
@@ -150,7 +399,8 @@ struct SpCodec : jsp_codec {
                 ++w1;
             }
             if ((int)outs.size() < w1 - w0) outs.resize(w1 - w0);
-            decode_frames(host, spare, hf.data() + w0, w1 - w0, outs.data(), threads, fuse_inter);
+            if (one) decode_single(host, hf[w0], outs[0], fuse_inter);
+            else decode_frames(host, spare, hf.data() + w0, w1 - w0, outs.data(), threads, fuse_inter);
         for (int i = w0; i < w1; ++i) {
             const jsp_frame_in& f = frames[i];
             FrameOut& fo = outs[i - w0];
@@ -158,7 +408,7 @@ struct SpCodec : jsp_codec {
             st->adopted[i] = fo.adopted ? 1 : 0;
             st->significant[i] = fo.significant ? 1 : 0;
             st->cleared[i] = fo.prev_cleared ? 1 : 0;
-            if (fo.status != JSP_ZERO_STATE && fo.error) set_error("%s", fo.error);
+            if (fo.status != JSP_ZERO_STATE && fo.error) { set_error("%s", fo.error); st->why = fo.error; }
             if (fo.prev_cleared) prev_dev = nullptr;
             st->info.stream_bytes += fo.stream_bytes;
             const uint64_t npx = (uint64_t)g.X * g.Y;
@@ -223,7 +473,7 @@ struct SpCodec : jsp_codec {
         }
             w0 = w1;
         }
-        if (outs.size() > 1) outs.resize(1);   // (a wave's worth of frame tables is hundreds of MB: only the per-frame calls' one stays)
+        if (!one && outs.size() > 1) outs.resize(1);   // (a wave's worth of frame tables is hundreds of MB: only the per-frame calls' one stays)
         st->info.frames = nf;
         st->info.pixels = (uint64_t)g.X * g.Y * nf;
         st->info.kernel_launches = st->ops.size();

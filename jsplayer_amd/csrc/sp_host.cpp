@@ -488,6 +488,7 @@ void decode_one(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literali
     }
 }
 }  // namespace
+void decode_single(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise) { decode_one(d, f, out, literalise); }
 bool starts_group(const HostFrame& f) { return f.key && f.n > 0 && (f.src[0] & 0xF) == 2; }   // a CODED key frame (flat ones renew nothing)
 
 void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<HostDecoder>>& spare, const HostFrame* frames,
