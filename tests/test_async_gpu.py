@@ -162,6 +162,105 @@ def test_screenpressor_async_matches_oracle(version):
     drive(ScreenPressor(w, h, 24), OracleScreenPressor(w, h, 24), w, h, chunks, keys)
 
 
+@pytest.mark.parametrize("version", [2, 3, 4])
+def test_screenpressor_async_groups_of_pictures_on_worker_threads(version):
+    """Every coded key frame opens a group of pictures that the asynchronous calls hand to a worker thread and a decoder of
+    its own (option sp_async_threads): key frames only, key frames with inter frames behind them, flat key frames (which
+    renew nothing and stay in the group in hand), unchanged frames — eight frames in flight, results as the oracle's."""
+    w, h = 320, 240
+    for seed, n, every, flat, unchanged in ((61, 12, 1, (), ()), (62, 20, 3, (6, 7), (4, 11)), (63, 10, 1, (2, 5), ())):
+        chunks, keys, _ = sg.sp_clip(seed, w, h, n, version=version, key_every=every, flat_at=flat, unchanged_at=unchanged)
+        gpu = ScreenPressor(w, h, 24)
+        gpu.set_option("sp_async_threads", "4")
+        drive(gpu, OracleScreenPressor(w, h, 24), w, h, chunks, keys, depth=8)
+
+
+def test_screenpressor_async_broken_key_frame_lets_older_state_show_through():
+    """A coded key frame that does not decode (cut to a third of its bytes) leaves the decoder the stream had — its
+    "a key frame has been decoded" state included — to the frames behind it: the worker that took the broken frame's group,
+    on a decoder of its own, must go on with the decoder of the group before.  Such a stream is outside what the oracle
+    defines (the reference raises); the bar here is the product's own one-frame-at-a-time path: same states, same errors,
+    same previous-frame identities, same pixels."""
+    import torch
+    w, h = 320, 240
+    chunks, keys, _ = sg.sp_clip(64, w, h, 20, version=4, key_every=4)
+    chunks = list(chunks)
+    chunks[12] = chunks[12][:len(chunks[12]) // 3]
+    nbuf = 20
+    results = []
+    for mode in ("sync", "async"):
+        gpu = ScreenPressor(w, h, 24)
+        gpu.Preinit(36)
+        gpu.set_option("sp_async_threads", "4")
+        gpu.set_option("async_depth", "8")
+        bufs = [torch.full((w * h,), 7, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+        log, tickets = [], []
+
+        def settle(i, fn):
+            try:
+                r = fn()
+                out = ("state", int(r)) if keys[i] else ("p", next((k for k in range(nbuf) if bufs[k] is r.data_pnt), None), r.significant_changes)
+            except CodecError:
+                out = ("raise",)
+            log.append((i, out))
+
+        for i, (c, k) in enumerate(zip(chunks, keys)):
+            dst = bufs[i]                          # a buffer per frame: no reuse questions
+            if mode == "sync":
+                settle(i, (lambda: gpu.DecompressI(c, dst)) if k else (lambda: gpu.DecompressP(c, dst)))
+            else:
+                if len(tickets) == 8:
+                    j, t = tickets.pop(0)
+                    settle(j, lambda: gpu.wait(t))
+                tickets.append((i, (gpu.DecompressI_async if k else gpu.DecompressP_async)(c, dst)))
+        for j, t in tickets:
+            settle(j, lambda: gpu.wait(t))
+        torch.cuda.synchronize()
+        prev = gpu.PreviousFrame()
+        results.append((log, next((k for k in range(nbuf) if bufs[k] is prev), None), [b.cpu().numpy() for b in bufs]))
+        gpu.StopAndClean()
+    (log_s, prev_s, pix_s), (log_a, prev_a, pix_a) = results
+    assert log_s == log_a
+    assert any(o == ("state", 2) or o == ("raise",) for _, o in log_s), "the broken key frame must show"
+    assert prev_s == prev_a
+    for i, (a, b) in enumerate(zip(pix_s, pix_a)):
+        assert np.array_equal(a, b), f"buffer {i}"
+
+
+def test_screenpressor_async_and_synchronous_calls_alternate():
+    """The stream's decoder state moves between the worker threads' decoders and the codec's own: synchronous calls after
+    asynchronous ones (and back) see one continuous stream."""
+    import torch
+    w, h = 320, 240
+    chunks, keys, _ = sg.sp_clip(65, w, h, 16, version=3, key_every=3)
+    gpu, orc = ScreenPressor(w, h, 24), OracleScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    orc.Preinit(36)
+    gpu.set_option("sp_async_threads", "4")
+    gpu.set_option("async_depth", "4")
+    gbufs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(8)]
+    obufs = [np.zeros(w * h, dtype=np.int32) for _ in range(8)]
+    i = 0
+    while i < len(chunks):
+        if (i // 4) % 2 == 0:                     # four frames through the asynchronous calls ...
+            tickets = []
+            for j in range(i, min(i + 4, len(chunks))):
+                k = next(b for b in range(8) if obufs[b] is not orc.PreviousFrame() and gbufs[b] is not gpu.PreviousFrame() and b not in [t[1] for t in tickets])
+                (orc.DecompressI if keys[j] else orc.DecompressP)(chunks[j], obufs[k])
+                tickets.append(((gpu.DecompressI_async if keys[j] else gpu.DecompressP_async)(chunks[j], gbufs[k]), k))
+            for t, _ in tickets:
+                gpu.wait(t)
+            i = min(i + 4, len(chunks))
+        else:                                     # ... then four through the synchronous ones
+            for j in range(i, min(i + 4, len(chunks))):
+                k = next(b for b in range(8) if obufs[b] is not orc.PreviousFrame() and gbufs[b] is not gpu.PreviousFrame())
+                (orc.DecompressI if keys[j] else orc.DecompressP)(chunks[j], obufs[k])
+                (gpu.DecompressI if keys[j] else gpu.DecompressP)(chunks[j], gbufs[k])
+            i = min(i + 4, len(chunks))
+        assert np.array_equal(gpu.PreviousFrame().cpu().numpy(), orc.PreviousFrame()), f"after frame {i - 1}"
+    gpu.StopAndClean()
+
+
 def test_async_usage_errors():
     import torch
     w, h = 64, 48
