@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WG) void msv1_blocks_kernel(
 // counter); two row waves fed through LDS by a loader wave that never stores: 254 us (one load latency
 // under full write pressure per frame on the critical path).  Both bit-exact, both dropped.
 template <int BITS>
-__global__ __launch_bounds__(WG) void msv1_blocks_temporal_kernel(
+__global__ __launch_bounds__(WG) void msv1_blocks_temporal1_kernel(
     const uint8_t* __restrict__ stream, const uint32_t* __restrict__ desc,
     const Msv1FrameArgs* __restrict__ frames, int nframes, const int32_t* __restrict__ palette, int nblocks,
     int nbx, int X) {
@@ -440,7 +440,7 @@ typedef __attribute__((address_space(1))) const void t_gvoid;
 typedef __attribute__((address_space(3))) void t_lvoid;
 
 template <int BITS>
-__global__ __launch_bounds__(TWG) void msv1_blocks_temporal2_kernel(
+__global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
     const uint8_t* __restrict__ stream, const uint32_t* __restrict__ desc,
     const Msv1FrameArgs* __restrict__ frames, int nframes, const int32_t* __restrict__ palette, int nblocks,
     int nbx, int X) {
@@ -679,25 +679,25 @@ void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_strea
     if (old_form) {
         dim3 grid((geo.nblocks + WG - 1) / WG), block(WG);
         if (geo.bits == 16)
-            hipLaunchKernelGGL((msv1_blocks_temporal_kernel<16>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+            hipLaunchKernelGGL((msv1_blocks_temporal1_kernel<16>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
                                d_palette, geo.nblocks, geo.nbx, geo.X);
         else
-            hipLaunchKernelGGL((msv1_blocks_temporal_kernel<8>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
+            hipLaunchKernelGGL((msv1_blocks_temporal1_kernel<8>), grid, block, 0, stream, d_stream, d_desc, d_frames, nframes,
                                d_palette, geo.nblocks, geo.nbx, geo.X);
         return;
     }
     const size_t lds = 2 * sizeof(TChunk) + 256 * 4 + (((size_t)nframes + 31) / 32 + 2) * 4;
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     dim3 grid((geo.nblocks + WG - 1) / WG), block(TWG);
     if (geo.bits == 16)
-        hipLaunchKernelGGL((msv1_blocks_temporal2_kernel<16>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
+        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<16>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
                            d_palette, geo.nblocks, geo.nbx, geo.X);
     else
-        hipLaunchKernelGGL((msv1_blocks_temporal2_kernel<8>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
+        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<8>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
                            d_palette, geo.nblocks, geo.nbx, geo.X);
 }
 

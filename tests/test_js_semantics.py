@@ -72,6 +72,37 @@ def test_oracle_agrees_with_a_real_js_engine():
     assert checked > 300
 
 
+def test_js_engine_decodes_the_full_size_bench_frames_to_the_recorded_digests(tmp_path):
+    """The golden digests of the 1920x1080 bench workloads come from the C++ oracle; here the first frames of every MSVideo1
+    workload go through the plain typed-array decoder under node and must hash to the same values: the oracle's second
+    opinion at the size that is timed (it narrows what is unchecked; it pins nothing to the reference)."""
+    from jsplayer_amd import workloads as wl
+    gold_doc = json.load(open(wl.GOLDEN))["digests"]
+    cases, wanted = [], []
+    for name, spec in wl.WORKLOADS.items():
+        if spec["codec"] != "msv1":
+            continue
+        nfr = 3 if "inter" in spec else 1
+        clip = wl.build_clips(name, 0, frames=nfr)[0]
+        files = []
+        for i, f in enumerate(clip.frames):
+            path = tmp_path / f"{name}_{i}.bin"
+            path.write_bytes(f)
+            files.append(str(path))
+        cases.append(dict(bits=spec["bits"], w=wl.W, h=wl.H, lines=36, prefill=0, palette=list(clip.palette) if clip.palette else [], files=files))
+        wanted.append((name, gold_doc[f"{name}/rank0"][0][:nfr]))
+    res = subprocess.run([NODE, os.path.join(HERE, "js", "msv1_js_semantics.js")], input=json.dumps(cases).encode(),
+                         stdout=subprocess.PIPE, check=True)
+    js = json.loads(res.stdout)
+    checked = 0
+    for (name, gold), frames in zip(wanted, js):
+        for i, (g, r) in enumerate(zip(gold, frames)):
+            assert not r["raised"], (name, i)
+            assert g != "-" and r["digest"] == g, (name, i)
+            checked += 1
+    assert checked >= 8
+
+
 # ---- ScreenPressor, range-coder (version 2) streams ---------------------------------------------------
 def build_sp_cases():
     from jsplayer_amd import streamgen as sg2
