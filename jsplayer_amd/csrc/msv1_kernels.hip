@@ -452,11 +452,11 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
     // would then wait for the wave's row stores)
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
     lds_vu32* s_ready = (lds_vu32*)(s_sig + ((nframes + 31) >> 5));             // chunks handed over by the loader
-    lds_vu32* s_consumed = s_ready + 1;                                         // worker waves done, summed over chunks
+    lds_vu32* s_done = s_ready + 1;                                             // [TW] chunks each worker wave is through with
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (provably uniform: the loader's loops then run on the scalar unit, its frame records are scalar loads)
     if (BITS == 8 && tid < 256) s_pal[tid] = (uint32_t)palette[tid];
-    for (int i = tid; i < ((nframes + 31) >> 5) + 2; i += TWG) s_sig[i] = 0u;   // (+ ready, consumed)
+    for (int i = tid; i < ((nframes + 31) >> 5) + 1 + TW; i += TWG) s_sig[i] = 0u;   // (+ ready, done[TW])
     __syncthreads();
     const int blk0 = blockIdx.x * WG;
 
@@ -468,8 +468,14 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
         while (f < nframes) {
             TChunk& ck = chunks[c & 1];
             // the buffer was chunk c - 2's: all its readers must be through
+            // (EVERY worker wave: a count summed over the waves would let a wave that is a chunk ahead stand in for one that is
+            // still reading the buffer)
             if (c >= 2)
-                for (int spin = 0; (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_consumed) < (uint32_t)(TW * (c - 1)) && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(2);
+                for (int spin = 0; spin < T_SPIN; ++spin) {
+                    const uint32_t slowest = min(min(s_done[0], s_done[1]), min(s_done[2], s_done[3]));
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)slowest) >= (uint32_t)(c - 1)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
             // 1. table entries of up to T_NF frames (frames that write nothing are left out), one 1 KiB row each
             int nf = 0, scan = f;
 #pragma unroll 1
@@ -635,11 +641,11 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
                 __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)&s_sig[tf.index >> 5], 1u << (tf.index & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)s_consumed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) s_done[wave] = (uint32_t)(c + 1);
         if (next >= nframes) break;
     }
     // significance bits -> the frames' words (MSVideo1.hx:195-204), once the four worker waves are through
-    for (int spin = 0; *s_consumed < (uint32_t)(TW * (int)*s_ready) && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
+    for (int spin = 0; min(min(s_done[0], s_done[1]), min(s_done[2], s_done[3])) < *s_ready && spin < T_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
     for (int fi = tid; fi < nframes; fi += TW * 64)
         if ((s_sig[fi >> 5] >> (fi & 31)) & 1u) {
             gu32* sg = (gu32*)frames[fi].signif;
@@ -686,7 +692,7 @@ void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_strea
                                d_palette, geo.nblocks, geo.nbx, geo.X);
         return;
     }
-    const size_t lds = 2 * sizeof(TChunk) + 256 * 4 + (((size_t)nframes + 31) / 32 + 2) * 4;
+    const size_t lds = 2 * sizeof(TChunk) + 256 * 4 + (((size_t)nframes + 31) / 32 + 1 + TW) * 4;
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

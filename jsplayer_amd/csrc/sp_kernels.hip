@@ -609,6 +609,181 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Inter-frame groups, second form: 8 pixels per lane and a LOADER wave.
+//
+// sp_pframe_group_kernel above staged every chunk of frames itself: all four waves stopped at workgroup barriers — which wait
+// for the wave's row stores in flight — and then paid two load round trips behind the CU's store queue (54 % of its wave cycles
+// parked, profiles/r03_sp_pclip300_group_sq_counters.txt).  A loader wave cannot simply be added to it: with one wave per 16x16
+// block a 1080p frame needs 8 160 of the chip's 8 192 wave slots.  So a lane carries TWO rows of 4 pixels here (a workgroup = 8
+// adjacent blocks = 128 x 16 pixels, 256 worker lanes; a wave's store is two 512-byte row segments), half the waves do the
+// same work, and the fifth wave of every workgroup fetches the next chunk — block records, frame records, literal pixels —
+// straight into LDS (global_load_lds) while the workers walk the current one.  The workers' frame loop holds no load and no
+// workgroup barrier; chunks change hands through two LDS counters.
+constexpr int G2_BLOCKS = 8;                  // blocks per workgroup
+constexpr int G2_CF = 16;                     // frames per chunk, at most
+constexpr int G2_LW = 3072;                   // literal words per chunk (one frame needs at most 8 x 256)
+constexpr int G2_WG = 5 * 64;
+constexpr int G2_SPIN = 1 << 24;
+struct G2Chunk {
+    PBlock pb[G2_CF * G2_BLOCKS];             // (frame, block) records, frame-major: what one LDS-DMA per 64 records writes
+    PGroupFrame gf[G2_CF];
+    uint32_t lit_at[G2_CF * G2_BLOCKS];       // where in `lits` the rectangle of (frame, block) starts
+    uint32_t lits[G2_LW];
+    int nf, next;
+};
+static_assert(sizeof(PGroupFrame) == 16, "one LDS-DMA lane per frame record");
+
+typedef __attribute__((address_space(1))) const void g2_gvoid;
+typedef __attribute__((address_space(3))) void g2_lvoid;
+
+__global__ __launch_bounds__(G2_WG) void sp_pframe_group2_kernel(const PGroupFrame* __restrict__ frames, int nframes,
+                                                                const uint32_t* __restrict__ prev,
+                                                                const PBlock* __restrict__ blocks,
+                                                                const uint32_t* __restrict__ payload, int X, int Y, int nbx) {
+    extern __shared__ __align__(16) uint8_t g2_lds[];
+    G2Chunk* chunks = reinterpret_cast<G2Chunk*>(g2_lds);                       // [2]
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;       // (LDS spelled out: generic pointers would poll with FLAT loads, which count on vmcnt too)
+    lds_vu32* s_ready = (lds_vu32*)(g2_lds + 2 * sizeof(G2Chunk));          // chunks the loader has handed over
+    lds_vu32* s_done = s_ready + 1;                                          // [4] chunks each worker wave is through with
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 5) s_ready[tid] = 0u;
+    __syncthreads();
+    const int by = blockIdx.y;
+    const int nb_here = nbx - (int)blockIdx.x * G2_BLOCKS < G2_BLOCKS ? nbx - (int)blockIdx.x * G2_BLOCKS : G2_BLOCKS;
+
+    if (wave == 4) {
+        // ---------------------------------------- loader ----------------------------------------
+        const uint32_t block_off0 = frames[0].block_off, nblocks_frame = (uint32_t)nbx * (uint32_t)gridDim.y;
+        int f0 = 0, c = 0;
+        while (f0 < nframes) {
+            G2Chunk& ck = chunks[c & 1];
+            // the buffer was chunk c - 2's: EVERY worker wave must be through with that chunk (a count summed over the waves
+            // would let a wave that is a chunk ahead stand in for one that is still reading)
+            if (c >= 2)
+                for (int spin = 0; spin < G2_SPIN; ++spin) {
+                    const uint32_t slowest = min(min(s_done[0], s_done[1]), min(s_done[2], s_done[3]));
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)slowest) >= (uint32_t)(c - 1)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            const int nf_try = nframes - f0 < G2_CF ? nframes - f0 : G2_CF;
+            // 1. records: (frame, block) items 64 at a time, frame records one per lane
+#pragma unroll
+            for (int q = 0; q < G2_CF * G2_BLOCKS / 64; ++q) {
+                const int item = q * 64 + lane, f = item >> 3, k = item & 7;
+                if (q * 64 < nf_try * G2_BLOCKS && f < nf_try && k < nb_here)
+                    __builtin_amdgcn_global_load_lds((g2_gvoid*)(blocks + (size_t)block_off0 + (size_t)(f0 + f) * nblocks_frame + (size_t)by * nbx + blockIdx.x * G2_BLOCKS + k),
+                                                     (g2_lvoid*)&ck.pb[q * 64], 16, 0, 0);
+            }
+            if (lane < nf_try) __builtin_amdgcn_global_load_lds((g2_gvoid*)(frames + f0 + lane), (g2_lvoid*)&ck.gf[0], 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // 2. where each changed rectangle's literals go, and how many frames fit: two items per lane, exclusive scan
+            uint32_t need[2] = {0, 0}, from[2] = {0, 0};    // literal words of the lane's two items, and where they start in `payload`
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int item = lane * 2 + h;
+                if (item < nf_try * G2_BLOCKS && (item & 7) < nb_here) {
+                    const PBlock pb = ck.pb[item];
+                    if (pb.flags & PB_DATA) {
+                        need[h] = (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
+                        from[h] = ck.gf[item >> 3].payload_off + pb.payload;
+                    }
+                }
+            }
+            uint32_t incl = need[0] + need[1];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint32_t excl = incl - need[0] - need[1];
+            ck.lit_at[lane * 2] = excl;
+            ck.lit_at[lane * 2 + 1] = excl + need[0];
+            // a frame fits if the literals up to and including its last block do; frame 0 always does (at most 2048 words)
+            const bool over = (lane & 3) == 3 && lane * 2 + 1 < nf_try * G2_BLOCKS && incl > (uint32_t)G2_LW && lane >= 4;
+            const unsigned long long om = __ballot(over);
+            const int nf = om ? (__ffsll((long long)om) - 1) >> 2 : nf_try;
+            // 3. the literals: rectangle by rectangle, 64 words per LDS-DMA, every request out before any is waited for
+            unsigned long long want = __ballot(need[0] != 0u && lane * 2 < nf * G2_BLOCKS) ;
+            unsigned long long want1 = __ballot(need[1] != 0u && lane * 2 + 1 < nf * G2_BLOCKS);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                unsigned long long m = h ? want1 : want;
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)need[h], l);
+                    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(h ? excl + need[0] : excl), l);
+                    // (everything the loop needs comes out of registers: an LDS read here would be made to wait for the LDS-DMAs
+                    // already in flight, one round trip per rectangle)
+                    const uint32_t* src = payload + (uint32_t)__builtin_amdgcn_readlane((int)from[h], l);
+                    for (uint32_t i = 0; i < n; i += 64)
+                        if (i + lane < n) __builtin_amdgcn_global_load_lds((g2_gvoid*)(src + i + lane), (g2_lvoid*)&ck.lits[at + i], 4, 0, 0);
+                }
+            }
+            if (lane == 0) { ck.nf = nf; ck.next = f0 + nf; }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *s_ready = (uint32_t)(c + 1);
+            f0 += nf;
+            ++c;
+        }
+        return;
+    }
+
+    // ---------------------------------------- workers ----------------------------------------
+    // lane = 16-byte chunk of two rows: rows r and r + 8 of the block row, chunk ch of the workgroup's 128 pixels; a wave's 64
+    // lanes are two rows x 32 chunks, so one store instruction writes two 512-byte row segments
+    const int r = tid >> 5, ch = tid & 31;
+    const int kb = ch >> 2;                                  // which of the workgroup's 8 blocks
+    const int cx0 = (ch & 3) * 4;                            // chunk origin relative to the block
+    const int bx = blockIdx.x * G2_BLOCKS + kb;
+    const int x0 = bx * 16 + cx0;
+    const int ya = by * 16 + r, yb2 = ya + 8;
+    const bool col = bx < nbx && x0 < X;
+    const bool mine_a = col && ya < Y, mine_b = col && yb2 < Y;
+    const size_t ia = (size_t)ya * X + x0, ib = (size_t)yb2 * X + x0;
+    uint32_t pa[4] = {0, 0, 0, 0}, pb4[4] = {0, 0, 0, 0};
+    if (mine_a) { const uint4 q = *reinterpret_cast<const uint4*>(prev + ia); pa[0] = q.x; pa[1] = q.y; pa[2] = q.z; pa[3] = q.w; }
+    if (mine_b) { const uint4 q = *reinterpret_cast<const uint4*>(prev + ib); pb4[0] = q.x; pb4[1] = q.y; pb4[2] = q.z; pb4[3] = q.w; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the previous-frame pixels are settled before any store is issued
+    for (int c = 0;; ++c) {
+        int spin = 0;
+        for (; *s_ready < (uint32_t)(c + 1) && spin < G2_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
+        if (spin >= G2_SPIN) return;                         // (cannot happen: every wait here is bounded so that a mistake ends the launch)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const G2Chunk& ck = chunks[c & 1];
+        const int nf = ck.nf, next = ck.next;
+        if (col) {
+            for (int f = 0; f < nf; ++f) {
+                const PBlock pb = ck.pb[f * G2_BLOCKS + kb];
+                uint32_t* out = reinterpret_cast<uint32_t*>(ck.gf[f].dst);
+                if (pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
+                    const int w = pb.x2 - pb.x1;
+                    const uint32_t* lit0 = ck.lits + ck.lit_at[f * G2_BLOCKS + kb] - pb.x1;
+                    if (r >= pb.y1 && r < pb.y2) {
+                        const uint32_t* lit = lit0 + (uint32_t)((r - pb.y1) * w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pa[j] = lit[rx]; }
+                    }
+                    if (r + 8 >= pb.y1 && r + 8 < pb.y2) {
+                        const uint32_t* lit = lit0 + (uint32_t)((r + 8 - pb.y1) * w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pb4[j] = lit[rx]; }
+                    }
+                }
+                if (mine_a) store4_global(out + ia, make_uint4(pa[0], pa[1], pa[2], pa[3]));
+                if (mine_b) store4_global(out + ib, make_uint4(pb4[0], pb4[1], pb4[2], pb4[3]));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) s_done[wave] = (uint32_t)(c + 1);
+        if (next >= nframes) break;
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -707,6 +882,17 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     // pixels of a chunk fetched by a flat index space in one round trip (3 % slower than rectangle by rectangle).
     // With the block records withheld (every block "unchanged", nothing staged but the destinations) the same loop
     // takes 483 us — the temporal fill ceiling; without the literal fetches 539 us.
+    static const bool old_form = std::getenv("JSP_SP_GROUP_OLD") != nullptr;   // lab: the kernel that stages its own chunks
+    if (vec && (g.X & 3) == 0 && !old_form) {   // whole 16-byte chunks everywhere: the loader-wave kernel
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_group2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        });
+        const dim3 grid2((g.nbx + G2_BLOCKS - 1) / G2_BLOCKS, g.nby);
+        hipLaunchKernelGGL(sp_pframe_group2_kernel, grid2, dim3(G2_WG), 2 * sizeof(G2Chunk) + 32, stream, d_frames, nframes,
+                           reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx);
+        return;
+    }
     constexpr int chunk = 32, lit_words = 2048, stagger = 1;   // (chunk <= 64: one (frame, block) item per lane in the kernel's scan)
     static_assert(lit_words >= GROUP_LITERALS_MIN, "one frame's literals must fit");
     const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 32;
