@@ -406,7 +406,14 @@ public:
                     // the previous image row, decoded later), row 0 has nothing above
                     consider(3, scan([&](long i) { return t[i] == prev_[i]; }));
                     consider(2, scan([&](long i) { return i >= X && t[i] == t[i - X]; }));
-                    consider(1, scan([&](long i) { return i % X != 0 && t[i] == t[i - 1]; }));
+                    // (tests only, set_stale: in column 0 the decoder's "left" is the last pixel of the row above — of a block
+                    // this frame has not reached yet unless the row is a block row's first, i.e. whatever the destination
+                    // buffer held: ScreenPressor.hx:436-444.  `stale_` says what that is, so that a stream exercising the read
+                    // can be built; no real encoder emits it.)
+                    consider(1, scan([&](long i) {
+                        if (i % X != 0) return t[i] == t[i - 1];
+                        return stale_ != nullptr && i > 0 && (i / X) % 16 != 0 && t[i] == stale_[i - 1];
+                    }));
                     consider(5, scan([&](long i) { return i >= X && i % X != 0 && t[i] == t[i - X - 1]; }));
                     consider(4, scan([&](long i) { return i >= X && i % X != 0 && t[i] == grad(t[i - 1], t[i - X], t[i - X - 1]); }));
                     if (bestn == 0) {
@@ -428,8 +435,15 @@ public:
         std::memcpy(prev_.data(), t, sizeof(uint32_t) * (size_t)end);
     }
     const std::vector<uint32_t>& prev() const { return prev_; }
+    void set_stale(const uint32_t* picture) {   // what the decoder's destination buffer holds before the next inter frame (null: unknown)
+        if (!picture) { stale_store_.clear(); stale_ = nullptr; return; }
+        stale_store_.assign(picture, picture + prev_.size());
+        stale_ = stale_store_.data();
+    }
 
 private:
+    std::vector<uint32_t> stale_store_;
+    const uint32_t* stale_ = nullptr;
     void literal(uint32_t clr) {  // three components with the decoder's context chain
         const int comp[3] = {(int)(clr & 0xFF), (int)((clr >> 8) & 0xFF), (int)((clr >> 16) & 0xFF)};
         for (int ch = 0; ch < 3; ++ch) {
@@ -494,6 +508,7 @@ long jspgen_sp_encode_p(void* p, const uint32_t* frame, const int16_t* hints, ui
 void jspgen_stage_census(uint64_t* out) { for (int k = 0; k < 8; ++k) out[k] = g_census[k].load(); }
 // The frame a decoder holds after the last encoded frame (for flat frames the colour is derived
 // from the emitted bytes).
+void jspgen_sp_set_stale(void* p, const uint32_t* picture) { ((Handle*)p)->enc.set_stale(picture); }
 void jspgen_sp_current(void* p, uint32_t* out) {
     auto* h = (Handle*)p;
     std::memcpy(out, h->enc.prev().data(), h->enc.prev().size() * sizeof(uint32_t));

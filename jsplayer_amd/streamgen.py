@@ -227,6 +227,7 @@ def _genlib():
         L.jspgen_sp_encode_flat.argtypes = [_C.c_void_p, _C.c_uint32, _C.c_void_p, _C.c_size_t]
         L.jspgen_sp_encode_p.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.jspgen_sp_current.argtypes = [_C.c_void_p, _C.c_void_p]
+        L.jspgen_sp_set_stale.argtypes = [_C.c_void_p, _C.c_void_p]
         _gen = L
     return _gen
 
@@ -263,6 +264,17 @@ class SpEncoder:
             hints = np.ascontiguousarray(hints, dtype=np.int16)
             hp = hints.ctypes.data
         return self._ret(self.L.jspgen_sp_encode_p(self.h, f.ctypes.data, hp, self._buf.ctypes.data, self._buf.size))
+
+    def set_stale(self, picture: Optional[np.ndarray]) -> None:
+        """Tests only: tell the encoder what the decoder's destination buffer will hold before the next inter frame, so
+        that it may code a column-0 pixel as "the pixel to the left" (ScreenPressor.hx:436-444 reads the last pixel of the
+        row above — stale content of the destination — there).  None: back to never emitting that."""
+        if picture is None:
+            self.L.jspgen_sp_set_stale(self.h, None)
+            return
+        f = np.ascontiguousarray(picture, dtype=np.uint32).reshape(-1)
+        assert f.size == self.X * self.Y
+        self.L.jspgen_sp_set_stale(self.h, f.ctypes.data)
 
     def current(self) -> np.ndarray:
         """The frame a decoder holds after the last encoded frame."""

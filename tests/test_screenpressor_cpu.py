@@ -256,3 +256,61 @@ def test_side_by_side_literalises_what_one_by_one_does():
         _same_frame(a, side[i], i)
     seq.close()
     par.close()
+
+
+def column0_clip(version=4):
+    """Three frames whose last one codes pixel (0, y0) of a data rectangle as "the pixel to the left": at x = 0 that is the last
+    pixel of the row above (ScreenPressor.hx:436-444, linear index di - 1), which belongs to a block the frame has not decoded
+    yet — so the decoder reads whatever its DESTINATION buffer held there.  The encoder is told (set_stale) that this is the
+    picture two frames back, which is what a caller rotating two buffers hands it; frame 1 changes exactly that pixel, so one
+    and two frames back differ there."""
+    w, h, y0 = 64, 48, 19
+    rng = sg.SplitMix64(sg.SEED_BASE + 901)
+    enc = sg.SpEncoder(w, h, 24, version)
+    f0 = sg.desktop_frame(rng, w, h, 24).astype(np.uint32).reshape(h, w)
+    v0 = int(f0[y0 - 1, w - 1])
+    f1 = f0.copy()
+    f1[y0 - 1, w - 1] = (v0 ^ 0x00F0F0F0) & 0xFFFFFF
+    f2 = f1.copy()
+    f2[y0, 0] = v0
+    assert v0 != int(f1[y0, 0]) and v0 != int(f2[y0 - 1, 0])
+    chunks = [enc.encode_i(f0), enc.encode_p(f1)]
+    enc.set_stale(f0)
+    chunks.append(enc.encode_p(f2))
+    enc.close()
+    return w, h, y0, chunks, [f0, f1, f2]
+
+
+def oracle_with_rotation(w, h, chunks, nbuf, fill=0x123456):
+    o = OracleScreenPressor(w, h, 24)
+    o.Preinit(36)
+    bufs = [np.full(w * h, fill, np.int32) for _ in range(nbuf)]
+    o.DecompressI(chunks[0], bufs[0])
+    o.DecompressP(chunks[1], bufs[1])
+    o.DecompressP(chunks[2], bufs[2 % nbuf])
+    return o.PreviousFrame().view(np.uint32).reshape(h, w).copy()
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_left_of_column_zero_is_the_destinations_old_content(version):
+    """The documented deviation, pinned down: the reference reads the caller's destination buffer
+    there, so its result depends on how the caller rotates its buffers; the product's host stage reads its own shadow of
+    that position — the picture two frames back — whatever the caller does.  With two buffers in rotation both see the same
+    thing (and the stream decodes to what the encoder meant); with three the reference reads older content and differs in
+    exactly that pixel."""
+    w, h, y0, chunks, frames = column0_clip(version)
+    two = oracle_with_rotation(w, h, chunks, 2)
+    assert np.array_equal(two, frames[2])
+    three = oracle_with_rotation(w, h, chunks, 3)
+    ys, xs = np.nonzero(three != two)
+    assert (ys.tolist(), xs.tolist()) == ([y0], [0]) and int(three[y0, 0]) == 0x123456   # the third buffer's fill shows through
+    # the product's host stage -> descriptors -> numpy kernel emulation: as the reference with two buffers
+    host = hs.HostStage(w, h, 24)
+    host.preinit(36)
+    prev = None
+    for i, c in enumerate(chunks):
+        d = host.decode(i == 0, c)
+        assert d["status"] == 0
+        prev = hs.expand_iframe(d, w, h) if i == 0 else hs.expand_pframe(d, prev, w, h)
+    host.close()
+    assert np.array_equal(np.asarray(prev).view(np.uint32).reshape(h, w), two)

@@ -358,3 +358,23 @@ def test_batches_staged_into_one_batch_object():
             if adopted[i - lo]:
                 assert np.array_equal(to_np(md[i]), want[i]), f"msvideo1 frame {i}"
     st.close()
+
+
+@pytest.mark.parametrize("nbuf", [2, 3])
+def test_left_of_column_zero_reads_the_picture_two_frames_back(nbuf):
+    """The documented deviation (tests/test_screenpressor_cpu.py::test_left_of_column_zero_is_the_destinations_old_content) through
+    the C ABI: whatever the caller's buffer rotation, the product decodes the crafted stream as the reference does for a caller
+    that rotates two buffers."""
+    import torch
+    from test_screenpressor_cpu import column0_clip, oracle_with_rotation
+    w, h, y0, chunks, frames = column0_clip(4)
+    want = oracle_with_rotation(w, h, chunks, 2)
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    bufs = [torch.full((w * h,), 0x123456, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    assert gpu.DecompressI(chunks[0], bufs[0]) == 0
+    gpu.DecompressP(chunks[1], bufs[1])
+    gpu.DecompressP(chunks[2], bufs[2 % nbuf])
+    got = gpu.PreviousFrame().cpu().numpy().view(np.uint32).reshape(h, w)
+    assert np.array_equal(got, want)
+    gpu.StopAndClean()
