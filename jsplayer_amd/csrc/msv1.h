@@ -116,8 +116,10 @@ struct Msv1AsyncInfo {
     uint32_t fault;    // look-back gave up
     uint32_t arrived;  // mode 3: workgroups whose findings are in `flags` / that have written their last pixel; both run
     uint32_t finished; //         on from launch to launch (see `want`)
-    uint32_t pad[3];
+    uint32_t verdict;  // mode 3: 0 undecided, MSV1_VERDICT_GO / _VETO — set ONCE per launch (compare-and-swap), obeyed by every tile
+    uint32_t pad[2];
 };
+constexpr uint32_t MSV1_VERDICT_GO = 1u, MSV1_VERDICT_VETO = 2u;
 // mode 4 (batch form): nothing is rebuilt; every tile writes its blocks' entries of the frame's descriptor table (the record's
 // `dst` points at it) — the on-GPU descriptor parse in ONE launch, for the batches whose frames depend on each other.
 // mode 3 (one frame per launch, at most MSV1_MERGED_MAX_TILES tiles): scout and decode in ONE launch — every tile parses

@@ -480,6 +480,7 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
             __hip_atomic_store(&info->flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&info->signif, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&info->fault, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&info->verdict, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every tile has obeyed it by now)
         }
     };
     if (MODE == 3) {
@@ -796,16 +797,25 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
             if (lane == 0 && seen) atomicOr(&info->flags, seen);
             __syncthreads();
             if (tid == 0) {
+                // ONE verdict per launch, whoever pronounces it: a tile that sees every report in proposes GO or VETO from the
+                // (then complete) flags, a tile that gives up waiting proposes VETO; the first compare-and-swap wins and every
+                // tile obeys the word it then reads — no tile can write pixels of a frame another tile vetoes a moment later.
                 arrive();
-                bool all = false;
-                for (int spin = 0; spin < VERDICT_SPIN_LIMIT; ++spin) {
-                    all = (int32_t)(__hip_atomic_load(&info->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
-                    if (all) break;
-                    __builtin_amdgcn_s_sleep(8);
+                uint32_t verdict = 0;
+                for (int spin = 0;; ++spin) {
+                    verdict = __hip_atomic_load(&info->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (verdict) break;
+                    uint32_t propose = 0;
+                    if ((int32_t)(__hip_atomic_load(&info->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0)
+                        propose = (__hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (bad_mask | MSV1_ASYNC_STUCK)) ? MSV1_VERDICT_VETO : MSV1_VERDICT_GO;
+                    else if (spin >= VERDICT_SPIN_LIMIT) {
+                        atomicOr(&info->flags, MSV1_ASYNC_STUCK);      // the host re-runs the frame synchronously
+                        propose = MSV1_VERDICT_VETO;
+                    }
+                    if (propose) atomicCAS(&info->verdict, 0u, propose);
+                    else __builtin_amdgcn_s_sleep(8);
                 }
-                if (!all) atomicOr(&info->flags, MSV1_ASYNC_STUCK);    // the host re-runs the frame synchronously
-                const uint32_t fl = __hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (all ? 0u : MSV1_ASYNC_STUCK);
-                s_entry = fl & (bad_mask | MSV1_ASYNC_STUCK);
+                s_entry = verdict == MSV1_VERDICT_VETO ? 1u : 0u;
                 if (s_entry) atomicOr(poison, 1u);             // ... and every later frame in flight with it
             }
             arrived = true;

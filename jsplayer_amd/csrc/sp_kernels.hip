@@ -834,7 +834,13 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, in
 bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; }
 // 4 pixels per lane, 256-column spans (8 per lane measured 189 us against 147 us at 64 x 1080p: half as many waves,
 // each with a longer serial row step)
-int iframe_tile_span(const Geometry&) { return 256; }
+namespace {
+int tile_ppl() {   // lab: JSP_SP_TILE_PPL=8 selects 8 pixels per lane (512-column spans)
+    static const int ppl = [] { const char* e = std::getenv("JSP_SP_TILE_PPL"); return e && std::atoi(e) == 8 ? 8 : 4; }();
+    return ppl;
+}
+}  // namespace
+int iframe_tile_span(const Geometry&) { return 64 * tile_ppl(); }
 namespace {
 struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {
@@ -858,7 +864,10 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
     const dim3 grid(nframes, bands * t.nspans);
-    hipLaunchKernelGGL(sp_iframe_tile_kernel<4>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
+    if (tile_ppl() == 8)
+        hipLaunchKernelGGL(sp_iframe_tile_kernel<8>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
+    else
+        hipLaunchKernelGGL(sp_iframe_tile_kernel<4>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,
