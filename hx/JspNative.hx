@@ -33,6 +33,7 @@ extern class JspNative {
     @:native("jsp_needs_index")        static function needsIndex(c:RawPointer<JspCodec>):Int;
     @:native("jsp_last_error")         static function lastError():ConstCharStar;
     @:native("jsp_set_option")         static function setOption(c:RawPointer<JspCodec>, key:ConstCharStar, value:ConstCharStar):Int;
+    @:native("jsp_counter")            static function counter(c:RawPointer<JspCodec>, name:ConstCharStar):cpp.Int64;   // diagnostics: "async_reruns", "lookback_fallbacks"
     // the asynchronous form of DecompressI / DecompressP (optional: a Manager that decodes ahead of display)
     @:native("jsp_decompress_i_async") static function decompressIAsync(c:RawPointer<JspCodec>, src:RawConstPointer<UInt8>, n:SizeT, dst:RawPointer<cpp.Int32>, ticket:RawPointer<UInt64>):Int;
     @:native("jsp_decompress_p_async") static function decompressPAsync(c:RawPointer<JspCodec>, src:RawConstPointer<UInt8>, n:SizeT, dst:RawPointer<cpp.Int32>, ticket:RawPointer<UInt64>):Int;

@@ -138,6 +138,14 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value);
 /* Block until everything queued by this codec has finished (frames in flight on the asynchronous path stay to be
  * collected with jsp_wait). */
 int jsp_sync(jsp_codec* c);
+/* Diagnostics (no reference counterpart): how often this codec instance took one of its slow paths since it was created.
+ *   "async_reruns"       frames of the asynchronous per-frame calls that were re-run through the synchronous path (the GPU
+ *                        alone could not settle the stream — short streams, end markers, skip codes without a previous
+ *                        frame — or the frame's tiles did not report in time);
+ *   "lookback_fallbacks" staged MSVideo1 batches re-run through the descriptor kernels after a tile gave up waiting for
+ *                        the tiles before it.
+ * Unknown names and null arguments answer -1.  Results never depend on either path having been taken. */
+long long jsp_counter(jsp_codec* c, const char* name);
 
 /* ---- asynchronous per-frame calls: the `_async` variant SURVEY.md 8(b) allows for the one-call-per-tick surface
  * (Manager.hx:507,511) --------------------------------------------------------------------------------------------

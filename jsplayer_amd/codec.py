@@ -200,6 +200,13 @@ class _NativeCodec:
         if self._lib.jsp_sync(self._h) != 0:
             raise CodecError(N.last_error())
 
+    def counter(self, name: str) -> int:
+        """How often this instance took one of its slow paths ("async_reruns", "lookback_fallbacks"): jsp_counter."""
+        v = int(self._lib.jsp_counter(self._h, name.encode()))
+        if v < 0:
+            raise CodecError(f"no counter named {name}")
+        return v
+
     def stage_batch(self, srcs: Sequence, dsts: Sequence, is_key: Optional[Sequence[bool]] = None,
                     reuse: Optional["StagedBatch"] = None) -> "StagedBatch":
         """jsp_stage_batch; with `reuse` (a batch of this codec whose decodes have finished) jsp_restage_batch: the batch

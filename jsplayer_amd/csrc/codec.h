@@ -88,6 +88,8 @@ struct jsp_codec {
     // has to be uploaded first to keep them as the caller had them).
     virtual bool may_leave_pixels(const jsp_frame_in& f) = 0;
     virtual int set_option(const char*, const char*) { return -1; }
+    long long async_reruns = 0;            // jsp_counter("async_reruns")
+    virtual long long counter(const char*) { return -1; }   // the codec's own counters (jsp_counter)
     // Host stage of ONE frame for the asynchronous path: like stage(), but it must not wait for the GPU (uploads come
     // from pinned memory owned by the returned object).  What cannot be known without the GPU's answer is settled in
     // async_finish(), called after the frame's event: false = the frame has to be re-run through the synchronous path.

@@ -279,6 +279,12 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
     return c->set_option(key, value);
 }
 
+long long jsp_counter(jsp_codec* c, const char* name) {
+    if (!c || !name) return -1;
+    if (std::strcmp(name, "async_reruns") == 0) return c->async_reruns;
+    return c->counter(name);
+}
+
 // ---- asynchronous per-frame path ---------------------------------------------------------------------------
 
 namespace {
@@ -300,6 +306,7 @@ void redo_from(jsp_codec* c, uint64_t from) {
         if (j.status != JSP_ZERO_STATE) j.why = last_error_slot();
         j.prev_caller_after = c->prev_caller;
         j.redone = true;
+        ++c->async_reruns;
     }
 }
 

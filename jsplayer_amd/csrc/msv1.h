@@ -120,6 +120,7 @@ struct Msv1AsyncInfo {
     uint32_t pad[2];
 };
 constexpr uint32_t MSV1_VERDICT_GO = 1u, MSV1_VERDICT_VETO = 2u;
+constexpr uint32_t MSV1_LAB_DEAF = 0x80000000u;   // in `bad_mask` (tests): mode 3 tiles never see all reports in — the verdict is the time-out's
 // mode 4 (batch form): nothing is rebuilt; every tile writes its blocks' entries of the frame's descriptor table (the record's
 // `dst` points at it) — the on-GPU descriptor parse in ONE launch, for the batches whose frames depend on each other.
 // mode 3 (one frame per launch, at most MSV1_MERGED_MAX_TILES tiles): scout and decode in ONE launch — every tile parses

@@ -5,6 +5,7 @@
 // (msv1_parse_kernels.hip, option "msv1_parse" = "gpu").
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <exception>
 #include <thread>
 #include <unordered_set>
@@ -126,6 +127,7 @@ struct Msv1Staged : jsp_staged {
             // launch, the block kernels paint from them — and only what that path reports counts.
             inject_fault = false;
             ++fallback_runs;
+            if (fallback_total) ++*fallback_total;
             note_kernel("msv1_parse_tiles (look-back fallback)");
             *static_cast<uint32_t*>(h_fault.p) = 0;
             hipStream_t stream = last_stream;
@@ -150,6 +152,7 @@ struct Msv1Staged : jsp_staged {
     hipStream_t last_stream = nullptr;   // where decode() queued its launches
     bool inject_fault = false;           // tests (option "msv1_inject_fault"): the next after_sync() behaves as if a tile had given up
     int fallback_runs = 0;
+    std::shared_ptr<std::atomic<long long>> fallback_total;   // the codec's jsp_counter("lookback_fallbacks")
 };
 
 // One frame on the asynchronous path (jsp_decompress_*_async) with the on-GPU parse.  Nothing here waits for the GPU; what the
@@ -174,6 +177,7 @@ struct Msv1AsyncStaged : jsp_staged {
     // argument, the report comes back through pinned memory, and the kernel reads the frame's bytes from pinned host
     // memory itself (the caller's, or h_stream), leaving a copy in d_stream: no copy is queued at all
     bool merged = false, small_tiles = false;
+    bool deaf = false;                        // tests: see MSV1_LAB_DEAF
     Msv1TileRec rec{};
     DeviceBuffer d_report;                    // one Msv1AsyncInfo, allocated (and zeroed) once: its counters run on
     uint32_t want = 0;                        // ... to this value once every launch so far is through
@@ -188,7 +192,7 @@ struct Msv1AsyncStaged : jsp_staged {
     }
     void decode(hipStream_t stream) override {
         auto* info_dev = d_info();
-        const uint32_t bad = MSV1_ASYNC_SHORT | MSV1_ASYNC_END | MSV1_ASYNC_STUCK | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE);
+        const uint32_t bad = MSV1_ASYNC_SHORT | MSV1_ASYNC_END | MSV1_ASYNC_STUCK | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE) | (deaf ? MSV1_LAB_DEAF : 0u);
         if (merged) {
             want += (uint32_t)ntiles;
             if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
@@ -226,6 +230,11 @@ struct Msv1Codec : jsp_codec {
     bool opt_gpu_parse = true;    // "msv1_parse": frames are parsed on the GPU unless the caller asks for the host parser
     bool opt_scrub_tables = false;
     bool opt_inject_fault = false;
+    bool opt_inject_deaf = false;        // tests ("msv1_inject_fault" = "2"): the next one-launch asynchronous frame never sees all its tiles report
+    std::shared_ptr<std::atomic<long long>> lookback_fallbacks = std::make_shared<std::atomic<long long>>(0);
+    long long counter(const char* name) override {
+        return std::strcmp(name, "lookback_fallbacks") == 0 ? lookback_fallbacks->load() : -1;
+    }
     bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
     bool counted_async = false;   // this instance is in g_async_streams
     hipStream_t up_stream = nullptr;
@@ -300,6 +309,7 @@ struct Msv1Codec : jsp_codec {
         }
         if (std::strcmp(key, "msv1_inject_fault") == 0) {   // tests: the next staged batch behaves as if a tile's look-back had timed out
             opt_inject_fault = std::strcmp(value, "1") == 0;
+            opt_inject_deaf = std::strcmp(value, "2") == 0;   // ... or the next one-launch asynchronous frame as if its verdict wait had
             return 0;
         }
         if (std::strcmp(key, "msv1_scrub_tables") == 0) {   // tests: a replay must rebuild every block table it reads
@@ -399,6 +409,8 @@ struct Msv1Codec : jsp_codec {
         st->ntiles = nt;
         st->merged = opt_async_merged && nt <= MSV1_MERGED_MAX_TILES;
         st->small_tiles = small_tiles;
+        st->deaf = st->merged && opt_inject_deaf;
+        if (st->deaf) opt_inject_deaf = false;
         const size_t slot = (size_t)nt * tile_bytes;
         st->d_stream.reserve(slot + 64);
         st->h_info.reserve(sizeof(Msv1AsyncInfo));
@@ -520,6 +532,7 @@ struct Msv1Codec : jsp_codec {
         st->why.clear();
         st->insignificant_blocks = insignificant_blocks;
         st->inject_fault = opt_inject_fault;
+        st->fallback_total = lookback_fallbacks;
         // the on-GPU parse packs block counts in 20 bits
         st->gpu_parse = opt_gpu_parse && geo.nblocks > 0 && geo.nblocks < (1 << 20);
         if (geo.bits == 8 && !d_palette.p) {  // Preinit not called: all-zero palette

@@ -806,7 +806,7 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
                     verdict = __hip_atomic_load(&info->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (verdict) break;
                     uint32_t propose = 0;
-                    if ((int32_t)(__hip_atomic_load(&info->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0)
+                    if (!(bad_mask & MSV1_LAB_DEAF) && (int32_t)(__hip_atomic_load(&info->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0)
                         propose = (__hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (bad_mask | MSV1_ASYNC_STUCK)) ? MSV1_VERDICT_VETO : MSV1_VERDICT_GO;
                     else if (spin >= VERDICT_SPIN_LIMIT) {
                         atomicOr(&info->flags, MSV1_ASYNC_STUCK);      // the host re-runs the frame synchronously

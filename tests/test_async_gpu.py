@@ -13,7 +13,7 @@ from oracle_binding import OracleAbort, OracleMSVideo1, OracleScreenPressor
 pytestmark = pytest.mark.gpu
 
 
-def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36):
+def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36, before_close=None):
     import torch
     gpu.Preinit(lines)
     orc.Preinit(lines)
@@ -78,6 +78,8 @@ def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36):
         inflight.append((t, i, k, want, picture))
     while inflight:
         collect()
+    if before_close is not None:
+        before_close(gpu)
     gpu.StopAndClean()
     if arena is not None:
         arena.close()
@@ -125,6 +127,28 @@ def test_msvideo1_async_hands_unsettled_frames_to_the_synchronous_path(depth):
     gpu = MSVideo1_16bit(w, h)
     gpu.set_option("msv1_parse", "gpu")
     drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, depth=depth)
+
+
+@pytest.mark.parametrize("form", ["one_launch_dma", "one_launch"])
+def test_msvideo1_async_verdict_that_times_out_goes_to_the_synchronous_path(form):
+    """One-launch form: a frame whose tiles do not all report in time (GPU shared with other work) gets ONE verdict — the
+    time-out's veto, obeyed by every tile —, no pixel of it is written by the launch, and the host re-runs it and the
+    frames in flight behind it; the caller sees the same results, later.  (The time-out cannot be provoked on demand:
+    option msv1_inject_fault = 2 makes the next such launch deaf to its tiles' reports.)"""
+    w, h = 1920, 1080
+    frames, keys, _ = sg.msv1_clip(61, w, h, 8, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=5)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    gpu.set_option("msv1_async", form)
+    gpu.set_option("msv1_inject_fault", "2")
+    assert gpu.counter("async_reruns") == 0
+
+    def check(g):
+        assert 1 <= g.counter("async_reruns") <= 4, g.counter("async_reruns")   # the deaf frame + what was in flight behind it
+        assert g.counter("lookback_fallbacks") == 0
+        with pytest.raises(CodecError):
+            g.counter("no_such_counter")
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, depth=4, before_close=check)
 
 
 @pytest.mark.parametrize("size", [(320, 240), (1224, 752)], ids=["320x240", "1224x752"])

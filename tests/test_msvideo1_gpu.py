@@ -261,6 +261,7 @@ def test_look_back_fault_falls_back_to_the_descriptor_kernels(bits):
     gpu.sync()
     status, adopted, signif = st.results()
     assert "look-back fallback" in st.kernels()
+    assert gpu.counter("lookback_fallbacks") == 1
     assert status == [0] * n
     orc = OracleMSVideo1(bits, w, h, pal)
     orc.Preinit(36)
