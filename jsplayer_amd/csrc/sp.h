@@ -37,6 +37,18 @@ struct IRun {
     uint32_t start;  // linear pixel index of the first pixel
     uint32_t word;   // low 24 bits: colour or addend; bits 24..25: RunKind; bits 26..31 zero
 };
+// Tile layout (sp_iframe_tile_kernel): the same 8 bytes say where the word goes and what it is, ready to use — `start` is
+// the BYTE offset of the run's first pixel inside its span's row of words (4 x column within the span), `word` keeps the low
+// 24 bits, has kTileHead set (the kernel tells "a run starts here" from "nothing" by it) and ONE of the two predictor bits
+// (or neither: a constant): each is a sign-extending bit-field extract away from being a lane mask.
+constexpr uint32_t kTileAbove = 1u << 24;       // the pixel starts from the pixel above (RUN_ABOVE)
+constexpr uint32_t kTileAboveLeft = 1u << 25;   // ... from the pixel above and one to the left (RUN_ABOVE_LEFT), kTileAbove clear
+constexpr uint32_t kTileHead = 0x80000000u;
+inline IRun tile_record(const IRun& r, uint32_t span_row_origin) {   // span_row_origin: linear index of (row, first column of the span)
+    uint32_t w = r.word;
+    if (w & kTileAboveLeft) w &= ~kTileAbove;
+    return IRun{(r.start - span_row_origin) * 4u, w | kTileHead};
+}
 
 // ---- P-frame descriptors --------------------------------------------------------------------
 enum : uint8_t { PB_SUBRECT = 1, PB_MOTION = 2, PB_DATA = 4 };  // 0 = unchanged block

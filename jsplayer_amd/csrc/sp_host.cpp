@@ -265,7 +265,11 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
                     for (uint32_t k = 0; same && k < hi - lo; ++k)
                         same = tiled[lo + k].word == tiled[plo + k].word && tiled[lo + k].start - tiled[plo + k].start == (uint32_t)X;
                     idx[base + r] = (uint32_t)runs.size() | (same ? kRowRepeats : 0u);
-                    if (!same) runs.insert(runs.end(), tiled.begin() + lo, tiled.begin() + hi);
+                    if (!same) {
+                        const size_t b = t / (size_t)nspans, sp = t % (size_t)nspans;
+                        const uint32_t origin = (uint32_t)((b * (size_t)rows_per + (size_t)r) * (size_t)X + sp * (size_t)span_px_);
+                        for (uint32_t k = lo; k < hi; ++k) runs.push_back(tile_record(tiled[k], origin));
+                    }
                 }
                 idx[base + rows_per] = (uint32_t)runs.size();   // the tile's end
             }

@@ -172,25 +172,31 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     }
 }
 
-constexpr uint32_t HEAD_PRESENT = 0x80000000u;
-
 __device__ __forceinline__ uint32_t lane_to_the_left(uint32_t v) {   // lane i gets lane i-1's value (lane 0: undefined)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
-// Tile path: one WAVE per tile = a band of rows x a span of 64*PPL columns.  The host stage hands every
+// Tile path: one WAVE per tile = a band of rows x a span of 256 columns (4 pixels per lane).  The host stage hands every
 // tile what crosses its borders — the row above the band (seeds) and, per row, the pixel left of the span's
 // first pixel one row up (`left`) — orders the run records tile by tile and never lets one cross a span, so
 // a wave needs nothing another wave produces: no workgroup barrier, no LDS shared between waves, the row
-// loop is one wave's private instruction stream (resolve as in sp_iframe_rows_reg_kernel: row above in
-// registers, run words scattered through an LDS row of the span, branch-free predictor).  PPL = 4 pixels per
-// lane is the default (see iframe_tile_span).
-template <int PPL>
+// loop is one wave's private instruction stream: row above in registers, run words scattered through an LDS row
+// of the span, branch-free predictor.
+//
+// The kernel is bound by the instructions it issues (profiles/r03_sp_iframes_tile_sq_counters.txt: a wave64 VALU
+// instruction holds its SIMD for four cycles and the row loop ran to ~110 of them per row), so everything that is the
+// same for all 64 lanes lives on the scalar unit: a window's index entries and left pixels sit one per lane in two
+// registers and each row takes its own with v_readlane (no LDS read, no address arithmetic); a record arrives as
+// {byte offset inside the LDS row, word | kTileHead} (tile_record, sp.h) and is scattered by ONE ds_write with no arithmetic; the word's
+// two predictor bits are exclusive (kTileAbove / kTileAboveLeft), each a v_bfe_i32 away from being a lane mask.
+__device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFFFFFFF for 0
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
                                                             int band_rows, int nspans, int win_cap) {
-    static_assert(PPL == 4 || PPL == 8, "4 or 8 pixels per lane");
-    constexpr int SPAN = 64 * PPL;
-    constexpr int V = PPL / 4;
+    constexpr int PPL = 4, SPAN = 64 * PPL;
     extern __shared__ __align__(16) uint32_t lds[];
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
@@ -202,16 +208,13 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     const int lane = threadIdx.x;
     const int xs = span * SPAN;                       // first column of the span
     const int x0 = xs + lane * PPL;
-    const bool active = x0 < X;                       // X % PPL == 0: an active lane owns PPL pixels
+    const bool active = x0 < X;                       // X % 4 == 0: an active lane owns 4 pixels
     if (fa.flat) {
         if (active)
-            for (int y = yb; y < ye; ++y)
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    store4_global(dst + (size_t)y * X + x0 + 4 * v, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
+            for (int y = yb; y < ye; ++y) store4_global(dst + (size_t)y * X + x0, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
         return;
     }
-    uint32_t* head = lds;                             // SPAN words
+    uint32_t* head = lds;                             // SPAN words, at LDS address 0 of the wave's allocation: a record's offset is its address
     uint32_t* idx = lds + SPAN;                       // band_rows + 1 offsets (relative to fa.runs)
     uint32_t* left = idx + ((band_rows + 1 + 3) & ~3);   // band_rows words
     uint2* win = reinterpret_cast<uint2*>(left + ((band_rows + 3) & ~3));   // win_cap records
@@ -219,11 +222,8 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
     for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
     for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
-#pragma unroll
-    for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + lane * PPL + 4 * v) = make_uint4(0, 0, 0, 0);
-    uint32_t p[PPL];                                  // this lane's pixels of the row above
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) p[j] = 0;
+    *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
+    uint32_t p[PPL] = {0, 0, 0, 0};                   // this lane's pixels of the row above
     if (yb > 0 && active) {
         const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
 #pragma unroll
@@ -236,20 +236,14 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 
     const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
     constexpr uint32_t OFF = ~kRowRepeats;            // an index entry = record offset | kRowRepeats ("same words as the row above")
-    // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the 24-bit colour / addend, its
-    // low 7 bits per byte, and the two masks that pick the pixel's starting value — the pixel to the upper left, the pixel
-    // above, or nothing (a constant).  A row that repeats the layout of the row above keeps all of it.
-    uint32_t d24[PPL], dlo[PPL], m_left[PPL], m_above[PPL];
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) d24[j] = dlo[j] = m_left[j] = m_above[j] = 0;
-    int y = yb;
-    // window: rows y .. y_end-1 whose records fit in win_cap.  A single row with more records than that (more than one run
-    // every other pixel) is scattered straight from global memory.
+    // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the word itself (colour / addend in
+    // its low 24 bits), its low 7 bits per byte, and the two masks that pick the pixel's starting value — the pixel to the upper
+    // left, the pixel above, or nothing (a constant).  A row that repeats the layout of the row above keeps all of it.
+    uint32_t d24[PPL] = {0, 0, 0, 0}, dlo[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
+    const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // the lanes below this one
+    // window: rows [y, y + n) whose records fit in win_cap (at most 63 rows: a window's index entries live one per lane).  A
+    // single row with more records than that (more than one run every other pixel) is scattered straight from global memory.
     constexpr int WMAX = 6;                                    // win_cap <= 64 * WMAX (tile_plan)
-    uint32_t w0 = 0;
-    int y_end = yb, wn = 0;
-    bool direct = false;
-    uint2 wv[WMAX];                                            // the window's records on their way from memory
     // The window's loads are written as asm and waited for BY COUNT.  A wave's loads and stores share one in-order counter
     // (vmcnt): the compiler, seeing loads whose results are used after a loop of row stores, waits for vmcnt(0) — every window
     // then also waited for the acknowledgement of all its own row stores, 2-3 us a dozen times per tile.  Issued as asm the
@@ -257,22 +251,29 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     // re-read its last record) and every row issues exactly one row store, so after R rows `s_waitcnt vmcnt(R)` says precisely
     // "the window's records have landed" while the R stores behind them stay in flight.
     unsigned long long wva[WMAX];
+    struct Window { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
     auto plan_and_fetch = [&](int from) {
-        w0 = idx[from - yb] & OFF;
-        y_end = from + 1;
-        while (y_end < ye && (int)((idx[y_end + 1 - yb] & OFF) - w0) <= win_cap) ++y_end;
-        wn = (int)((idx[y_end - yb] & OFF) - w0);
-        direct = wn > win_cap;                                 // only possible with y_end == from + 1
-        if (direct) wn = 0;
+        Window w;
+        const int k = from + lane;
+        w.ve = idx[(k < ye ? k : ye) - yb];
+        w.vl = left[(k < ye ? k : ye - 1) - yb];
+        w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ve) & OFF;
+        const bool fits = lane >= 1 && k <= ye && (int)((w.ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
+        const unsigned long long m = __ballot(fits) >> 1;
+        int n = __builtin_ctzll(~m);                           // (bit 63 of ~m is always set: at most 63 rows)
+        w.direct = n == 0;                                     // the first row alone is too much for the window
+        if (n == 0) n = 1;
+        w.n = n;
+        w.wn = w.direct ? 0 : (int)(((uint32_t)__builtin_amdgcn_readlane((int)w.ve, n) & OFF) - w.w0);
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
-            const int k = lane + 64 * q, kk = k < wn ? k : (wn > 0 ? wn - 1 : 0);
-            const uint2* src = gruns + w0 + kk;                // (always a record of this tile)
+            const int kq = lane + 64 * q, kk = kq < w.wn ? kq : (w.wn > 0 ? w.wn - 1 : 0);
+            const uint2* src = gruns + w.w0 + kk;              // (always a record of this tile)
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wva[q]) : "v"(src) : "memory");
         }
+        return w;
     };
-    // wait until at most `stores_behind` vector-memory operations of this wave are outstanding (the newest ones), then hand the
-    // window's registers over to the compiler
+    // wait until at most `stores_behind` vector-memory operations of this wave are outstanding (the newest ones)
     auto settle_window = [&](int stores_behind) {
         switch (stores_behind < 16 ? stores_behind : 16) {     // (more than 16 rows per window: waiting down to 16 is just as exact)
 #define JSP_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -281,116 +282,107 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 #undef JSP_VM
         }
 #pragma unroll
-        for (int q = 0; q < WMAX; ++q) {
-            asm volatile("" : "+v"(wva[q]));                   // (the value is defined from here on)
-            wv[q] = make_uint2((uint32_t)wva[q], (uint32_t)(wva[q] >> 32));
-        }
+        for (int q = 0; q < WMAX; ++q) asm volatile("" : "+v"(wva[q]));   // (the values are defined from here on)
     };
-    plan_and_fetch(yb);
+    Window nw = plan_and_fetch(yb);
     int rows_since_fetch = 0;                                  // row stores issued after the loads in flight
+    int y = yb;
     while (y < ye) {
         // The window's records were asked for a window ago — all of them at once, and BEFORE the rows of the window in
         // between were stored: in a load -> wait -> LDS-write loop each 64 records cost a memory round trip of their own, and
         // every wait also waited for the frame stores in front of it (loads and stores share the counter); a tile has a
         // dozen windows.  Now a window costs one wait for the stores behind its loads.
-        const uint32_t cw0 = w0;
-        const int cy_end = y_end, cwn = wn;
-        const bool cdirect = direct;
+        const Window cw = nw;
         settle_window(rows_since_fetch);
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
             const int k = lane + 64 * q;
-            if (k < cwn) win[k] = wv[q];
+            if (k < cw.wn) win[k] = make_uint2((uint32_t)wva[q], (uint32_t)(wva[q] >> 32));
         }
-        if (cy_end < ye) plan_and_fetch(cy_end);               // the next window's records start travelling now
+        if (y + cw.n < ye) nw = plan_and_fetch(y + cw.n);      // the next window's records start travelling now
         rows_since_fetch = 0;
+        uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 0);   // this row's entry (its flag matters)
+        uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 1);
         {
-            const uint32_t r0 = cw0, r1 = idx[y + 1 - yb] & OFF, origin = (uint32_t)((size_t)y * X + xs);
-            if (cdirect) {
-                for (int r = lane; r < (int)(r1 - r0); r += 64) {
-                    const uint2 q = load2_global(gruns + r0 + r);
-                    head[q.x - origin] = q.y | HEAD_PRESENT;
+            const int nfirst = (int)((e1 & OFF) - cw.w0);
+            if (cw.direct) {
+                for (int r = lane; r < nfirst; r += 64) {
+                    const uint2 q = load2_global(gruns + cw.w0 + r);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
                 }
+                __builtin_amdgcn_s_waitcnt(0x0F70);            // (its scatter read straight from memory)
             }
-            if (cdirect) __builtin_amdgcn_s_waitcnt(0x0F70);   // (its scatter above read straight from memory)
             __builtin_amdgcn_wave_barrier();
-            if (!cdirect)
-                for (int r = lane; r < (int)(r1 - r0); r += 64) {
+            if (!cw.direct)
+                for (int r = lane; r < nfirst; r += 64) {
                     const uint2 q = win[r];
-                    head[q.x - origin] = q.y | HEAD_PRESENT;
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
                 }
         }
-        uint32_t e0 = idx[y - yb];                                        // this row's entry (its flag matters)
-        uint32_t e1 = idx[y + 1 - yb];
-        uint32_t e2 = y + 1 < cy_end ? idx[y + 2 - yb] : e1;
-        for (; y < cy_end; ++y) {
-            const bool more = y + 1 < cy_end;
-            const uint32_t e3 = y + 2 < cy_end ? idx[y + 3 - yb] : e2;     // a row ahead, off the critical path
-            const uint32_t r1 = e1 & OFF, r2 = e2 & OFF;
+#if defined(JSP_SP_LAB_STOREONLY)   // lab: the row stores and nothing else
+        for (int r = 0; r < cw.n; ++r, ++y) {
+            if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(p[0], p[1], p[2], p[3]));
+            ++rows_since_fetch;
+        }
+        continue;
+#endif
+        for (int r = 0; r < cw.n; ++r, ++y) {
+            const bool more = r + 1 < cw.n;
+            const uint32_t e2 = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2) : e1;   // (r + 2 <= n <= 63)
             const bool repeat = (e0 & kRowRepeats) != 0u;                  // (uniform) no records: the words of the row above stay
-            const uint32_t eg = left[y - yb];
-            uint4 hv[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) hv[v] = make_uint4(0, 0, 0, 0);
-            if (active && !repeat) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) hv[v] = *reinterpret_cast<const uint4*>(head + lane * PPL + 4 * v);
-            }
-            const int n_next = more ? (int)(r2 - r1) : 0;
+            const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw.vl, r);
+            const int n_next = (int)((e2 & OFF) - (e1 & OFF));             // records of the next row (0 past the window's last)
+            const int next_at = (int)((e1 & OFF) - cw.w0);
             uint2 nrec = make_uint2(0, 0);
-            if (lane < n_next) nrec = win[(int)(r1 - cw0) + lane];
-            const uint32_t row0 = (uint32_t)((size_t)y * X);
+            if (lane < n_next) nrec = win[next_at + lane];
             uint32_t u0 = lane_to_the_left(p[PPL - 1]);
-            if (lane == 0) u0 = eg;
-            if (active) {
-                if (!repeat) {
+            u0 = lane == 0 ? eg : u0;
+            if (!repeat) {
+                const uint4 hv = *reinterpret_cast<const uint4*>(head + lane * PPL);
+                *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
+                const uint32_t h[PPL] = {hv.x, hv.y, hv.z, hv.w};
+                uint32_t last = h[0];
 #pragma unroll
-                    for (int v = 0; v < V; ++v) *reinterpret_cast<uint4*>(head + lane * PPL + 4 * v) = make_uint4(0, 0, 0, 0);
-                    uint32_t h[PPL];
-#pragma unroll
-                    for (int v = 0; v < V; ++v) { h[4 * v] = hv[v].x; h[4 * v + 1] = hv[v].y; h[4 * v + 2] = hv[v].z; h[4 * v + 3] = hv[v].w; }
-                    uint32_t last = h[0];
-#pragma unroll
-                    for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
-                    const unsigned long long seen = __ballot(last != 0u);
-                    const unsigned long long lower = seen & ((1ull << lane) - 1ull);
-                    const int src = lower ? 63 - __clzll((long long)lower) : lane;
-                    uint32_t w = (uint32_t)__shfl((int)last, src);   // lane 0 always has h[0] != 0: a record starts every span
-#pragma unroll
-                    for (int j = 0; j < PPL; ++j) {
-                        w = h[j] ? h[j] : w;
-                        const uint32_t use_above = (uint32_t)((int32_t)(w << 7) >> 31), use_left = (uint32_t)((int32_t)(w << 6) >> 31);
-                        d24[j] = w & 0x00FFFFFFu;
-                        dlo[j] = w & 0x007F7F7Fu;
-                        m_left[j] = use_left & use_above;
-                        m_above[j] = ~use_left & use_above;
-                    }
-                }
-                // pixel = start value + addend, byte by byte (bytes 0..2; byte 3 stays 0): the low 7 bits of every byte
-                // are added in one go (no carry can cross a byte), bit 7 of each byte is put right with an exclusive or
-                uint32_t q[PPL];
+                for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
+                // the word in force at this lane's first pixel: the last one of the nearest lane to the left that has any (lane 0
+                // always has h[0]: a record starts every span; its own `below` is empty and whatever it fetches is not used)
+                const unsigned long long seen = __ballot(last != 0u);
+                const uint32_t below_lo = (uint32_t)seen & lt_lo, below_hi = (uint32_t)(seen >> 32) & lt_hi;
+                const uint32_t lead = min(ffbh(below_hi), ffbh(below_lo) + 32u);   // leading zeros of the 64-bit set (v_ffbh: all ones for 0, which loses the min)
+                uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(~lead << 2), (int)last);   // lane 63 - lead (the instruction looks at address bits 7:2 only)
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) {
-                    const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
-                    q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
+                    w = h[j] ? h[j] : w;
+                    d24[j] = w;
+                    dlo[j] = w & 0x007F7F7Fu;
+                    m_above[j] = (uint32_t)((int32_t)(w << 7) >> 31);   // kTileAbove
+                    m_left[j] = (uint32_t)((int32_t)(w << 6) >> 31);    // kTileAboveLeft
                 }
-#pragma unroll
-                for (int v = 0; v < V; ++v)
-                    store4_global(dst + row0 + x0 + 4 * v, make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]));   // (nontemporal: same time, measured)
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) p[j] = q[j];
             }
-            rows_since_fetch += V;                             // (one row store per 4 pixels of the lane, issued by every wave with an active lane)
-            const uint32_t origin_next = row0 + (uint32_t)X + (uint32_t)xs;
-            if (lane < n_next) head[nrec.x - origin_next] = nrec.y | HEAD_PRESENT;
-            for (int r = lane + 64; r < n_next; r += 64) {   // rows with more records than lanes
-                const uint2 q2 = win[(int)(r1 - cw0) + r];
-                head[q2.x - origin_next] = q2.y | HEAD_PRESENT;
+            // pixel = start value + addend, byte by byte (bytes 0..2; byte 3 stays 0): the low 7 bits of every byte
+            // are added in one go (no carry can cross a byte), bit 7 of each byte is put right with an exclusive or
+            uint32_t q[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
+                q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
+            }
+#if defined(JSP_SP_LAB_NOSTORE)   // lab: everything but the row store (one that never happens keeps the arithmetic alive)
+            if (active && q[0] == 0xFEEDBEEFu) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));
+#else
+            if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));   // (nontemporal: same time, measured)
+#endif
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) p[j] = q[j];
+            ++rows_since_fetch;                                // (one row store per row, issued by every wave with an active lane)
+            if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + nrec.x) = nrec.y;
+            for (int k = lane + 64; k < n_next; k += 64) {     // rows with more records than lanes
+                const uint2 q2 = win[next_at + k];
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q2.x) = q2.y;
             }
             __builtin_amdgcn_wave_barrier();
             e0 = e1;
             e1 = e2;
-            e2 = e3;
         }
     }
 }
@@ -834,13 +826,7 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, in
 bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; }
 // 4 pixels per lane, 256-column spans (8 per lane measured 189 us against 147 us at 64 x 1080p: half as many waves,
 // each with a longer serial row step)
-namespace {
-int tile_ppl() {   // lab: JSP_SP_TILE_PPL=8 selects 8 pixels per lane (512-column spans)
-    static const int ppl = [] { const char* e = std::getenv("JSP_SP_TILE_PPL"); return e && std::atoi(e) == 8 ? 8 : 4; }();
-    return ppl;
-}
-}  // namespace
-int iframe_tile_span(const Geometry&) { return 64 * tile_ppl(); }
+int iframe_tile_span(const Geometry&) { return 256; }   // (8 pixels per lane, 512-column spans: 0.71 vs 0.54 ms, profiles/r03_fused_notes.txt)
 namespace {
 struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {
@@ -864,10 +850,7 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
     const dim3 grid(nframes, bands * t.nspans);
-    if (tile_ppl() == 8)
-        hipLaunchKernelGGL(sp_iframe_tile_kernel<8>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
-    else
-        hipLaunchKernelGGL(sp_iframe_tile_kernel<4>, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
+    hipLaunchKernelGGL(sp_iframe_tile_kernel, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap);
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,

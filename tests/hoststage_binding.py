@@ -14,6 +14,7 @@ _PATH = os.path.join(HERE, "hoststage", "libhoststage.so")
 _lib = None
 
 RUN_CONST, RUN_ABOVE, RUN_ABOVE_LEFT = 0, 1, 3
+TILE_ABOVE_LEFT = 2   # tile layout: bits 24 / 25 of a record's word are exclusive (kTileAbove / kTileAboveLeft)
 PB_SUBRECT, PB_MOTION, PB_DATA = 1, 2, 4
 KIND_NONE, KIND_FLAT, KIND_INTRA, KIND_INTER = 0, 1, 2, 3
 
@@ -192,16 +193,19 @@ def expand_iframe_tiles(desc, X, Y):
                 else:
                     rec = runs[lo:hi]
                     covered[lo:hi] = True
-                    cols = rec[:, 0].astype(np.int64) - y * X - xs
+                    # tile records (sp.h tile_record): byte offset inside the span's row of words; kTileHead set; ONE predictor bit at most
+                    assert np.all(rec[:, 0] % 4 == 0) and np.all(rec[:, 1] >> 31 == 1) and np.all((rec[:, 1] >> 26) & 31 == 0), (b, s, r)
+                    cols = rec[:, 0].astype(np.int64) // 4
                 assert len(rec) and cols[0] == 0 and np.all(np.diff(cols) > 0) and cols[-1] < xe - xs, (b, s, r)
                 k = np.searchsorted(cols, np.arange(xe - xs), side="right") - 1
                 w = rec[k, 1]
-                kind, val = w >> 24, w & 0xFFFFFF
+                kind, val = (w >> 24) & 3, w & 0xFFFFFF
+                assert np.all(kind != 3)
                 lft = np.empty(xe - xs, np.uint32)
                 lft[1:] = up[:-1]
                 lft[0] = left[t * rows_per + r]
                 v = np.where(kind == RUN_ABOVE, _add_bytes(up, val), val)
-                v = np.where(kind == RUN_ABOVE_LEFT, lft, v).astype(np.uint32)
+                v = np.where(kind == TILE_ABOVE_LEFT, lft, v).astype(np.uint32)
                 out[y, xs:xe] = v
                 up = v
     assert covered.all()
