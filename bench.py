@@ -165,6 +165,8 @@ def main():
     nfr_override = int(os.environ["JSP_BENCH_FRAMES"]) if os.environ.get("JSP_BENCH_FRAMES") else None   # experiment knob
     t_gen = time.perf_counter()
     clips = wl.build_clips(name, rank, nfr_override)
+    if os.environ.get("JSP_BENCH_CLIPS"):   # experiment knob: the first n clips of the workload only (digests still match: clips are independent)
+        clips = clips[:max(1, int(os.environ["JSP_BENCH_CLIPS"]))]
     t_gen = time.perf_counter() - t_gen
     inter = spec.get("mode") == "inter"
 

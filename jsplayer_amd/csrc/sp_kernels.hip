@@ -13,7 +13,10 @@
 //                                contiguous bytes per row), lane = 16-byte chunk of a row: unchanged / base
 //                                copy / motion from the previous frame in HBM, literal payload for data
 //                                rectangles (ScreenPressor.hx:361-475);
-//   sp_pframe_group_kernel       consecutive inter frames in one launch, pixels carried in registers.
+//   sp_pframe_group_kernel       consecutive inter frames in one launch, pixels carried in registers: 8 blocks per workgroup,
+//                                four worker waves and a loader wave that brings 16 frames' block records and literals
+//                                into LDS at a time (X % 4 == 0, aligned buffers);
+//   sp_pframe_group1_kernel      the same for any width / alignment: the workgroup stages its own chunks.
 #include <cstdlib>
 #include <mutex>
 
@@ -470,7 +473,7 @@ struct GroupSlot {       // LDS image of one frame of the chunk, 80 bytes
 };
 static_assert(sizeof(GroupSlot) == 80, "GroupSlot layout");
 
-__global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame* __restrict__ frames, int nframes,
+__global__ __launch_bounds__(PWG) void sp_pframe_group1_kernel(const PGroupFrame* __restrict__ frames, int nframes,
                                                               const uint32_t* __restrict__ prev,
                                                               const PBlock* __restrict__ blocks,
                                                               const uint32_t* __restrict__ payload, int X, int Y, int nbx,
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group_kernel(const PGroupFrame*
 // ---------------------------------------------------------------------------------------------------------
 // Inter-frame groups, second form: 8 pixels per lane and a LOADER wave.
 //
-// sp_pframe_group_kernel above staged every chunk of frames itself: all four waves stopped at workgroup barriers — which wait
+// sp_pframe_group1_kernel above staged every chunk of frames itself: all four waves stopped at workgroup barriers — which wait
 // for the wave's row stores in flight — and then paid two load round trips behind the CU's store queue (54 % of its wave cycles
 // parked, profiles/r03_sp_pclip300_group_sq_counters.txt).  A loader wave cannot simply be added to it: with one wave per 16x16
 // block a 1080p frame needs 8 160 of the chip's 8 192 wave slots.  So a lane carries TWO rows of 4 pixels here (a workgroup = 8
@@ -630,7 +633,7 @@ static_assert(sizeof(PGroupFrame) == 16, "one LDS-DMA lane per frame record");
 typedef __attribute__((address_space(1))) const void g2_gvoid;
 typedef __attribute__((address_space(3))) void g2_lvoid;
 
-__global__ __launch_bounds__(G2_WG) void sp_pframe_group2_kernel(const PGroupFrame* __restrict__ frames, int nframes,
+__global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFrame* __restrict__ frames, int nframes,
                                                                 const uint32_t* __restrict__ prev,
                                                                 const PBlock* __restrict__ blocks,
                                                                 const uint32_t* __restrict__ payload, int X, int Y, int nbx) {
@@ -878,17 +881,17 @@ void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nfr
     if (vec && (g.X & 3) == 0 && !old_form) {   // whole 16-byte chunks everywhere: the loader-wave kernel
         static std::once_flag attr_once;
         std::call_once(attr_once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_group2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         });
         const dim3 grid2((g.nbx + G2_BLOCKS - 1) / G2_BLOCKS, g.nby);
-        hipLaunchKernelGGL(sp_pframe_group2_kernel, grid2, dim3(G2_WG), 2 * sizeof(G2Chunk) + 32, stream, d_frames, nframes,
+        hipLaunchKernelGGL(sp_pframe_group_kernel, grid2, dim3(G2_WG), 2 * sizeof(G2Chunk) + 32, stream, d_frames, nframes,
                            reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx);
         return;
     }
     constexpr int chunk = 32, lit_words = 2048, stagger = 1;   // (chunk <= 64: one (frame, block) item per lane in the kernel's scan)
     static_assert(lit_words >= GROUP_LITERALS_MIN, "one frame's literals must fit");
     const size_t lds = (size_t)chunk * sizeof(GroupSlot) + (size_t)chunk * 16 + (size_t)lit_words * 4 + 32;
-    hipLaunchKernelGGL(sp_pframe_group_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
+    hipLaunchKernelGGL(sp_pframe_group1_kernel, grid, dim3(PWG), lds, stream, d_frames, nframes,
                        reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec, chunk, lit_words, stagger);
 }
 

@@ -42,7 +42,10 @@ __global__ void band_kernel(uint32_t* __restrict__ out, int nframes, int B, int 
                 else *(gu32x4*)(dst + (size_t)y * X + x) = v;
             }
         }
-        if (L) __syncthreads();
+        if (L == 1) __syncthreads();
+        else if (L == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (L == 3) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (L == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     }
     if (a == 0x12345u) sink[0] = a;
 }
@@ -72,7 +75,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(u32x4* __restrict__ dst, siz
     int since = 0;
     for (size_t p = blockIdx.x; p < n_pieces; p += gridDim.x) {
         *(gu32x4*)(dst + p * 256 + threadIdx.x) = u32x4{(uint32_t)p, 1u, 2u, 3u};
-        if (sync_every && ++since == sync_every) {
+        if (sync_every < 0) {                                  // no lockstep, but at most -sync_every - 1 stores of the wave in flight
+            if (sync_every == -1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (sync_every == -2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (sync_every == -3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (sync_every == -5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        if (sync_every > 0 && ++since == sync_every) {
             since = 0;
             arrived += gridDim.x;
             if (threadIdx.x == 0) {
@@ -144,17 +154,37 @@ int main(int argc, char** argv) {
         printf("pieces: one wave per 1 KB, B %4d, %s order | %9.1f us %9.0f GB/s\n", B, order ? "band-time" : "address", best * 1000, bytes / best / 1e6);
         fflush(stdout);
     };
+    for (int per : {1, 2, 4, 8, 16, 64}) {   // short-lived workgroups in address order: `per` pieces of 4 KB each (sweep_kernel with a grid of n / per)
+        const size_t n_pieces = (size_t)F * 1920 * Y * 4 / 4096;
+        const unsigned grid = (unsigned)(n_pieces / per);
+        auto launch = [&] { hipLaunchKernelGGL(sweep_kernel, dim3(grid), dim3(256), 0, 0, (u32x4*)out, n_pieces, 0, (unsigned int*)sink, 0u); };
+        launch();
+        CK(hipDeviceSynchronize());
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 3; ++i) launch();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms / 3 < best) best = ms / 3;
+        }
+        printf("sweep: %u workgroups handed out in order, %d pieces of 4 KB each (grid-stride) | %9.1f us %9.0f GB/s\n", grid, per, best * 1000,
+               (double)n_pieces * 4096 / best / 1e6);
+        fflush(stdout);
+    }
     {
         unsigned int* counter;
         CK(hipMalloc(&counter, 64));
         CK(hipMemset(counter, 0, 64));
         const size_t n_pieces = (size_t)F * 1920 * Y * 4 / 4096;
         unsigned int base = 0;
-        for (int grid : {2025, 1080}) for (int sync_every : {0, 1, 2, 4, 16}) {
+        for (int grid : {2025, 8100}) for (int sync_every : {0, -1}) {
             const size_t iters = (n_pieces + grid - 1) / grid;
             auto launch = [&] {
                 hipLaunchKernelGGL(sweep_kernel, dim3(grid), dim3(256), 0, 0, (u32x4*)out, n_pieces, sync_every, counter, base);
-                if (sync_every) base += (unsigned int)(iters / sync_every) * grid;   // (every workgroup makes the same number of visits: n_pieces is a multiple of the grid)
+                if (sync_every > 0) base += (unsigned int)(iters / sync_every) * grid;   // (every workgroup makes the same number of visits: n_pieces is a multiple of the grid)
             };
             if (n_pieces % grid) { printf("pieces not a multiple of the grid\n"); break; }
             launch();
@@ -169,7 +199,7 @@ int main(int argc, char** argv) {
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 if (ms / 3 < best) best = ms / 3;
             }
-            printf("sweep: %d long-lived workgroups, 4 KB pieces, global lockstep every %2d | %9.1f us %9.0f GB/s\n", grid, sync_every, best * 1000,
+            printf("sweep: %d long-lived workgroups, 4 KB pieces, stores in flight per wave at most %2d (0: no limit) | %9.1f us %9.0f GB/s\n", grid, -sync_every, best * 1000,
                    (double)n_pieces * 4096 / best / 1e6);
             fflush(stdout);
         }
@@ -180,7 +210,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(X), &hX, sizeof(int)));
         bytes = (double)F * hX * Y * 4;
         printf("row pitch %d bytes\n", hX * 4);
-        for (int B : {90}) for (int order : {0, 1}) run(B, 1, 8, 0, order, 20, 4608, 0);
+        for (int B : {90}) for (int order : {0}) for (int L : {0}) run(B, 1, 1, L, order, 20, 4608, 0);
     }
     hX = 1920;
     CK(hipMemcpyToSymbol(HIP_SYMBOL(X), &hX, sizeof(int)));
