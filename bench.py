@@ -337,6 +337,25 @@ def main():
                 ceiling = {"value": cj[kind + "_GBs"], "unit": "GB/s", "kind": kind, "shape": cj[kind + "_shape"], "source": cj["source"]}
             except Exception:
                 ceiling = None
+        # ... and what THIS box's memory takes right now, measured in this run: nothing but 16-byte stores, one per lane, workgroups
+        # in address order (the friendliest shape found, profiles/r03_sp_store_lab.txt) over 2 GiB, HIP events on the bench's stream.
+        # The boxes of the pool differ by up to a fifth here (profiles/r03_fused_notes.txt: the memory phases of the kernel are
+        # what moves, the arithmetic phases do not), so the fraction of this number travels better than the fraction of 8 TB/s.
+        live = None
+        try:
+            import ctypes as C
+            from jsplayer_amd import _native as N
+            scratch = torch.empty(1 << 29, dtype=torch.int32, device=f"cuda:{local_rank}")
+            rate = C.c_double(0.0)
+            if N.lib().jsp_measure_fill(C.c_void_p(scratch.data_ptr()), C.c_size_t(scratch.numel() * 4), 10, C.byref(rate), C.c_void_p(stream.cuda_stream)) == 0:
+                live = {"value": round(rate.value, 1), "unit": "GB/s", "kind": "fill", "shape": "16-byte stores, one per lane, 256-lane workgroups in address order, 2 GiB",
+                        "source": "measured in this run (jsp_measure_fill: 10 launches, HIP events, best of 3)"}
+            del scratch
+        except Exception as e:   # (the number is a courtesy: the bench line does not depend on it)
+            print(f"[bench] live fill ceiling not measured: {e}", file=sys.stderr)
+        recorded = ceiling
+        if live:
+            ceiling = live
         out = {
             "metric": "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs",
             "value": round(total_pixels / elapsed / 1e6, 1),
@@ -372,6 +391,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "measured_ceiling": ceiling,
                 "frac_of_measured": round(achieved / ceiling["value"], 4) if ceiling else None,
+                "recorded_ceiling": recorded,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_step": alg,

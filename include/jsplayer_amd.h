@@ -241,6 +241,12 @@ int jsp_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, si
                       void* hip_stream);
 
 /* Library/build identification: "jsplayer_amd <version> gfx950". */
+/* Measurement helper (no reference counterpart): the store rate this GPU reaches when asked for nothing else — `reps` launches
+ * that fill `nbytes` of `device` (16-byte aligned) with one 16-byte store per lane, workgroups in address order, timed with HIP
+ * events on `hip_stream`; best of three passes, GB/s.  bench.py reports it next to the 8 TB/s the roofline is priced against
+ * (the boxes of one pool differ by a fifth in what their memory delivers). */
+int jsp_measure_fill(int32_t* device, size_t nbytes, int reps, double* gbytes_per_s, void* hip_stream);
+
 const char* jsp_version(void);
 
 #ifdef __cplusplus

@@ -81,6 +81,7 @@ SIGNATURES = {
     "jsp_staged_kernels": (C.c_char_p, [C.c_void_p]),
     "jsp_staged_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "jsp_display_convert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "jsp_measure_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "jsp_frames_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),
     "jsp_version": (C.c_char_p, []),
 }

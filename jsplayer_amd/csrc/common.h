@@ -2,7 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -30,6 +34,34 @@ struct HipError : std::runtime_error {
             throw ::jsp::HipError(_buf);                                                       \
         }                                                                                      \
     } while (0)
+
+// Host threads this process may keep busy: the machine's, narrowed by the affinity mask and by the cgroup's CPU quota (a GPU
+// box shows all 256 threads of its host to a container that may use 16 of them: worker pools sized by
+// hardware_concurrency() there spend their time being throttled).  Read once.
+inline int usable_cpus() {
+    static const int n = [] {
+        int c = (int)std::thread::hardware_concurrency();
+        if (c < 1) c = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1 && a < c) c = a; }
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {               // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            long long period = 0;
+            if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+                const long long quota = std::atoll(q);
+                if (quota > 0) { const int k = (int)((quota + period - 1) / period); if (k >= 1 && k < c) c = k; }
+            }
+            std::fclose(f);
+        } else {                                                                   // cgroup v1
+            long long quota = -1, period = 0;
+            if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(fq, "%lld", &quota) != 1) quota = -1; std::fclose(fq); }
+            if (FILE* fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(fp, "%lld", &period) != 1) period = 0; std::fclose(fp); }
+            if (quota > 0 && period > 0) { const int k = (int)((quota + period - 1) / period); if (k >= 1 && k < c) c = k; }
+        }
+        return c;
+    }();
+    return n;
+}
 
 inline double now_ms() {
     using clk = std::chrono::steady_clock;

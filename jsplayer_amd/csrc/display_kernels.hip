@@ -62,9 +62,50 @@ __global__ __launch_bounds__(256) void frames_differ_kernel(const uint32_t* __re
     if (__ballot(diff) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// What the memory system takes when it is asked for nothing but stores in the friendliest shape this chip has been found to
+// have (profiles/r03_sp_store_lab.txt): 16 bytes per lane, ONE store per lane, workgroups of 256 lanes handed out in address order.
+typedef uint32_t fill_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ceiling_fill_kernel(fill_u32x4* __restrict__ dst, size_t n, uint32_t v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = fill_u32x4{v, v + 1u, v + 2u, v + 3u};
+}
+
 }  // namespace
 
 extern "C" {
+
+int jsp_measure_fill(int32_t* device, size_t nbytes, int reps, double* gbytes_per_s, void* hip_stream) {
+    try {
+        if (!device || !gbytes_per_s || nbytes < 4096 || reps < 1 || (reinterpret_cast<uintptr_t>(device) & 15)) throw std::runtime_error("bad argument");
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        const size_t n = nbytes / 16;
+        if ((n + 255) / 256 > 0x7FFFFFFFull) throw std::runtime_error("buffer too large for one launch");
+        const dim3 grid((unsigned)((n + 255) / 256));
+        hipEvent_t e0, e1;
+        JSP_HIP(hipEventCreate(&e0));
+        JSP_HIP(hipEventCreate(&e1));
+        float best = 0;
+        for (int pass = 0; pass < 3; ++pass) {                   // (the first pass also warms the launch path up)
+            JSP_HIP(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r)
+                hipLaunchKernelGGL(ceiling_fill_kernel, grid, dim3(256), 0, s, reinterpret_cast<fill_u32x4*>(device), n, (uint32_t)(pass * 16 + r));
+            JSP_HIP(hipEventRecord(e1, s));
+            JSP_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            JSP_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (pass == 0 || ms < best) best = ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        JSP_HIP(hipGetLastError());
+        *gbytes_per_s = (double)n * 16.0 * reps / ((double)best * 1e6);
+        return 0;
+    } catch (const std::exception& e) {
+        jsp::set_error("%s", e.what());
+        return JSP_ERROR_OCCURED;
+    }
+}
+
 
 int jsp_display_convert(const int32_t* frame, int32_t* out, int width, int height, int mode, int flip_rows,
                         void* hip_stream) {

@@ -5,6 +5,7 @@
 // (msv1_parse_kernels.hip, option "msv1_parse" = "gpu").
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <memory>
 #include <exception>
 #include <thread>
@@ -588,7 +589,7 @@ struct Msv1Codec : jsp_codec {
                     std::memset(h_stream + beg[i] + frames[i].n, 0, padded - frames[i].n);
                 }
             };
-            const int nthreads = gather_bytes > (32u << 20) ? (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency() / 2)) : 1;
+            const int nthreads = gather_bytes > (32u << 20) ? (int)std::min<size_t>(8, (size_t)std::max(1, usable_cpus() / 2)) : 1;
             if (nthreads > 1) {
                 std::vector<std::thread> pool;
                 std::exception_ptr failed;
@@ -905,8 +906,14 @@ struct Msv1Codec : jsp_codec {
                         for (int i = f0; i < f1; ++i)
                             if (j < h_pf[i].ntiles) rr[o++] = tmp[h_pf[i].first_tile - t0 + j];
                 };
+                static const int major_frames = [] { const char* e = std::getenv("JSP_MSV1_TILE_MAJOR_FRAMES"); return e ? std::atoi(e) : 0; }();   // lab: permute within runs of this many frames
                 for (const auto& g : st->groups)
-                    if (g.fused) tile_major(recs, g.first, g.first + g.count);
+                    if (g.fused) {
+                        if (major_frames > 0)
+                            for (int f = g.first; f < g.first + g.count; f += major_frames) tile_major(recs, f, std::min(f + major_frames, g.first + g.count));
+                        else
+                            tile_major(recs, g.first, g.first + g.count);
+                    }
                 JSP_HIP(hipMemcpyAsync(st->d_recs.p, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
                 if (st->needs_desc) {   // the same records for the descriptor form: `dst` = the frame's block table; frames whose
                                         // table nobody reads (fused groups) or that came from the host parser are skipped

@@ -110,7 +110,7 @@ struct SpCodec : jsp_codec {
     int async_threads() const {
         if (opt_async_threads > 0) return opt_async_threads;
         const int streams = std::max(1, g_sp_async_streams.load());
-        int t = (int)std::thread::hardware_concurrency() / streams;
+        int t = usable_cpus() / streams;
         return t < 2 ? 1 : (t > 8 ? 8 : t);
     }
     bool async_by_workers() override {
@@ -391,7 +391,7 @@ struct SpCodec : jsp_codec {
         std::vector<HostFrame> hf(nf);
         for (int i = 0; i < nf; ++i) hf[i] = HostFrame{frames[i].src, frames[i].n, frames[i].key};
         int threads = opt_host_threads;
-        if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads); }
+        if (threads <= 0) { threads = usable_cpus(); threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads); }
         for (int w0 = 0; w0 < nf;) {
             int w1 = w0 + 1, groups = 1;
             while (w1 < nf && w1 - w0 < 64) {
