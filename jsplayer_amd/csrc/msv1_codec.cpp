@@ -548,9 +548,10 @@ struct Msv1Codec : jsp_codec {
         std::vector<size_t> beg(nf);
         size_t total_stream = 0;
         const size_t frame_align = st->gpu_parse ? (size_t)msv1_parse_tile_bytes() : 16;
+        static const size_t lab_gap = [] { const char* e = std::getenv("JSP_MSV1_FRAME_GAP"); return e ? (size_t)std::atoll(e) & ~size_t(15) : size_t(0); }();   // lab: bytes left free after every frame's slot
         for (int i = 0; i < nf; ++i) {
             beg[i] = total_stream;
-            total_stream += (frames[i].n + frame_align - 1) / frame_align * frame_align;
+            total_stream += (frames[i].n + frame_align - 1) / frame_align * frame_align + (st->gpu_parse ? lab_gap : 0);
         }
         if (total_stream + 64 > 0xFFFFFFF0u) throw std::runtime_error("batch stream exceeds 4 GiB");
         // Where the frames' bytes are: a frame in pinned host memory (jsp_host_alloc, or memory the caller registered) is uploaded

@@ -154,7 +154,19 @@ class StagedWorkload:
                 first = torch.empty(W * H, dtype=torch.int32, device=f"cuda:{device}")
                 assert codec.DecompressI(frames[0], first) == 0
                 frames, keys = frames[1:], keys[1:]
-            dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{device}") for _ in frames]
+            # Every frame buffer is an allocation of its own, as a player's frame pool hands them out (jsp_pool_create, FramePool.hx).
+            # Where the frames lie in physical memory moves the store-bound kernels by up to a quarter from one session to the next
+            # on the SAME GPU (tools/front_lab.hip, tools/lab/pool_ab.sh): lab knobs below put them in one pool instead.
+            if os.environ.get("JSP_BENCH_FRAME_POOL") or os.environ.get("JSP_BENCH_FRAME_STRIDE") or os.environ.get("JSP_BENCH_FRAMES_PER_POOL"):
+                stride = int(os.environ.get("JSP_BENCH_FRAME_STRIDE", W * H * 4)) // 4      # bytes from frame to frame
+                per_pool = int(os.environ.get("JSP_BENCH_FRAMES_PER_POOL", 0)) or len(frames)
+                dsts = []
+                for lo in range(0, len(frames), per_pool):
+                    k = min(per_pool, len(frames) - lo)
+                    pool = torch.empty((k - 1) * stride + W * H, dtype=torch.int32, device=f"cuda:{device}")
+                    dsts += [pool[i * stride:i * stride + W * H] for i in range(k)]
+            else:
+                dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{device}") for _ in frames]
             self.staged.append(codec.stage_batch(frames, dsts, is_key=keys))   # host stage + H2D
             self.codecs.append(codec)
             self.dsts.append(dsts)

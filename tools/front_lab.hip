@@ -1,0 +1,128 @@
+// lab: does it matter WHERE the destination frames lie?  The store shape of msv1_fused_kernel on all-solid frames — a workgroup per
+// (frame, tile of T blocks), tiles handed out tile-major (tile j of every frame, then tile j + 1 ...: up to F write fronts at once),
+// lane = 4x4 block, four 16-byte row stores per block — with the frames
+//   A  back to back in one allocation,          B  one hipMalloc per frame,
+//   C  two frames per 20 MB hipMalloc (what torch's caching allocator does with 8.3 MB tensors),
+//   D  one VA range backed by separately created 2 MB-granular physical chunks (hipMemCreate / hipMemMap), frames back to back.
+//   hipcc -O3 --offload-arch=gfx950 tools/front_lab.hip -o tools/front_lab.bin && tools/front_lab.bin [frames]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+constexpr int X = 1920, Y = 1080, NBX = X / 4, NBLK = (X / 4) * (Y / 4);
+constexpr size_t FRAME_BYTES = (size_t)X * Y * 4;
+
+__global__ __launch_bounds__(256) void front_kernel(uint32_t* const* __restrict__ frames, int nframes, int T, int tiles_per_frame, int tile_major) {
+    int f, j;
+    if (tile_major) { j = blockIdx.x / nframes; f = blockIdx.x - j * nframes; }
+    else { f = blockIdx.x / tiles_per_frame; j = blockIdx.x - f * tiles_per_frame; }
+    uint32_t* dst = frames[f];
+    const int b0 = j * T;
+    for (int r = 0; r < T; r += 256) {
+        const int blk = b0 + r + (int)threadIdx.x;
+        if (blk < NBLK) {
+            const int by = blk / NBX, bx = blk - by * NBX;
+            uint32_t* p = dst + (size_t)by * 4 * X + bx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) *(gu32x4*)(p + (size_t)y * X) = u32x4{(uint32_t)blk, 1u, 2u, (uint32_t)y};
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    const int F = argc > 1 ? atoi(argv[1]) : 512;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    uint32_t** d_table;
+    CK(hipMalloc(&d_table, sizeof(uint32_t*) * F));
+    auto measure = [&](const char* what, const std::vector<uint32_t*>& frames) {
+        CK(hipMemcpy(d_table, frames.data(), sizeof(uint32_t*) * F, hipMemcpyHostToDevice));
+        for (int T : {8192, 2048}) for (int tm : {1, 0}) {
+            const int tpf = (NBLK + T - 1) / T;
+            auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * F), dim3(256), 0, 0, d_table, F, T, tpf, tm); };
+            launch();
+            CK(hipDeviceSynchronize());
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / 3 < best) best = ms / 3;
+            }
+            printf("%-58s T %5d %s | %8.1f us %7.0f GB/s\n", what, T, tm ? "tile-major " : "frame-major", best * 1000, (double)F * FRAME_BYTES / best / 1e6);
+            fflush(stdout);
+        }
+    };
+    {   // A
+        uint32_t* pool;
+        CK(hipMalloc(&pool, FRAME_BYTES * F));
+        std::vector<uint32_t*> fr(F);
+        for (int i = 0; i < F; ++i) fr[i] = pool + (size_t)i * X * Y;
+        measure("A one allocation, frames back to back", fr);
+        CK(hipFree(pool));
+    }
+    {   // B
+        std::vector<uint32_t*> fr(F);
+        for (int i = 0; i < F; ++i) CK(hipMalloc(&fr[i], FRAME_BYTES));
+        measure("B one hipMalloc per frame", fr);
+        printf("   (frame 0 at %p, 1 at %p, 2 at %p)\n", (void*)fr[0], (void*)fr[1], (void*)fr[2]);
+        for (auto* p : fr) CK(hipFree(p));
+    }
+    {   // C
+        std::vector<uint32_t*> fr(F), segs;
+        for (int i = 0; i < F; i += 2) {
+            uint32_t* s;
+            CK(hipMalloc(&s, 20u << 20));
+            segs.push_back(s);
+            fr[i] = s;
+            if (i + 1 < F) fr[i + 1] = s + (size_t)X * Y;
+        }
+        measure("C two frames per 20 MB hipMalloc", fr);
+        printf("   (segment 0 at %p, 1 at %p, 2 at %p)\n", (void*)segs[0], (void*)segs[1], (void*)segs[2]);
+        for (auto* p : segs) CK(hipFree(p));
+    }
+    {   // D
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { printf("D: no virtual memory management here\n"); return 0; }
+        for (size_t chunk : {(size_t)256 << 20, (size_t)1024 << 20}) {
+            chunk = (chunk + gran - 1) / gran * gran;
+            const size_t total = (FRAME_BYTES * F + chunk - 1) / chunk * chunk;
+            void* va = nullptr;
+            if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { printf("D: reserve failed\n"); break; }
+            std::vector<hipMemGenericAllocationHandle_t> handles;
+            bool ok = true;
+            for (size_t off = 0; off < total && ok; off += chunk) {
+                hipMemGenericAllocationHandle_t h;
+                ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess && hipMemMap((char*)va + off, chunk, 0, h, 0) == hipSuccess;
+                if (ok) handles.push_back(h);
+            }
+            hipMemAccessDesc acc{};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            ok = ok && hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+            if (ok) {
+                std::vector<uint32_t*> fr(F);
+                for (int i = 0; i < F; ++i) fr[i] = (uint32_t*)va + (size_t)i * X * Y;
+                char what[96];
+                std::snprintf(what, sizeof what, "D one VA range over physical chunks of %zu MB (granularity %zu KB)", chunk >> 20, gran >> 10);
+                measure(what, fr);
+            } else printf("D: mapping chunks of %zu MB failed\n", chunk >> 20);
+            (void)hipMemUnmap(va, total);
+            for (auto h : handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(va, total);
+        }
+    }
+    return 0;
+}
