@@ -95,8 +95,16 @@ const char* jsp_last_error(void);
 
 /* ---- frame pool in HBM (Manager.hx:114-118: num_buffers+1 frame buffers) ---------------- */
 
+/* A pool of 32 frames or more (what batch decoding writes into: tile j of every frame at about the same time) is PLACED: where the
+ * frames lie in physical memory, relative to each other, moves that store shape by a quarter (persistently per set of allocations; no
+ * query reveals it), so the pool measures up to nine candidates with the shape (a few milliseconds each) — two frames per
+ * allocation, one allocation for all, one per frame, in turn, the slow ones held until it has chosen — and keeps the first that takes what a plain fill
+ * takes, or the best.  JSP_POOL_PROBE=0 in the environment: one allocation per frame, first come — what smaller pools (a player's
+ * num_buffers + 1) always get. */
 jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf);
 int32_t* jsp_pool_buffer(jsp_pool* p, int i); /* device pointer, width*height ints, zeroed */
+/* GB/s the chosen allocation took from the probe (0: a pool that is not probed); *attempts = allocations tried. */
+double jsp_pool_store_rate(jsp_pool* p, int* attempts);
 int jsp_pool_count(jsp_pool* p);
 void jsp_pool_destroy(jsp_pool* p);
 /* Copy one frame between a device frame buffer and host memory (parity checks, display). */

@@ -5,8 +5,8 @@ C++ (parse / entropy -> descriptor tables), reconstruction in hand-written HIP f
 through the C ABI of include/jsplayer_amd.h.  This package is the Python mirror of the reference's
 plugin interface over that ABI.
 """
-from .codec import (CodecError, DecoderState, HostBuffer, MSVideo1_16bit, MSVideo1_8bit, PFrameResult, ScreenPressor,
+from .codec import (CodecError, DecoderState, FramePool, HostBuffer, MSVideo1_16bit, MSVideo1_8bit, PFrameResult, ScreenPressor,
                     StagedBatch)
 
-__all__ = ["CodecError", "DecoderState", "HostBuffer", "MSVideo1_16bit", "MSVideo1_8bit", "PFrameResult", "ScreenPressor",
+__all__ = ["CodecError", "DecoderState", "FramePool", "HostBuffer", "MSVideo1_16bit", "MSVideo1_8bit", "PFrameResult", "ScreenPressor",
            "StagedBatch"]

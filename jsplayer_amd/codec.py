@@ -320,6 +320,44 @@ class ScreenPressor(_NativeCodec):
         super().__init__(width, height, bits_per_pixel, None, device)
 
 
+class _DeviceView:
+    """npixels int32 at a device address, for torch.as_tensor (the CUDA array interface; ROCm builds of torch honour it)."""
+
+    def __init__(self, ptr: int, npixels: int):
+        self.__cuda_array_interface__ = {"shape": (npixels,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+class FramePool:
+    """The frame buffers a caller decodes into (Manager.hx:114-118, hx/FrameBuffer.hx): jsp_pool_create.  `frames` are torch int32
+    tensors over the pool's buffers (valid until close()).  A pool of 32 frames or more is one allocation that the library PLACES —
+    it measures what candidate allocations take from the decode kernels' store shape and keeps a fast one (include/jsplayer_amd.h);
+    `store_rate` (GB/s, 0 for small pools) and `attempts` say what it found."""
+
+    def __init__(self, width: int, height: int, count: int, device: int = 0):
+        import torch
+        self._lib = N.lib()
+        self._h = self._lib.jsp_pool_create(device, width, height, count)
+        if not self._h:
+            raise CodecError(N.last_error())
+        tried = C.c_int(0)
+        self.store_rate = float(self._lib.jsp_pool_store_rate(self._h, C.byref(tried)))
+        self.attempts = tried.value
+        n = width * height
+        self.frames = [torch.as_tensor(_DeviceView(int(self._lib.jsp_pool_buffer(self._h, i)), n), device=f"cuda:{device}") for i in range(count)]
+
+    def close(self) -> None:
+        if self._h:
+            self.frames = []
+            self._lib.jsp_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HostBuffer:
     """Pinned host memory for compressed frames (jsp_host_alloc): uploads from it need no staging copy.  `.array` is a
     numpy uint8 view; frames handed to the *_async calls as slices of it are uploaded from where they are."""

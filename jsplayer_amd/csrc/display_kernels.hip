@@ -70,7 +70,69 @@ __global__ __launch_bounds__(256) void ceiling_fill_kernel(fill_u32x4* __restric
     if (i < n) dst[i] = fill_u32x4{v, v + 1u, v + 2u, v + 3u};
 }
 
+// What a frame pool's memory takes from the decode kernels' store shape: a workgroup per (frame, run of `T` 4x4 blocks), handed out
+// tile-major — run j of every frame, then run j + 1: as many write fronts as the pool has frames —, lane = block, four 16-byte row
+// stores per block.  Physical memory differs in what it takes from this shape by a quarter (jsp_pool_create probes with it).
+__global__ __launch_bounds__(256) void pool_probe_kernel(uint32_t* const* __restrict__ frames, int nframes, int X, int nbx, int nblocks, int T, uint32_t v) {
+    const int j = blockIdx.x / nframes, f = blockIdx.x - j * nframes;
+    uint32_t* dst = frames[f];
+    for (int r = 0; r < T; r += 256) {
+        const int blk = j * T + r + (int)threadIdx.x;
+        if (blk < nblocks) {
+            const int by = blk / nbx, bx = blk - by * nbx;
+            uint32_t* p = dst + (size_t)by * 4 * X + bx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) *reinterpret_cast<fill_u32x4*>(p + (size_t)y * X) = fill_u32x4{v, v, v, v};
+        }
+    }
+}
+
 }  // namespace
+
+namespace jsp {
+// GB/s of pool_probe_kernel over the `nframes` frames of X x Y pixels whose addresses are in the device table `d_frames` (X, Y
+// multiples of 4, 16-byte aligned frames); leaves the frames filled with `fill`.  Synchronous.
+double pool_store_rate(uint32_t* const* d_frames, int nframes, int X, int Y, uint32_t fill) {
+    const int nbx = X / 4, nblocks = nbx * (Y / 4), T = 8192, runs = (nblocks + T - 1) / T;
+    hipEvent_t e0, e1;
+    JSP_HIP(hipEventCreate(&e0));
+    JSP_HIP(hipEventCreate(&e1));
+    float best = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        JSP_HIP(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(pool_probe_kernel, dim3((unsigned)(runs * nframes)), dim3(256), 0, nullptr, d_frames, nframes, X, nbx, nblocks, T, fill);
+        JSP_HIP(hipEventRecord(e1, nullptr));
+        JSP_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        JSP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 1 || (pass == 2 && ms < best)) best = ms;        // (the first pass faults the pages in)
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    JSP_HIP(hipGetLastError());
+    return (double)nblocks * 64.0 * nframes / ((double)best * 1e6);
+}
+// GB/s of the plain fill (one 16-byte store per lane, workgroups in address order) over the same memory: the yardstick.
+double pool_fill_rate(uint32_t* slab, size_t nbytes) {
+    const size_t n = nbytes / 16;
+    hipEvent_t e0, e1;
+    JSP_HIP(hipEventCreate(&e0));
+    JSP_HIP(hipEventCreate(&e1));
+    float best = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        JSP_HIP(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(ceiling_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<fill_u32x4*>(slab), n, 0u);
+        JSP_HIP(hipEventRecord(e1, nullptr));
+        JSP_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        JSP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 1 || (pass == 2 && ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)n * 16.0 / ((double)best * 1e6);
+}
+}  // namespace jsp
 
 extern "C" {
 

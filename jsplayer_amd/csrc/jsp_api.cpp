@@ -1,4 +1,5 @@
 // extern "C" surface of libjsplayer_amd.so (declared in include/jsplayer_amd.h).
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 
@@ -64,7 +65,16 @@ struct jsp_pool {
     int device = 0;
     int X = 0, Y = 0;
     std::vector<int32_t*> bufs;
+    std::vector<void*> allocs;     // what to free: one allocation per frame, or one for all of them (bufs point into it)
+    double store_rate = 0;         // GB/s the chosen slab took from the probe (0: not probed)
+    int attempts = 0;              // allocations tried
+    double fill_rate = 0;          // GB/s of a plain fill over the first candidate: what the probe is held against
+    std::vector<double> tried;     // ... and what each of them took
 };
+namespace jsp {
+double pool_store_rate(uint32_t* const* d_frames, int nframes, int X, int Y, uint32_t fill);
+double pool_fill_rate(uint32_t* slab, size_t nbytes);
+}
 
 namespace {
 
@@ -224,9 +234,83 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         p->X = width;
         p->Y = height;
         const size_t bytes = (size_t)width * height * sizeof(int32_t);
+        // A pool large enough for batches (the staged-batch calls write tile j of EVERY frame at about the same time: as many write
+        // fronts as frames) is probed: the same store shape gets 5.4 - 7.0 TB/s from one set of allocations or another of the same
+        // process, persistently — a property of where the frames lie in physical memory, relative to each other, that no query
+        // reveals (profiles/r03_fused_notes.txt, tools/front_lab.hip): sometimes one allocation per frame is the fast form and one
+        // allocation for all the slow one, sometimes the other way round, sometimes the second try of the same form.  So the pool
+        // measures what it was given (a few milliseconds per candidate), going round three forms (two frames per allocation, one
+        // allocation for all, one per frame), keeps slow candidates
+        // allocated while it asks for the next (else the allocator hands the same pages back) and settles for the first that takes
+        // what a plain fill of the same memory takes, or the best of nine.  JSP_POOL_PROBE=0: one allocation per frame, first come.
+        constexpr int kProbeFrom = 32, kCandidates = 9;
+        const char* env = std::getenv("JSP_POOL_PROBE");
+        const bool probe = nbuf >= kProbeFrom && (width & 3) == 0 && (height & 3) == 0 && bytes * (size_t)nbuf / 16 / 256 < 0x7FFFFFFFull &&
+                           !(env && std::atoi(env) == 0);
+        if (probe) {
+            struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; };
+            std::vector<Candidate> cands;
+            auto release = [](Candidate& c) { for (void* d : c.allocs) (void)hipFree(d); c.allocs.clear(); };
+            uint32_t** d_table = nullptr;
+            int best = -1;
+            double yardstick = 0;
+            try {
+                JSP_HIP(hipMalloc(reinterpret_cast<void**>(&d_table), sizeof(uint32_t*) * (size_t)nbuf));
+                for (int a = 0; a < kCandidates; ++a) {
+                    Candidate c;
+                    bool ok = true;
+                    if (a % 3 == 1) {                          // all frames in one allocation, back to back
+                        void* d = nullptr;
+                        ok = hipMalloc(&d, bytes * (size_t)nbuf) == hipSuccess;
+                        if (ok) { c.allocs.push_back(d); for (int i = 0; i < nbuf; ++i) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)i * width * height); }
+                    } else if (a % 3 == 0) {                   // two frames per allocation
+                        for (int i = 0; i < nbuf && ok; i += 2) {
+                            void* d = nullptr;
+                            const int k = i + 1 < nbuf ? 2 : 1;
+                            ok = hipMalloc(&d, bytes * k) == hipSuccess;
+                            if (ok) { c.allocs.push_back(d); for (int q = 0; q < k; ++q) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)q * width * height); }
+                        }
+                    } else {                                   // an allocation per frame
+                        for (int i = 0; i < nbuf && ok; ++i) {
+                            void* d = nullptr;
+                            ok = hipMalloc(&d, bytes) == hipSuccess;
+                            if (ok) { c.allocs.push_back(d); c.frames.push_back(static_cast<int32_t*>(d)); }
+                        }
+                    }
+                    if (!ok) {                                 // the memory ran out while candidates were being held: the best so far it is
+                        (void)hipGetLastError();
+                        release(c);
+                        if (best >= 0) break;
+                        throw std::runtime_error("out of device memory for the frame pool");
+                    }
+                    JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
+                    if (a == 1) yardstick = jsp::pool_fill_rate(reinterpret_cast<uint32_t*>(c.allocs[0]), bytes * (size_t)nbuf);
+                    c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
+                    p->tried.push_back(c.rate);
+                    cands.push_back(std::move(c));
+                    if (best < 0 || cands.back().rate > cands[best].rate) best = (int)cands.size() - 1;
+                    if (a >= 1 && cands[best].rate >= 0.97 * yardstick) break;   // as good as it gets
+                    if (a >= 2 && cands[best].rate >= 0.93 * yardstick) break;   // the fast kind, every form tried once
+                }
+            } catch (...) {
+                for (auto& c : cands) release(c);
+                if (d_table) (void)hipFree(d_table);
+                throw;
+            }
+            (void)hipFree(d_table);
+            for (int i = 0; i < (int)cands.size(); ++i) if (i != best) release(cands[i]);
+            p->attempts = (int)cands.size();
+            p->store_rate = cands[best].rate;
+            p->fill_rate = yardstick;
+            p->allocs = cands[best].allocs;
+            p->bufs = cands[best].frames;
+            for (int32_t* f : p->bufs) JSP_HIP(hipMemset(f, 0, bytes));
+            return p.release();
+        }
         for (int i = 0; i < nbuf; ++i) {
             void* d = nullptr;
             JSP_HIP(hipMalloc(&d, bytes));
+            p->allocs.push_back(d);
             p->bufs.push_back(static_cast<int32_t*>(d));
             JSP_HIP(hipMemset(d, 0, bytes));
         }
@@ -243,8 +327,12 @@ int jsp_pool_count(jsp_pool* p) { return p ? (int)p->bufs.size() : 0; }
 void jsp_pool_destroy(jsp_pool* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (auto* b : p->bufs) (void)hipFree(b);
+    for (void* d : p->allocs) (void)hipFree(d);
     delete p;
+}
+double jsp_pool_store_rate(jsp_pool* p, int* attempts) {
+    if (attempts) *attempts = p ? p->attempts : 0;
+    return p ? p->store_rate : 0.0;
 }
 int jsp_download(const int32_t* device_frame, int32_t* host, size_t npixels) {
     return guarded([&] {

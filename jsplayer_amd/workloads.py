@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import sys
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import List, Optional
@@ -145,6 +146,7 @@ class StagedWorkload:
         spec = WORKLOADS[name]
         self.name, self.clips, self.inter = name, clips, spec.get("mode") == "inter"
         self.codecs, self.staged, self.dsts, self.firsts = [], [], [], []
+        self.pools = []
         for clip in clips:
             codec = make_codec(name, clip.palette, device=device, options=options)
             if hip_stream:
@@ -154,19 +156,22 @@ class StagedWorkload:
                 first = torch.empty(W * H, dtype=torch.int32, device=f"cuda:{device}")
                 assert codec.DecompressI(frames[0], first) == 0
                 frames, keys = frames[1:], keys[1:]
-            # Every frame buffer is an allocation of its own, as a player's frame pool hands them out (jsp_pool_create, FramePool.hx).
-            # Where the frames lie in physical memory moves the store-bound kernels by up to a quarter from one session to the next
-            # on the SAME GPU (tools/front_lab.hip, tools/lab/pool_ab.sh): lab knobs below put them in one pool instead.
-            if os.environ.get("JSP_BENCH_FRAME_POOL") or os.environ.get("JSP_BENCH_FRAME_STRIDE") or os.environ.get("JSP_BENCH_FRAMES_PER_POOL"):
-                stride = int(os.environ.get("JSP_BENCH_FRAME_STRIDE", W * H * 4)) // 4      # bytes from frame to frame
-                per_pool = int(os.environ.get("JSP_BENCH_FRAMES_PER_POOL", 0)) or len(frames)
-                dsts = []
-                for lo in range(0, len(frames), per_pool):
-                    k = min(per_pool, len(frames) - lo)
-                    pool = torch.empty((k - 1) * stride + W * H, dtype=torch.int32, device=f"cuda:{device}")
-                    dsts += [pool[i * stride:i * stride + W * H] for i in range(k)]
-            else:
+            # The frames a clip is decoded into come from the product's frame pool (jsp_pool_create / FramePool, the counterpart of the
+            # Manager's buffer pool, Manager.hx:114-118), which PLACES a pool of this size: where the frames lie in physical memory moves
+            # the store-bound kernels by up to a quarter from one set of allocations to the next on the same GPU (tools/front_lab.hip,
+            # tools/lab/pool_ab.sh).  Lab knobs: JSP_BENCH_FRAME_POOL=torch (one torch tensor per frame: what rounds 1-3
+            # timed), =1 (one torch allocation, frames back to back).
+            how = os.environ.get("JSP_BENCH_FRAME_POOL", "probed")
+            if how == "probed":
+                from .codec import FramePool
+                fp = FramePool(W, H, len(frames), device=device)
+                self.pools.append(fp)
+                dsts = list(fp.frames)
+            elif how == "torch":
                 dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{device}") for _ in frames]
+            else:
+                pool = torch.empty(len(frames) * W * H, dtype=torch.int32, device=f"cuda:{device}")
+                dsts = [pool[i * W * H:(i + 1) * W * H] for i in range(len(frames))]
             self.staged.append(codec.stage_batch(frames, dsts, is_key=keys))   # host stage + H2D
             self.codecs.append(codec)
             self.dsts.append(dsts)
@@ -213,3 +218,6 @@ class StagedWorkload:
         for c in self.codecs:
             c.StopAndClean()
         self.staged, self.codecs, self.dsts, self.firsts = [], [], [], []
+        for fp in self.pools:
+            fp.close()
+        self.pools = []

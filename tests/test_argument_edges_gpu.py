@@ -48,3 +48,43 @@ def test_degenerate_but_legal_inputs():
     assert res.data_pnt is None and res.significant_changes is False
     assert s.DecompressI(b"", dev(256)) == DecoderState.error_occured
     assert ScreenPressor(16, 16, 7).DecompressI(b"\x12", dev(256)) in (DecoderState.zero_state, DecoderState.error_occured)
+
+
+@pytest.mark.parametrize("count,size", [(3, (320, 240)), (40, (320, 240)), (33, (322, 242))], ids=["small", "placed", "large-odd-size"])
+def test_frame_pool_buffers_are_usable_whichever_way_they_were_placed(count, size):
+    """jsp_pool_create: a small pool is one allocation per frame; a pool of 32 frames or more whose size the probe's store shape
+    fits is placed by measuring candidate allocations.  Either way every buffer is zeroed, distinct, 16-byte aligned and decodes
+    exactly as a torch tensor does."""
+    import torch
+    from jsplayer_amd import FramePool
+    from jsplayer_amd import streamgen as sg
+    w, h = size
+    pool = FramePool(w, h, count)
+    try:
+        placed = count >= 32 and w % 4 == 0 and h % 4 == 0
+        assert (pool.attempts >= 2 and pool.store_rate > 0) if placed else (pool.attempts == 0 and pool.store_rate == 0)
+        assert pool.attempts <= 9
+        ptrs = [f.data_ptr() for f in pool.frames]
+        assert len(set(ptrs)) == count and all(p % 16 == 0 for p in ptrs)
+        spans = sorted(ptrs)
+        assert all(b - a >= w * h * 4 for a, b in zip(spans, spans[1:]))          # no two buffers overlap
+        assert all(not f.cpu().numpy().any() for f in pool.frames)
+        if w % 4 == 0:
+            frames, keys, _ = sg.msv1_clip(5, w, h, min(count, 6), p_mix=sg.msv1_p_mix(0.5, 10.0), key_every=3)
+            a, b = MSVideo1_16bit(w, h), MSVideo1_16bit(w, h)
+            a.Preinit(36)
+            b.Preinit(36)
+            mine = [dev(w * h) for _ in frames]
+            for i, (fr, key) in enumerate(zip(frames, keys)):
+                if key:
+                    assert a.DecompressI(fr, pool.frames[i]) == b.DecompressI(fr, mine[i])
+                else:
+                    ra, rb = a.DecompressP(fr, pool.frames[i]), b.DecompressP(fr, mine[i])
+                    assert ra.significant_changes == rb.significant_changes
+                    assert (ra.data_pnt is pool.frames[i]) == (rb.data_pnt is mine[i])
+                if a.PreviousFrame() is not None:
+                    assert torch.equal(a.PreviousFrame(), b.PreviousFrame())
+            a.StopAndClean()
+            b.StopAndClean()
+    finally:
+        pool.close()

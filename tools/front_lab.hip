@@ -33,6 +33,18 @@ __global__ __launch_bounds__(256) void front_kernel(uint32_t* const* __restrict_
     }
 }
 
+// translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
+// `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
+__global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (int r = 0; r < rounds; ++r) {
+        i = (i * 2654435761ull + 40503ull * (r + 1)) % npages;
+        acc += buf[i * page_words + (threadIdx.x & 15)];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main(int argc, char** argv) {
     const int F = argc > 1 ? atoi(argv[1]) : 512;
     hipEvent_t e0, e1;
@@ -61,6 +73,48 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     };
+    if (argc > 2) {   // several pools in ONE process, none freed before the last is measured: do they differ?
+        const int K = atoi(argv[2]);
+        uint32_t* sink;
+        CK(hipMalloc(&sink, 64));
+        std::vector<uint32_t*> pools(K);
+        const int clear = argc > 3 ? atoi(argv[3]) : 1;
+        for (int k = 0; k < K; ++k) { CK(hipMalloc(&pools[k], FRAME_BYTES * F)); if (clear) CK(hipMemset(pools[k], 0, FRAME_BYTES * F)); }
+        printf("%d pools of %d frames, %s\n", K, F, clear ? "cleared with hipMemset first" : "not touched before the first launch");
+        for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < K; ++k) {
+                std::vector<uint32_t*> fr(F);
+                for (int i = 0; i < F; ++i) fr[i] = pools[k] + (size_t)i * X * Y;
+                CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * F, hipMemcpyHostToDevice));
+                const int T = 8192, tpf = (NBLK + T - 1) / T;
+                auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * F), dim3(256), 0, 0, d_table, F, T, tpf, 1); };
+                launch();
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                float pr[2];
+                int q = 0;
+                for (size_t page : {(size_t)4096, (size_t)2 << 20}) {
+                    const size_t npages = FRAME_BYTES * F / page;
+                    auto probe = [&] { hipLaunchKernelGGL(page_probe_kernel, dim3(4096), dim3(256), 0, 0, pools[k], npages, page / 4, 64, sink); };
+                    probe();
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0));
+                    probe();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&pr[q++], e0, e1));
+                }
+                printf("pool %d at %p: stores tile-major %7.0f GB/s | 67 M scattered 4-byte reads: one per 4 KB page %7.1f us, one per 2 MB %7.1f us\n", k, (void*)pools[k],
+                       (double)F * FRAME_BYTES * 3 / ms / 1e6, pr[0] * 1000, pr[1] * 1000);
+                fflush(stdout);
+            }
+        return 0;
+    }
     {   // A
         uint32_t* pool;
         CK(hipMalloc(&pool, FRAME_BYTES * F));
