@@ -1,5 +1,5 @@
 #!/bin/bash
-# lab: destination frames as one torch tensor each (torch), back to back in one torch allocation (1), from the product's placed frame pool (probed: default)
+# lab: destination frames as one torch tensor each (torch), back to back in one torch allocation (1), from the product's placed frame pool (probed); torch is the default
 R="${GRAFT_REPO_ROOT:-$(pwd)}"; cd $R
 export JSP_BENCH_CLIPS=1
 for w in ${WORKLOADS:-msvideo1_16_1080p_keyframes_m1 msvideo1_16_1080p_keyframes_solid screenpressor_v4_1080p_iframes}; do
