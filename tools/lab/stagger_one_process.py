@@ -1,6 +1,7 @@
-"""lab: launch-order staggers of the fused kernel compared in ONE process on the SAME destination frames (every process gets its own luck with
-where its frames lie, so runs of bench.py cannot be compared with each other).
-usage: python tools/lab/stagger_one_process.py <workload> <frames: torch|pool> <stagger> [<stagger> ...]   (rounds through the list twice)"""
+"""lab: launch-order variants compared in ONE process on the SAME destination frames (every process gets its own luck with where its frames
+lie, so runs of bench.py cannot be compared with each other).
+usage: python tools/lab/stagger_one_process.py <workload> <frames: torch|pool> <value> [<value> ...]   (rounds through the list twice)
+       the values go into the environment variable named by LAB_VAR (default JSP_MSV1_STAGGER) before each staging"""
 import os
 import sys
 import time
@@ -22,7 +23,7 @@ else:
 spec = wl.WORKLOADS[name]
 for rnd in range(2):
     for st in staggers:
-        os.environ["JSP_MSV1_STAGGER"] = str(st)
+        os.environ[os.environ.get("LAB_VAR", "JSP_MSV1_STAGGER")] = str(st)
         codec = wl.make_codec(name, clip.palette, device=0)
         staged = codec.stage_batch(clip.frames, dsts, is_key=clip.keys)
         for _ in range(3):
@@ -37,6 +38,6 @@ for rnd in range(2):
         dt = (time.perf_counter() - t0) / 20
         info = staged.info()
         moved = min(info["algorithmic_bytes"], info["moved_bytes"]) if "moved_bytes" in info else info["algorithmic_bytes"]
-        print(f"{name} frames {how:5s} stagger {st:4d}: {dt * 1e3:.4f} ms  {moved / dt / 8e12:.4f} of 8 TB/s", flush=True)
+        print(f"{name} frames {how:5s} {os.environ.get('LAB_VAR', 'stagger')} {st:4d}: {dt * 1e3:.4f} ms  {moved / dt / 8e12:.4f} of 8 TB/s", flush=True)
         staged.close()
         codec.StopAndClean()
