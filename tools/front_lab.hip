@@ -18,8 +18,20 @@ constexpr size_t FRAME_BYTES = (size_t)X * Y * 4;
 
 __global__ __launch_bounds__(256) void front_kernel(uint32_t* const* __restrict__ frames, int nframes, int T, int tiles_per_frame, int tile_major) {
     int f, j;
-    if (tile_major) { j = blockIdx.x / nframes; f = blockIdx.x - j * nframes; }
-    else { f = blockIdx.x / tiles_per_frame; j = blockIdx.x - f * tiles_per_frame; }
+    if (tile_major == 1) { j = blockIdx.x / nframes; f = blockIdx.x - j * nframes; }
+    else if (tile_major == 0) { f = blockIdx.x / tiles_per_frame; j = blockIdx.x - f * tiles_per_frame; }
+    else if (tile_major == 2) {                    // staggered: frame f runs (f mod S) rounds late; rounds = tiles_per_frame + S, empty slots leave at once
+        const int S = 64;
+        const int r = blockIdx.x / nframes;
+        f = blockIdx.x - r * nframes;
+        j = r - f % S;
+        if (j < 0 || j >= tiles_per_frame) return;
+    } else {                                       // a pseudo-random permutation of all (frame, tile) pairs
+        const unsigned long long n = (unsigned long long)nframes * tiles_per_frame;
+        const unsigned long long p = ((unsigned long long)blockIdx.x * 2654435761ull + 12345ull) % n;   // (n is not a multiple of the odd multiplier's factors: a bijection when gcd = 1)
+        f = (int)(p % nframes);
+        j = (int)(p / nframes);
+    }
     uint32_t* dst = frames[f];
     const int b0 = j * T;
     for (int r = 0; r < T; r += 256) {
@@ -31,6 +43,12 @@ __global__ __launch_bounds__(256) void front_kernel(uint32_t* const* __restrict_
             for (int y = 0; y < 4; ++y) *(gu32x4*)(p + (size_t)y * X) = u32x4{(uint32_t)blk, 1u, 2u, (uint32_t)y};
         }
     }
+}
+
+// plain fill: one 16-byte store per lane, workgroups in address order
+__global__ __launch_bounds__(256) void fill_kernel(u32x4* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) *(gu32x4*)(dst + i) = u32x4{(uint32_t)i, 1u, 2u, 3u};
 }
 
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
@@ -87,15 +105,34 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < F; ++i) fr[i] = pools[k] + (size_t)i * X * Y;
                 CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * F, hipMemcpyHostToDevice));
                 const int T = 8192, tpf = (NBLK + T - 1) / T;
-                auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * F), dim3(256), 0, 0, d_table, F, T, tpf, 1); };
-                launch();
-                CK(hipDeviceSynchronize());
-                CK(hipEventRecord(e0));
-                for (int i = 0; i < 3; ++i) launch();
-                CK(hipEventRecord(e1));
-                CK(hipEventSynchronize(e1));
-                float ms;
-                CK(hipEventElapsedTime(&ms, e0, e1));
+                float ms = 0, by_order[4] = {0, 0, 0, 0};
+                for (int order : {1, 0, 2, 3}) {
+                    const int grid = order == 2 ? (tpf + 64) * F : tpf * F;
+                    auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(grid), dim3(256), 0, 0, d_table, F, T, tpf, order); };
+                    launch();
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 3; ++i) launch();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&by_order[order], e0, e1));
+                }
+                ms = by_order[1];
+                float fill_ms = 0;
+                {
+                    const size_t n16 = FRAME_BYTES * F / 16;
+                    auto fill = [&] { hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (u32x4*)pools[k], n16); };
+                    fill();
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 3; ++i) fill();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&fill_ms, e0, e1));
+                }
+                printf("pool %d: plain fill %5.0f | ", k, (double)F * FRAME_BYTES * 3 / fill_ms / 1e6);
+                printf("tile-major %5.0f | frame-major %5.0f | staggered %5.0f | scattered %5.0f GB/s\n", (double)F * FRAME_BYTES * 3 / by_order[1] / 1e6,
+                       (double)F * FRAME_BYTES * 3 / by_order[0] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[2] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[3] / 1e6);
                 float pr[2];
                 int q = 0;
                 for (size_t page : {(size_t)4096, (size_t)2 << 20}) {
