@@ -88,3 +88,21 @@ def test_frame_pool_buffers_are_usable_whichever_way_they_were_placed(count, siz
             b.StopAndClean()
     finally:
         pool.close()
+
+
+def test_measure_fill_reports_a_store_rate_and_refuses_bad_arguments():
+    """jsp_measure_fill (what bench.py prints as roofline.measured_ceiling): a plausible rate for a plain fill, the buffer left
+    filled, misaligned / tiny / null arguments refused with a message."""
+    import ctypes as C
+    import torch
+    from jsplayer_amd import _native as N
+    lib = N.lib()
+    buf = torch.zeros(1 << 24, dtype=torch.int32, device="cuda")          # 64 MiB
+    rate = C.c_double(0.0)
+    assert lib.jsp_measure_fill(C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel() * 4), 3, C.byref(rate), None) == 0
+    assert 100.0 < rate.value < 20000.0, rate.value                        # GB/s: an MI355X fills at several TB/s; anything sane passes
+    assert int(buf[4].item()) != 0 or int(buf[5].item()) != 0              # the fill pattern is v, v+1, v+2, v+3 per 16 bytes
+    assert lib.jsp_measure_fill(C.c_void_p(buf.data_ptr() + 4), C.c_size_t(1 << 20), 1, C.byref(rate), None) != 0
+    assert "bad argument" in N.last_error()
+    assert lib.jsp_measure_fill(C.c_void_p(buf.data_ptr()), C.c_size_t(64), 1, C.byref(rate), None) != 0
+    assert lib.jsp_measure_fill(None, C.c_size_t(1 << 20), 1, C.byref(rate), None) != 0
