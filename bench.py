@@ -378,7 +378,7 @@ def main():
                 "clips_per_step": len(clips),
                 "destination_frames": ({"from": "jsp_pool_create (the product's frame pool: one pool per clip, placed by probing candidate allocations, include/jsplayer_amd.h)",
                                         "allocations_tried": [p.attempts for p in work.pools], "probe_GBs": [round(p.store_rate) for p in work.pools]}
-                                       if work.pools else {"from": "one torch tensor per frame" if os.environ.get("JSP_BENCH_FRAME_POOL", "torch") == "torch" else "one torch allocation, frames back to back"}),
+                                       if work.pools else {"from": "one torch tensor per frame" if os.environ.get("JSP_BENCH_FRAME_POOL") == "torch" else "one torch allocation, frames back to back"}),
                 "streams": args.gpus,
                 "sharding": "one independent AVI stream per GPU, no data-path collective",
                 "inputs": ("raw stream bytes resident in HBM (on-GPU parse every step)" if spec.get("parse") == "gpu" else

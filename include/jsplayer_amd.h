@@ -97,7 +97,7 @@ const char* jsp_last_error(void);
 
 /* A pool of 32 frames or more (what batch decoding writes into: tile j of every frame at about the same time) is PLACED: where the
  * frames lie in physical memory, relative to each other, moves that store shape by a quarter (persistently per set of allocations; no
- * query reveals it), so the pool measures up to nine candidates with the shape (a few milliseconds each) — two frames per
+ * query reveals it), so the pool measures up to sixteen candidates with the shape (a few milliseconds each) — two frames per
  * allocation, one allocation for all, one per frame, in turn, the slow ones held until it has chosen — and keeps the first that takes what a plain fill
  * takes, or the best.  JSP_POOL_PROBE=0 in the environment: one allocation per frame, first come — what smaller pools (a player's
  * num_buffers + 1) always get. */

@@ -156,12 +156,13 @@ class StagedWorkload:
                 first = torch.empty(W * H, dtype=torch.int32, device=f"cuda:{device}")
                 assert codec.DecompressI(frames[0], first) == 0
                 frames, keys = frames[1:], keys[1:]
-            # Every frame buffer is a torch tensor of its own (what rounds 1-3 timed).  Where the frames lie in physical memory moves the
-            # store-bound kernels by up to a quarter from one set of allocations to the next on the same GPU (tools/front_lab.hip,
-            # tools/lab/pool_ab.sh).  JSP_BENCH_FRAME_POOL=probed takes them from the product's frame pool instead
-            # (jsp_pool_create / FramePool, which places a pool of this size by measuring candidate allocations: within noise of this
-            # form in six sessions of seven, clearly better than one allocation for all frames); =1: one torch allocation, back to back.
-            how = os.environ.get("JSP_BENCH_FRAME_POOL", "torch")
+            # The frames a clip is decoded into come from the product's frame pool (jsp_pool_create / FramePool, the counterpart of the
+            # Manager's buffer pool, Manager.hx:114-118), which PLACES a pool of this size: where the frames lie in physical memory moves
+            # the store-bound kernels by a quarter from one set of allocations to the next on the same GPU, and the pool measures up to
+            # sixteen candidates with the kernels' store shape and keeps a fast one (in one process, same clips: one torch
+            # tensor per frame 0.63 - 0.80 of 8 TB/s on M1 by session, the pool 0.76 - 0.78 in every one).  Lab knobs:
+            # JSP_BENCH_FRAME_POOL=torch (one torch tensor per frame: what rounds 1-3 timed), =1 (one torch allocation, back to back).
+            how = os.environ.get("JSP_BENCH_FRAME_POOL", "probed")
             if how == "probed":
                 from .codec import FramePool
                 fp = FramePool(W, H, len(frames), device=device)

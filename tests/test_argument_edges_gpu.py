@@ -63,7 +63,7 @@ def test_frame_pool_buffers_are_usable_whichever_way_they_were_placed(count, siz
     try:
         placed = count >= 32 and w % 4 == 0 and h % 4 == 0
         assert (pool.attempts >= 2 and pool.store_rate > 0) if placed else (pool.attempts == 0 and pool.store_rate == 0)
-        assert pool.attempts <= 9
+        assert pool.attempts <= 16
         ptrs = [f.data_ptr() for f in pool.frames]
         assert len(set(ptrs)) == count and all(p % 16 == 0 for p in ptrs)
         spans = sorted(ptrs)
