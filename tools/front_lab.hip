@@ -51,6 +51,21 @@ __global__ __launch_bounds__(256) void fill_kernel(u32x4* __restrict__ dst, size
     if (i < n) *(gu32x4*)(dst + i) = u32x4{(uint32_t)i, 1u, 2u, 3u};
 }
 
+// the ScreenPressor key-frame kernel's store shape: one wave per (frame, band of B rows, 1 KB of a row), D dependent instructions per row
+__global__ __launch_bounds__(64) void band_kernel(uint32_t* __restrict__ pool, int nframes, int B, int bands, int D) {
+    const int f = blockIdx.x % nframes, g = blockIdx.x / nframes;   // frames fastest, as launch_iframe_tiles
+    const int band = g / 8, sx = g - band * 8;
+    const int x = sx * 256 + (int)threadIdx.x * 4;
+    if (x >= X) return;
+    uint32_t* dst = pool + (size_t)f * X * Y;
+    uint32_t a = (uint32_t)(f + g);
+    const int y1 = (band + 1) * B < Y ? (band + 1) * B : Y;
+    for (int y = band * B; y < y1; ++y) {
+        for (int i = 0; i < D; ++i) a = a * 1664525u + 1013904223u;
+        *(gu32x4*)(dst + (size_t)y * X + x) = u32x4{a, a + 1, a + 2, a + 3};
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -130,7 +145,19 @@ int main(int argc, char** argv) {
                     CK(hipEventSynchronize(e1));
                     CK(hipEventElapsedTime(&fill_ms, e0, e1));
                 }
-                printf("pool %d: plain fill %5.0f | ", k, (double)F * FRAME_BYTES * 3 / fill_ms / 1e6);
+                float band_ms = 0;
+                {
+                    const int B = 90, bands = (Y + B - 1) / B;
+                    auto go = [&] { hipLaunchKernelGGL(band_kernel, dim3((unsigned)(F * bands * 8)), dim3(64), 4608, 0, pools[k], F, B, bands, 20); };
+                    go();
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 3; ++i) go();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&band_ms, e0, e1));
+                }
+                printf("pool %d: plain fill %5.0f | band-walking waves %5.0f | ", k, (double)F * FRAME_BYTES * 3 / fill_ms / 1e6, (double)F * FRAME_BYTES * 3 / band_ms / 1e6);
                 printf("tile-major %5.0f | frame-major %5.0f | staggered %5.0f | scattered %5.0f GB/s\n", (double)F * FRAME_BYTES * 3 / by_order[1] / 1e6,
                        (double)F * FRAME_BYTES * 3 / by_order[0] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[2] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[3] / 1e6);
                 float pr[2];
