@@ -114,6 +114,7 @@ double pool_store_rate(uint32_t* const* d_frames, int nframes, int X, int Y, uin
 }
 // GB/s of the plain fill (one 16-byte store per lane, workgroups in address order) over the same memory: the yardstick.
 double pool_fill_rate(uint32_t* slab, size_t nbytes) {
+    if (nbytes > ((size_t)8 << 30)) nbytes = (size_t)8 << 30;          // (a launch has fewer than 2^32 lanes; 8 GiB say as much as 80)
     const size_t n = nbytes / 16;
     hipEvent_t e0, e1;
     JSP_HIP(hipEventCreate(&e0));
@@ -141,7 +142,7 @@ int jsp_measure_fill(int32_t* device, size_t nbytes, int reps, double* gbytes_pe
         if (!device || !gbytes_per_s || nbytes < 4096 || reps < 1 || (reinterpret_cast<uintptr_t>(device) & 15)) throw std::runtime_error("bad argument");
         hipStream_t s = static_cast<hipStream_t>(hip_stream);
         const size_t n = nbytes / 16;
-        if ((n + 255) / 256 > 0x7FFFFFFFull) throw std::runtime_error("buffer too large for one launch");
+        if (n >= (1ull << 32)) throw std::runtime_error("buffer too large for one launch (64 GiB or more)");
         const dim3 grid((unsigned)((n + 255) / 256));
         hipEvent_t e0, e1;
         JSP_HIP(hipEventCreate(&e0));

@@ -245,7 +245,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         // what a plain fill of the same memory takes, or the best of sixteen.  JSP_POOL_PROBE=0: one allocation per frame, first come.
         constexpr int kProbeFrom = 32, kCandidates = 16;
         const char* env = std::getenv("JSP_POOL_PROBE");
-        const bool probe = nbuf >= kProbeFrom && (width & 3) == 0 && (height & 3) == 0 && bytes * (size_t)nbuf / 16 / 256 < 0x7FFFFFFFull &&
+        const bool probe = nbuf >= kProbeFrom && (width & 3) == 0 && (height & 3) == 0 && (size_t)nbuf * (size_t)((width / 4) * (height / 4) + 8191) / 8192 * 256 < (1ull << 32) &&   // (the probe: one launch, fewer than 2^32 lanes)
                            !(env && std::atoi(env) == 0);
         if (probe) {
             struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; };
