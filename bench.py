@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: decoded Mpixels/s at 1920x1080 (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--also a,b | --no-also]
 
 Workload at every N (weak scaling): each rank owns its own independent stream(s) — by default
 BASELINE.json configs[1], "MSVideo1 1920x1080 keyframe-only": 512 distinct frames of block mix M1 (25 % solid /
@@ -17,8 +17,13 @@ printed on a mismatch.  A second leg times the SAME frames end to end — compre
 stage -> H2D -> kernels, one frame per call through the asynchronous entry points — and reports it beside the
 resident-input number ("e2e").
 
+The metric names both codecs, so the default line carries the ScreenPressor configurations as well: `also` = one entry
+per further workload (BASELINE.json configs[2] and [3]: ScreenPressor key frames, ScreenPressor 300-frame clips), each
+timed, digest-verified and priced against the roofline exactly like the headline (same K, W, barriers, HIP events), with
+a bounded CPU baseline and the many-stream end-to-end rate beside it.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline`, `e2e`,
-`verified`.  The oracle (oracle/) is used ONLY in the cpu_baseline leg.
+`verified`, `also`.  The oracle (oracle/) is used ONLY in the cpu_baseline legs.
 """
 from __future__ import annotations
 
@@ -32,6 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs"
+# what the default line carries beside the headline workload (BASELINE.json configs[2], configs[3])
+ALSO_DEFAULT = ("screenpressor_v4_1080p_iframes", "screenpressor_v4_1080p_pclip300")
 
 
 def _oracle_stream(spec, clip, budget_s, max_frames, gate=None):
@@ -62,7 +70,7 @@ def _oracle_stream(spec, clip, budget_s, max_frames, gate=None):
             return done, el
 
 
-def cpu_baseline(spec, clip, budget_s=12.0):
+def cpu_baseline(spec, clip, budget_s=8.0):
     """Oracle (C++ restatement of the Haxe reference, -O2) on the same frames: one thread, then one
     independent stream per host core (the reference's only way to use more cores)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,7 +86,7 @@ def cpu_baseline(spec, clip, budget_s=12.0):
         t0 = time.perf_counter()
         parts = [f.result() for f in futs]
     wall = time.perf_counter() - t0
-    return {
+    out = {
         "all_cores": {"value": round(sum(d for d, _ in parts) * W * H / wall / 1e6, 2), "unit": "Mpixels/s",
                       "cores": ncores, "sample": f"{ncores} independent streams, one thread each, {wall:.1f} s"},
         "value": round(done * W * H / el / 1e6, 2),
@@ -87,7 +95,14 @@ def cpu_baseline(spec, clip, budget_s=12.0):
         "kind": "port",
         "sample": f"{done} frames of the workload's first clip ({len(clip.frames)} distinct 1920x1080 frames, in order), "
                   f"{el:.1f} s, oracle/ C++ restatement -O2 single thread, DecompressI/P only (parse / entropy decode included)",
+        "host_cores_available": os.cpu_count(),
     }
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return out
 
 
 def _spawn_ranks(n: int) -> int:
@@ -105,6 +120,298 @@ def _spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+class Job:
+    """What every leg needs to know about the run: ranks, the stream everything is queued on, the bracket."""
+
+    def __init__(self, args, rank, local_rank, world, distributed, stream):
+        self.args, self.rank, self.local_rank, self.world, self.distributed, self.stream = args, rank, local_rank, world, distributed, stream
+
+    def barrier(self):
+        import torch
+        if self.distributed:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def resident_leg(job: Job, name: str, nfr_override=None, nclips=None):
+    """Workload `name` with its inputs resident in HBM: W untimed steps, EXACTLY K timed steps between barrier +
+    synchronize on both sides, HIP events on the launch stream around the same region, then every frame the timed kernels
+    left in HBM against the oracle's digests.  Returns (result dict, clips); raises SystemExit on a mismatch (any rank)."""
+    import torch
+    import torch.distributed as dist
+    from jsplayer_amd import workloads as wl
+    from jsplayer_amd.sharding import gather_per_rank, reduce_counters
+    args, rank = job.args, job.rank
+    spec = dict(wl.WORKLOADS[name])
+    t_gen = time.perf_counter()
+    clips = wl.build_clips(name, rank, nfr_override)
+    if nclips:   # experiment knob: the first n clips of the workload only (digests still match: clips are independent)
+        clips = clips[:max(1, nclips)]
+    t_gen = time.perf_counter() - t_gen
+
+    t_stage = time.perf_counter()
+    work = wl.StagedWorkload(name, clips, device=job.local_rank, hip_stream=job.stream.cuda_stream)   # host stage + H2D: outside the timed region
+    t_stage = time.perf_counter() - t_stage
+    infos, nfr, step = work.infos, work.frames_per_step, work.step
+    for _ in range(args.warmup):
+        step()
+    job.barrier()                             # all ranks ready, device idle
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(job.stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(job.stream)
+    torch.cuda.synchronize()                  # this rank's K steps are done
+    elapsed = time.perf_counter() - t0
+    job.barrier()                             # closing bracket; the job's time is the max over ranks (below)
+    gpu_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream, whole timed region
+    # ---- what the timed kernels left in HBM against the oracle's digests ------------------------------------
+    verified, bad = False, []
+    if not args.no_verify and nfr_override is None:
+        gold = wl.golden_digests(name, rank)
+        if gold is None:
+            verified = "no golden digests recorded for this workload / rank"
+        else:
+            bad = work.mismatches(gold)
+            verified = not bad
+    # 2 = every frame matches, 1 = not checked, 0 = mismatch; the job's verdict is the minimum over ranks
+    ok = torch.tensor([0 if bad else (2 if verified is True else 1)], dtype=torch.int64, device="cuda")
+    if job.distributed:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 0:
+        if bad:
+            print(f"bench.py rank {rank}: {name}: {len(bad)} frames differ from the oracle's digests (first: clip/frame {bad[0]})", file=sys.stderr)
+        if job.distributed:
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: {name}: decoded frames differ from the oracle: no value printed")
+    # slow paths the timed launches may have taken instead of the kernels named below (results never depend on them; the
+    # number would): the fused kernel's look-back time-out re-runs a batch through the descriptor kernels
+    fallbacks = work.lookback_fallbacks()
+    fb = torch.tensor([fallbacks], dtype=torch.int64, device="cuda")
+    if job.distributed:
+        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+    fallbacks = int(fb[0])
+    if fallbacks:
+        print(f"[bench] {name}: {fallbacks} look-back fall-backs inside the run: the step time includes descriptor-path re-runs", file=sys.stderr)
+
+    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * wl.W * wl.H, elapsed, device="cuda")
+    per_rank = gather_per_rank(nfr * args.steps, device="cuda")
+
+    launches = sum(i["kernel_launches"] for i in infos)
+    step_us = gpu_ms * 1e3 / args.steps                       # GPU time of one step, HIP events
+    alg = sum(i["algorithmic_bytes"] for i in infos)          # SURVEY.md 8(d) formula, per step
+    moved = sum(i["moved_bytes"] for i in infos)              # what the launch plan has to move at the least
+    counted = min(alg, moved)     # reads the plan provably avoids (previous frame kept in registers) are not credited
+    achieved = counted / (step_us * 1e-6) / 1e9               # GB/s
+    kernels = work.kernels()
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_by_workload.json")
+    if os.path.exists(tpath):    # PMC passes kept under profiles/ (tools/pmc_traffic.sh): used only when they describe these kernels
+        try:
+            ent = json.load(open(tpath))["per_step"].get(name)
+            if ent and ent["kernels"] == kernels and ent["frames_per_step"] == nfr:
+                traffic, traffic_source = ent["hbm_bytes"], ent["source"]
+        except Exception:
+            pass
+    write_share = sum(i["pixels"] for i in infos) * 4 / max(counted, 1)      # the frames written, of all bytes counted
+    res = {
+        "workload": name,
+        "spec": spec,
+        "value": round(total_pixels / elapsed / 1e6, 1),
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "verified": True if int(ok[0]) == 2 else (verified if isinstance(verified, str) else False),
+        "lookback_fallbacks": fallbacks,
+        "frames_per_step": nfr,
+        "clips_per_step": len(clips),
+        "destination_frames": ({"from": "jsp_pool_create (the product's frame pool: one pool per clip, placed by probing candidate allocations, include/jsplayer_amd.h)",
+                                "allocations_tried": [p.attempts for p in work.pools], "probe_GBs": [round(p.store_rate) for p in work.pools],
+                                "probe_ms": [round(p.probe_ms, 1) for p in work.pools], "held_while_probing_GB": [round(p.held_bytes / 1e9, 2) for p in work.pools]}
+                               if work.pools else {"from": "one torch tensor per frame" if os.environ.get("JSP_BENCH_FRAME_POOL") == "torch" else "one torch allocation, frames back to back"}),
+        "inputs": ("raw stream bytes resident in HBM (on-GPU parse every step)" if spec.get("parse") == "gpu" else
+                   "host-built descriptor tables (+ MSVideo1 stream bytes) resident in HBM"),
+        "input_bytes_per_step": sum(i["stream_bytes"] if spec.get("parse") == "gpu" else i["descriptor_bytes"] + (i["stream_bytes"] if spec["codec"] == "msv1" else 0) for i in infos),
+        "write_share": write_share,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": kernels,
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes_per_step": alg,
+            "moved_bytes_per_step": moved,
+            "counted": "algorithmic" if counted == alg else "moved (the plan reads the previous frame once per launch, not once per frame)",
+            "step_us": round(step_us, 2),
+            "launches_per_step": launches,
+        },
+        "host_stage": {
+            "host_ms_per_step_batch": round(sum(i["host_stage_ms"] for i in infos), 3),
+            "h2d_ms_per_step_batch": round(sum(i["h2d_ms"] for i in infos), 3),
+            "device_parse_ms_at_staging": round(sum(i["device_parse_ms"] for i in infos), 3),
+            "generate_s": round(t_gen, 1),
+            "stage_s": round(t_stage, 1),
+            "note": "host stage + upload of one step's batches; outside the timed region (inside e2e)",
+        },
+        "total_frames": total_frames,
+        "per_rank_frames": per_rank,
+    }
+    work.close()
+    return res, clips
+
+
+def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, seconds=None):
+    """End to end, from the bytes of an AVI file in pinned host memory: AVI walk -> host stage -> H2D -> kernels, one frame per
+    call through the asynchronous entry points (the host stage of frame n+1 overlaps the uploads and kernels of frame n), by
+    examples/jsp_play — C++ over the C ABI only — for one stream and for one stream per host thread (independent codec
+    instances, the way streams shard).  Every stream of the many-stream run plays a file of its own, and all of
+    them play for the same length of time (`--seconds`: a stream starts its file over until the time is up, then stops where it
+    is), so the rate is one of streams that really run side by side."""
+    import subprocess
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from jsplayer_amd import avi
+    from jsplayer_amd import workloads as wl
+    args, rank, W, H = job.args, job.rank, wl.W, wl.H
+    spec = wl.WORKLOADS[name]
+    inter = spec.get("mode") == "inter"
+    exe = os.path.join(ROOT, "examples", "jsp_play")
+    threads = max(1, min(16, (os.cpu_count() or 1) // max(1, args.gpus)))
+    ncap = min(len(clips[0].frames), 256 if spec["codec"] == "msv1" else (64 if not inter else 150))   # a bounded sample of the first clip
+    # one file per stream: stream 0 plays the first `ncap` frames of this rank's first clip, streams 1.. play clips of their
+    # own (seeds of ranks 1000 + rank*16 + 1 ...: independent inputs), shorter ones — what matters is that no two streams read
+    # the same bytes
+    nshort = max(8, ncap // 8) if not inter else ncap
+    secs = seconds if seconds else (1.5 if spec["codec"] == "msv1" else 3.0)
+
+    def avi_of(frames, keys, palette):
+        return avi.write_avi(W, H, frames, fourcc=b"SCPR" if spec["codec"] == "sp" else b"CRAM",
+                             bpp=24 if spec["codec"] == "sp" else spec["bits"], palette=palette, key_flags=keys)
+    blobs = [avi_of(clips[0].frames[:ncap], clips[0].keys[:ncap], clips[0].palette)]
+    for s_ in range(1, threads):
+        c = wl.build_clips(name, 1000 + rank * 16 + s_, nshort)[0]
+        blobs.append(avi_of(c.frames, c.keys, c.palette))
+    files = []
+    try:
+        for blob in blobs:
+            tf = tempfile.NamedTemporaryFile(suffix=".avi", dir=os.environ.get("TMPDIR", "/tmp"))
+            tf.write(blob)
+            tf.flush()
+            files.append(tf)
+
+        def run(streams):
+            names = ",".join(f.name for f in files[:streams])
+            res = subprocess.run([exe, names, "--pipelined", "--quiet", "--depth", "8", "--streams", str(streams), "--seconds", str(secs),
+                                  "--device", str(job.local_rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if res.returncode != 0:
+                raise SystemExit("examples/jsp_play failed: " + res.stderr.decode()[-500:])
+            return json.loads(res.stdout.decode().strip().splitlines()[-1])
+        one = None
+        if one_stream:
+            job.barrier()                             # all ranks play at the same time
+            one = run(1)
+        job.barrier()
+        many = run(threads)
+    finally:
+        for tf in files:
+            tf.close()
+    batch_api = None
+    if batch_calls and not inter and "inter" not in spec and args.gpus == 1:
+        # the same sample through the batch calls, from HOST bytes, wall clock to frames in HBM: jsp_stage_batch (ScreenPressor:
+        # the host entropy stage takes the batch's groups of pictures side by side; MSVideo1: the bytes are gathered on several
+        # threads — or uploaded from where they are when the caller keeps them in pinned memory — and parsed on the GPU) +
+        # jsp_staged_decode; one stream, but not one frame per call.  First call (buffers allocated) and re-staging.
+        fr = clips[0].frames[:ncap]
+        codec = wl.make_codec(name, clips[0].palette, device=job.local_rank)
+        dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{job.local_rank}") for _ in fr]
+        torch.cuda.synchronize()
+        st, times = None, []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st = codec.stage_batch(fr, dsts, is_key=clips[0].keys[:ncap], reuse=st)
+            st.decode()
+            codec.sync()
+            times.append(time.perf_counter() - t0)
+        batch_api = {"value": round(len(fr) * W * H / min(times[1:]) / 1e6, 1), "unit": "Mpixels/s", "frames": len(fr),
+                     "first_call": round(len(fr) * W * H / times[0] / 1e6, 1),
+                     "host_stage_ms": round(st.info()["host_stage_ms"], 1),
+                     "note": "jsp_stage_batch + jsp_staged_decode of the same frames from host bytes (pageable memory), one stream, wall "
+                             "clock; value = re-staging into the same batch object, first_call = including its buffer allocations"}
+        st.close()
+        codec.StopAndClean()
+        del dsts
+    # job-wide: the ranks played at the same time, each on its own GPU; rates add up
+    tot = torch.tensor([one["mpixels_per_s"] if one else 0.0, many["mpixels_per_s"], one["uploaded_bytes_per_s"] if one else 0.0, many["uploaded_bytes_per_s"]],
+                       dtype=torch.float64, device="cuda")
+    if job.distributed:
+        dist.all_reduce(tot)
+    all_threads = {"value": round(float(tot[1]), 1), "unit": "Mpixels/s", "streams": threads * args.gpus, "frames": many["frames"],
+                   "seconds": round(many["seconds"], 3), "uploaded_bytes_per_s": round(float(tot[3])),
+                   "note": f"{threads} independent streams per GPU (host threads, a codec instance and a FILE OF ITS OWN each: stream 0 the "
+                           f"{ncap}-frame sample, the others {nshort}-frame clips of other seeds), every stream playing its file over and over for the same {secs} s"}
+    if not one:
+        return {"all_threads": all_threads}
+    e2e = {"value": round(float(tot[0]), 1), "unit": "Mpixels/s", "streams": args.gpus, "frames": one["frames"],
+           "ms_per_frame": round(one["seconds"] * 1e3 / one["frames"], 4),
+           "uploaded_bytes_per_s": round(float(tot[2])),
+           "all_threads": all_threads,
+           "includes": "AVI bytes in pinned host memory -> chunk walk + host stage + H2D + kernels, one frame per call "
+                       "(jsp_decompress_*_async / jsp_wait, 8 frames in flight per stream), examples/jsp_play over the C ABI; "
+                       "one untimed pass over the file first (codec and buffers set up), all streams start the timed passes together; "
+                       "uploaded_bytes_per_s = compressed bytes handed to the decoders per second (what crosses the bus)"}
+    if batch_api:
+        e2e["batch_api"] = batch_api
+    return e2e
+
+
+def measured_ceilings(job: Job):
+    """What THIS box's memory takes right now, measured in this run: nothing but 16-byte stores, one per lane, workgroups in
+    address order (the friendliest shape found, profiles/r03_sp_store_lab.txt) over 2 GiB, HIP events on the bench's stream —
+    and the rate on file (tools/hbm_ceiling.hip, profiles/hbm_ceiling.json).  The boxes of the pool differ by up to a fifth
+    here, so the fraction of this number travels better than the fraction of 8 TB/s."""
+    import torch
+    live, recorded = None, None
+    try:
+        import ctypes as C
+        from jsplayer_amd import _native as N
+        scratch = torch.empty(1 << 29, dtype=torch.int32, device=f"cuda:{job.local_rank}")
+        rate = C.c_double(0.0)
+        if N.lib().jsp_measure_fill(C.c_void_p(scratch.data_ptr()), C.c_size_t(scratch.numel() * 4), 10, C.byref(rate), C.c_void_p(job.stream.cuda_stream)) == 0:
+            live = {"value": round(rate.value, 1), "unit": "GB/s", "kind": "fill", "shape": "16-byte stores, one per lane, 256-lane workgroups in address order, 2 GiB",
+                    "source": "measured in this run (jsp_measure_fill: 10 launches, HIP events, best of 3)"}
+        del scratch
+    except Exception as e:   # (the number is a courtesy: the bench line does not depend on it)
+        print(f"[bench] live fill ceiling not measured: {e}", file=sys.stderr)
+    cpath = os.path.join(ROOT, "profiles", "hbm_ceiling.json")
+    if os.path.exists(cpath):
+        try:
+            recorded = json.load(open(cpath))
+        except Exception:
+            recorded = None
+    return live, recorded
+
+
+def _with_ceilings(roofline, write_share, live, recorded):
+    """measured_ceiling / frac_of_measured / recorded_ceiling for one workload's roofline object."""
+    rec = None
+    if recorded:
+        try:
+            kind = "fill" if write_share >= 0.8 else "copy"
+            rec = {"value": recorded[kind + "_GBs"], "unit": "GB/s", "kind": kind, "shape": recorded[kind + "_shape"], "source": recorded["source"]}
+        except Exception:
+            rec = None
+    ceiling = live or rec
+    out = dict(roofline)
+    out["measured_ceiling"] = ceiling
+    out["frac_of_measured"] = round(roofline["achieved"] / ceiling["value"], 4) if ceiling else None
+    out["recorded_ceiling"] = rec
+    return out
+
+
 def main():
     from jsplayer_amd import workloads as wl
     ap = argparse.ArgumentParser()
@@ -112,6 +419,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=wl.DEFAULT, choices=sorted(wl.WORKLOADS))
+    ap.add_argument("--also", default=None, help="comma-separated further workloads for the `also` block (default: the ScreenPressor "
+                                                  "configurations, when --workload is the default one)")
+    ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="experiments only: the JSON line then says verified: false")
@@ -120,8 +430,12 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_spawn_ranks(args.gpus))
+    also = [] if args.no_also else ([w for w in args.also.split(",") if w] if args.also is not None else
+                                    (list(ALSO_DEFAULT) if args.workload == wl.DEFAULT else []))
+    for w in also:
+        if w not in wl.WORKLOADS:
+            raise SystemExit(f"--also: no workload named {w}")
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -139,15 +453,18 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
             dist.barrier()
-        spec = wl.WORKLOADS[args.workload]
-        nfr = (spec["frames"] - (1 if spec.get("mode") == "inter" else 0)) * spec.get("clips", 1)
-        tf, tp, _ = reduce_counters(nfr * args.steps, nfr * args.steps * wl.W * wl.H, 0.0)
-        per_rank = gather_per_rank(nfr * args.steps)
+
+        def counters(name):
+            spec = wl.WORKLOADS[name]
+            nfr = (spec["frames"] - (1 if spec.get("mode") == "inter" else 0)) * spec.get("clips", 1)
+            tf, tp, _ = reduce_counters(nfr * args.steps, nfr * args.steps * wl.W * wl.H, 0.0)
+            return {"workload": name, "total_frames": tf, "total_pixels": tp, "per_rank_frames": gather_per_rank(nfr * args.steps)}
+        head = counters(args.workload)
+        rest = [counters(w) for w in also]
         if rank == 0:
-            print(json.dumps({"metric": "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs", "value": None,
-                              "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                              "config": {"workload": args.workload, "streams": args.gpus}, "total_frames": tf, "total_pixels": tp,
-                              "per_rank_frames": per_rank}), flush=True)
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                              "dry_run": True, "config": {"workload": args.workload, "streams": args.gpus}, "total_frames": head["total_frames"],
+                              "total_pixels": head["total_pixels"], "per_rank_frames": head["per_rank_frames"], "also": rest}), flush=True)
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -159,274 +476,98 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    name = args.workload
-    spec = dict(wl.WORKLOADS[name])
-    W, H = wl.W, wl.H
-    nfr_override = int(os.environ["JSP_BENCH_FRAMES"]) if os.environ.get("JSP_BENCH_FRAMES") else None   # experiment knob
-    t_gen = time.perf_counter()
-    clips = wl.build_clips(name, rank, nfr_override)
-    if os.environ.get("JSP_BENCH_CLIPS"):   # experiment knob: the first n clips of the workload only (digests still match: clips are independent)
-        clips = clips[:max(1, int(os.environ["JSP_BENCH_CLIPS"]))]
-    t_gen = time.perf_counter() - t_gen
-    inter = spec.get("mode") == "inter"
-
     # a dedicated (non-null) stream: kernels and the timing events are queued on the same one
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    work = wl.StagedWorkload(name, clips, device=local_rank, hip_stream=stream.cuda_stream)   # host stage + H2D: outside the timed region
-    infos, nfr, step = work.infos, work.frames_per_step, work.step
+    job = Job(args, rank, local_rank, world, distributed, stream)
+    t_all = time.perf_counter()
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    name = args.workload
+    nfr_override = int(os.environ["JSP_BENCH_FRAMES"]) if os.environ.get("JSP_BENCH_FRAMES") else None   # experiment knob
+    nclips = int(os.environ["JSP_BENCH_CLIPS"]) if os.environ.get("JSP_BENCH_CLIPS") else None          # experiment knob
+    head, clips = resident_leg(job, name, nfr_override, nclips)
+    spec = head["spec"]
+    e2e = None if args.no_e2e else e2e_leg(job, name, clips)
+    live, recorded = measured_ceilings(job) if rank == 0 else (None, None)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()                                 # all ranks ready, device idle
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()                  # this rank's K steps are done
-    elapsed = time.perf_counter() - t0
-    barrier()                                 # closing bracket; the job's time is the max over ranks (below)
-    gpu_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream, whole timed region
-    # ---- what the timed kernels left in HBM against the oracle's digests ------------------------------------
-    verified, bad = False, []
-    if not args.no_verify and nfr_override is None:
-        gold = wl.golden_digests(name, rank)
-        if gold is None:
-            verified = "no golden digests recorded for this workload / rank"
-        else:
-            bad = work.mismatches(gold)
-            verified = not bad
-    # 2 = every frame matches, 1 = not checked, 0 = mismatch; the job's verdict is the minimum over ranks
-    ok = torch.tensor([0 if bad else (2 if verified is True else 1)], dtype=torch.int64, device="cuda")
-    if distributed:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok[0]) == 0:
-        if bad:
-            print(f"bench.py rank {rank}: {len(bad)} frames differ from the oracle's digests (first: clip/frame {bad[0]})", file=sys.stderr)
-        if distributed:
-            dist.destroy_process_group()
-        raise SystemExit("bench.py: decoded frames differ from the oracle: no value printed")
-
-    # ---- end to end, from the bytes of an AVI file in pinned host memory: AVI walk -> host stage -> H2D -> kernels, one
-    #      frame per call through the asynchronous entry points (the host stage of frame n+1 overlaps the uploads and
-    #      kernels of frame n), by examples/jsp_play — C++ over the C ABI only — for one stream and for one stream per host
-    #      thread (independent codec instances, the way streams shard) ------------------------------------
-    e2e = None
-    if not args.no_e2e:
-        import subprocess
-        import tempfile
-        from jsplayer_amd import avi
-        exe = os.path.join(ROOT, "examples", "jsp_play")
-        threads = max(1, min(16, (os.cpu_count() or 1) // max(1, args.gpus)))
-        ncap = min(len(clips[0].frames), 256 if spec["codec"] == "msv1" else (64 if not inter else 150))   # a bounded sample of the first clip
-        # one file per stream: stream 0 plays the first `ncap` frames of this rank's first clip, streams 1.. play clips of their
-        # own (seeds of ranks rank*16 + 1 ...: independent inputs), shorter ones — what matters is that no two streams read the
-        # same bytes
-        nshort = max(8, ncap // 8) if not inter else ncap
-        def avi_of(frames, keys, palette):
-            return avi.write_avi(W, H, frames, fourcc=b"SCPR" if spec["codec"] == "sp" else b"CRAM",
-                                 bpp=24 if spec["codec"] == "sp" else spec["bits"], palette=palette, key_flags=keys)
-        blobs = [avi_of(clips[0].frames[:ncap], clips[0].keys[:ncap], clips[0].palette)]
-        for s_ in range(1, threads):
-            c = wl.build_clips(name, 1000 + rank * 16 + s_, nshort)[0]
-            blobs.append(avi_of(c.frames, c.keys, c.palette))
-        files = []
-        try:
-            for blob in blobs:
-                tf = tempfile.NamedTemporaryFile(suffix=".avi", dir=os.environ.get("TMPDIR", "/tmp"))
-                tf.write(blob)
-                tf.flush()
-                files.append(tf)
-
-            def run(streams, repeat):
-                names = ",".join(f.name for f in files[:streams])
-                res = subprocess.run([exe, names, "--pipelined", "--quiet", "--depth", "8", "--streams", str(streams), "--repeat", str(repeat),
-                                      "--device", str(local_rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-                if res.returncode != 0:
-                    raise SystemExit("examples/jsp_play failed: " + res.stderr.decode()[-500:])
-                return json.loads(res.stdout.decode().strip().splitlines()[-1])
-            rep = 8 if spec["codec"] == "msv1" else 1
-            barrier()                                 # all ranks play at the same time
-            one = run(1, rep)
-            barrier()
-            many = run(threads, rep * (ncap // nshort if not inter else 1))
-        finally:
-            for tf in files:
-                tf.close()
-        batch_api = None
-        if not inter and "inter" not in spec and args.gpus == 1:
-            # the same sample through the batch calls, from HOST bytes, wall clock to frames in HBM: jsp_stage_batch (ScreenPressor:
-            # the host entropy stage takes the batch's groups of pictures side by side; MSVideo1: the bytes are gathered on several
-            # threads — or uploaded from where they are when the caller keeps them in pinned memory — and parsed on the GPU) +
-            # jsp_staged_decode; one stream, but not one frame per call.  First call (buffers allocated) and re-staging.
-            fr = clips[0].frames[:ncap]
-            codec = wl.make_codec(args.workload, clips[0].palette, device=local_rank)
-            dsts = [torch.empty(W * H, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in fr]
-            torch.cuda.synchronize()
-            st, times = None, []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                st = codec.stage_batch(fr, dsts, is_key=clips[0].keys[:ncap], reuse=st)
-                st.decode()
-                codec.sync()
-                times.append(time.perf_counter() - t0)
-            batch_api = {"value": round(len(fr) * W * H / min(times[1:]) / 1e6, 1), "unit": "Mpixels/s", "frames": len(fr),
-                         "first_call": round(len(fr) * W * H / times[0] / 1e6, 1),
-                         "host_stage_ms": round(st.info()["host_stage_ms"], 1),
-                         "note": "jsp_stage_batch + jsp_staged_decode of the same frames from host bytes (pageable memory), one stream, wall "
-                                 "clock; value = re-staging into the same batch object, first_call = including its buffer allocations"}
-            st.close()
-            del dsts
-        # job-wide: the ranks played at the same time, each on its own GPU; rates add up
-        tot = torch.tensor([one["mpixels_per_s"], many["mpixels_per_s"], one["uploaded_bytes_per_s"], many["uploaded_bytes_per_s"]],
-                           dtype=torch.float64, device="cuda")
-        if distributed:
-            dist.all_reduce(tot)
-        e2e = {"value": round(float(tot[0]), 1), "unit": "Mpixels/s", "streams": args.gpus, "frames": one["frames"],
-               "ms_per_frame": round(one["seconds"] * 1e3 / one["frames"], 4),
-               "uploaded_bytes_per_s": round(float(tot[2])),
-               "all_threads": {"value": round(float(tot[1]), 1), "unit": "Mpixels/s", "streams": threads * args.gpus, "frames": many["frames"],
-                               "uploaded_bytes_per_s": round(float(tot[3])),
-                               "note": f"{threads} independent streams per GPU (host threads, a codec instance and a FILE OF ITS OWN each: "
-                                       f"stream 0 the {ncap}-frame sample, the others {nshort}-frame clips of other seeds)"},
-               "includes": "AVI bytes in pinned host memory -> chunk walk + host stage + H2D + kernels, one frame per call "
-                           "(jsp_decompress_*_async / jsp_wait, 8 frames in flight per stream), examples/jsp_play over the C ABI; "
-                           "one untimed pass over the file first (codec and buffers set up), all streams start the timed passes together; "
-                           "uploaded_bytes_per_s = compressed bytes handed to the decoders per second (what crosses the bus)"}
-        if batch_api:
-            e2e["batch_api"] = batch_api
-
-    # trivial counter reduce over RCCL (north_star): frames and pixels decoded by the whole job,
-    # time = max over ranks
-    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * W * H, elapsed, device="cuda")
-    per_rank = gather_per_rank(nfr * args.steps, device="cuda")
-
+    out = None
     if rank == 0:
-        launches = sum(i["kernel_launches"] for i in infos)
-        step_us = gpu_ms * 1e3 / args.steps                      # GPU time of one step, HIP events
-        alg = sum(i["algorithmic_bytes"] for i in infos)          # SURVEY.md 8(d) formula, per step
-        moved = sum(i["moved_bytes"] for i in infos)              # what the launch plan has to move at the least
-        counted = min(alg, moved)     # reads the plan provably avoids (previous frame kept in registers) are not credited
-        achieved = counted / (step_us * 1e-6) / 1e9               # GB/s
-        kernels = work.kernels()
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_by_workload.json")
-        if os.path.exists(tpath):    # PMC passes kept under profiles/ (tools/pmc_traffic.sh): used only when they describe these kernels
-            try:
-                ent = json.load(open(tpath))["per_step"].get(name)
-                if ent and ent["kernels"] == kernels and ent["frames_per_step"] == nfr:
-                    traffic, traffic_source = ent["hbm_bytes"], ent["source"]
-            except Exception:
-                pass
-        # the measured ceiling of this box's HBM for streaming stores / copies (tools/hbm_ceiling.hip, kept under profiles/):
-        # SURVEY.md 8(d) asks for the fraction of that beside the fraction of the 8 TB/s on the data sheet
-        ceiling = None
-        cpath = os.path.join(ROOT, "profiles", "hbm_ceiling.json")
-        if os.path.exists(cpath):
-            try:
-                cj = json.load(open(cpath))
-                write_share = sum(i["pixels"] for i in infos) * 4 / max(counted, 1)      # the frames written, of all bytes counted
-                kind = "fill" if write_share >= 0.8 else "copy"
-                ceiling = {"value": cj[kind + "_GBs"], "unit": "GB/s", "kind": kind, "shape": cj[kind + "_shape"], "source": cj["source"]}
-            except Exception:
-                ceiling = None
-        # ... and what THIS box's memory takes right now, measured in this run: nothing but 16-byte stores, one per lane, workgroups
-        # in address order (the friendliest shape found, profiles/r03_sp_store_lab.txt) over 2 GiB, HIP events on the bench's stream.
-        # The boxes of the pool differ by up to a fifth here (profiles/r03_fused_notes.txt: the memory phases of the kernel are
-        # what moves, the arithmetic phases do not), so the fraction of this number travels better than the fraction of 8 TB/s.
-        live = None
-        try:
-            import ctypes as C
-            from jsplayer_amd import _native as N
-            scratch = torch.empty(1 << 29, dtype=torch.int32, device=f"cuda:{local_rank}")
-            rate = C.c_double(0.0)
-            if N.lib().jsp_measure_fill(C.c_void_p(scratch.data_ptr()), C.c_size_t(scratch.numel() * 4), 10, C.byref(rate), C.c_void_p(stream.cuda_stream)) == 0:
-                live = {"value": round(rate.value, 1), "unit": "GB/s", "kind": "fill", "shape": "16-byte stores, one per lane, 256-lane workgroups in address order, 2 GiB",
-                        "source": "measured in this run (jsp_measure_fill: 10 launches, HIP events, best of 3)"}
-            del scratch
-        except Exception as e:   # (the number is a courtesy: the bench line does not depend on it)
-            print(f"[bench] live fill ceiling not measured: {e}", file=sys.stderr)
-        recorded = ceiling
-        if live:
-            ceiling = live
         out = {
-            "metric": "decoded Mpixels/sec at 1920x1080 (MSVideo1 + ScreenPressor), 1/2/4/8 GPUs",
-            "value": round(total_pixels / elapsed / 1e6, 1),
+            "metric": METRIC,
+            "value": head["value"],
             "unit": "Mpixels/s",
             "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "verified": True if int(ok[0]) == 2 else (verified if isinstance(verified, str) else False),
+            "verified": head["verified"],
+            "lookback_fallbacks": head["lookback_fallbacks"],
             "config": {
                 "workload": name,
                 "codec": f"ScreenPressor v{spec['version']}" if spec["codec"] == "sp" else f"MSVideo1_{spec['bits']}bit",
-                "frame": f"{W}x{H}",
-                "frames_per_step": nfr,
-                "clips_per_step": len(clips),
-                "destination_frames": ({"from": "jsp_pool_create (the product's frame pool: one pool per clip, placed by probing candidate allocations, include/jsplayer_amd.h)",
-                                        "allocations_tried": [p.attempts for p in work.pools], "probe_GBs": [round(p.store_rate) for p in work.pools]}
-                                       if work.pools else {"from": "one torch tensor per frame" if os.environ.get("JSP_BENCH_FRAME_POOL") == "torch" else "one torch allocation, frames back to back"}),
+                "frame": f"{wl.W}x{wl.H}",
+                "frames_per_step": head["frames_per_step"],
+                "clips_per_step": head["clips_per_step"],
+                "destination_frames": head["destination_frames"],
                 "streams": args.gpus,
                 "sharding": "one independent AVI stream per GPU, no data-path collective",
-                "inputs": ("raw stream bytes resident in HBM (on-GPU parse every step)" if spec.get("parse") == "gpu" else
-                           "host-built descriptor tables (+ MSVideo1 stream bytes) resident in HBM"),
-                "input_bytes_per_step": sum(i["stream_bytes"] if spec.get("parse") == "gpu" else i["descriptor_bytes"] + (i["stream_bytes"] if spec["codec"] == "msv1" else 0) for i in infos),
+                "inputs": head["inputs"],
+                "input_bytes_per_step": head["input_bytes_per_step"],
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernels,
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "measured_ceiling": ceiling,
-                "frac_of_measured": round(achieved / ceiling["value"], 4) if ceiling else None,
-                "recorded_ceiling": recorded,
-                "traffic": traffic,
-                "traffic_source": traffic_source,
-                "algorithmic_bytes_per_step": alg,
-                "moved_bytes_per_step": moved,
-                "counted": "algorithmic" if counted == alg else "moved (the plan reads the previous frame once per launch, not once per frame)",
-                "step_us": round(step_us, 2),
-                "launches_per_step": launches,
-            },
-            "host_stage": {
-                "host_ms_per_step_batch": round(sum(i["host_stage_ms"] for i in infos), 3),
-                "h2d_ms_per_step_batch": round(sum(i["h2d_ms"] for i in infos), 3),
-                "device_parse_ms_at_staging": round(sum(i["device_parse_ms"] for i in infos), 3),
-                "generate_s": round(t_gen, 1),
-                "note": "host stage + upload of one step's batches; outside the timed region (inside e2e)",
-            },
+            "roofline": _with_ceilings(head["roofline"], head["write_share"], live, recorded),
+            "host_stage": head["host_stage"],
             "e2e": e2e,
-            "total_frames": total_frames,
-            "per_rank_frames": per_rank,
+            "total_frames": head["total_frames"],
+            "per_rank_frames": head["per_rank_frames"],
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, clips[0])
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
             if e2e:
                 out["e2e"]["vs_cpu_one_thread"] = round(e2e["value"] / out["cpu_baseline"]["value"], 2)
                 out["e2e"]["vs_cpu_all_cores"] = round(e2e["value"] / out["cpu_baseline"]["all_cores"]["value"], 2)
-            try:
-                with open("/proc/cpuinfo") as f:
-                    out["cpu_baseline"]["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
-            except Exception:
-                pass
+                out["e2e"]["all_threads"]["vs_cpu_all_cores"] = round(e2e["all_threads"]["value"] / out["cpu_baseline"]["all_cores"]["value"], 2)
+    del clips
+
+    # ---- the other configurations the metric names, each to the same bar (same K and W, same bracket, digests, roofline) ----
+    entries = []
+    for w in also:
+        leg, wclips = resident_leg(job, w)
+        wspec = leg["spec"]
+        many = None if args.no_e2e else e2e_leg(job, w, wclips, one_stream=False, batch_calls=False)
+        if rank == 0:
+            ent = {
+                "workload": w,
+                "codec": f"ScreenPressor v{wspec['version']}" if wspec["codec"] == "sp" else f"MSVideo1_{wspec['bits']}bit",
+                "value": leg["value"], "unit": "Mpixels/s", "ms_per_step": leg["ms_per_step"], "verified": leg["verified"],
+                "frames_per_step": leg["frames_per_step"], "clips_per_step": leg["clips_per_step"],
+                "inputs": leg["inputs"], "input_bytes_per_step": leg["input_bytes_per_step"],
+                "destination_frames": {k: v for k, v in leg["destination_frames"].items() if k != "from"},
+                "roofline": _with_ceilings(leg["roofline"], leg["write_share"], live, recorded),
+                "host_stage": {k: v for k, v in leg["host_stage"].items() if k != "note"},
+                "total_frames": leg["total_frames"], "per_rank_frames": leg["per_rank_frames"],
+            }
+            ent["roofline"].pop("recorded_ceiling", None)
+            ent["roofline"]["measured_ceiling"] = ent["roofline"]["measured_ceiling"]["value"] if ent["roofline"]["measured_ceiling"] else None
+            if many:
+                ent["e2e"] = many
+            if args.gpus == 1 and not args.no_cpu_baseline:
+                base = cpu_baseline(wspec, wclips[0], budget_s=4.0)
+                ent["cpu_baseline"] = {"value": base["value"], "unit": "Mpixels/s", "cores": 1, "kind": "port", "sample": base["sample"],
+                                       "all_cores": base["all_cores"]}
+                if many:
+                    ent["e2e"]["all_threads"]["vs_cpu_all_cores"] = round(many["all_threads"]["value"] / base["all_cores"]["value"], 2)
+            entries.append(ent)
+        del wclips
+    if rank == 0:
+        if also:
+            out["also"] = entries
+        out["bench_wall_s"] = round(time.perf_counter() - t_all, 1)
         print(json.dumps(out), flush=True)
-    work.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -5,9 +5,10 @@
 //   jsp_play clip.avi --pipelined [--depth D]
 //                                the same lines, decoded through jsp_decompress_*_async / jsp_wait with D frames in
 //                                flight: the host stage of frame n+1 overlaps the uploads and kernels of frame n
-//   jsp_play clip.avi --pipelined --quiet [--streams T] [--repeat R] [--depth D]
+//   jsp_play clip.avi --pipelined --quiet [--streams T] [--repeat R | --seconds S] [--depth D]
 //                                end-to-end rate: T independent streams (threads, a codec instance each) play the clip R
-//                                times from the file's bytes in pinned memory; prints one JSON line
+//                                times (or over and over for S seconds, all streams for the same interval) from the file's
+//                                bytes in pinned memory; prints one JSON line
 //
 // It restates, in this project's own words, only what touches the codec:
 //   * the container facts that select and feed it (AVIParser.hx:42-88,142-171; ParserUtils.hx:24-27):
@@ -132,8 +133,10 @@ bool frame_is_key(const Clip& c, jsp_codec* dec, size_t i) {
 // stream waits at `gate` and the timed passes begin together; *t0 / *t1 bracket this stream's timed passes.
 struct Gate { std::atomic<int> waiting{0}; int parties = 1; };
 using Clock = std::chrono::steady_clock;
+// `seconds` > 0: the timed passes start the file over until that much time has passed since the gate opened and stop where they are (frames
+// in flight are collected) — streams with files of different lengths then all run for the same interval.
 long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int warmup = 0, Gate* gate = nullptr, Clock::time_point* t0 = nullptr,
-                    Clock::time_point* t1 = nullptr, int device = 0) {
+                    Clock::time_point* t1 = nullptr, int device = 0, double seconds = 0) {
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
                                       (int)clip.palette.size(), device);
     if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return -1; }
@@ -186,14 +189,20 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
             crc = crc32(reinterpret_cast<const uint8_t*>(host.data()), npx * 4);
         std::printf("%zu %s %d %d %08x\n", f.index, f.key ? "key" : "inter", shown, signif, crc);
     };
-    for (int rep = -warmup; rep < repeat && !failed; ++rep) {
+    Clock::time_point deadline{};
+    bool timed_out = false;
+    if (seconds > 0) repeat = 1 << 30;
+    for (int rep = -warmup; rep < repeat && !failed && !timed_out; ++rep) {
         if (rep == 0) {
             if (gate) { gate->waiting.fetch_add(1); while (gate->waiting.load() < gate->parties) std::this_thread::yield(); }
-            if (t0) *t0 = Clock::now();
+            const Clock::time_point now = Clock::now();
+            if (t0) *t0 = now;
+            deadline = now + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
             done = 0;
         }
         bool last_was_key = false;
         for (size_t i = 0; i < clip.frames.size(); ++i) {
+            if (seconds > 0 && rep >= 0 && Clock::now() >= deadline) { timed_out = true; break; }
             if ((int)flying.size() == depth) collect();
             const uint8_t* src = clip.bytes.data() + clip.frames[i].first;
             const size_t len = clip.frames[i].second;
@@ -316,6 +325,7 @@ int main(int argc, char** argv) {
     const Clip& clip = clips[0];
     bool pipelined = false, quiet = false;
     int depth = 4, streams = 1, repeat = 1, warmup = 1, batch = 0, device = 0;
+    double seconds = 0;
     for (int a = 2; a < argc; ++a) {
         const std::string o = argv[a];
         if (o == "--pipelined") pipelined = true;
@@ -323,6 +333,7 @@ int main(int argc, char** argv) {
         else if (o == "--depth" && a + 1 < argc) depth = std::atoi(argv[++a]);
         else if (o == "--streams" && a + 1 < argc) streams = std::atoi(argv[++a]);
         else if (o == "--repeat" && a + 1 < argc) repeat = std::atoi(argv[++a]);
+        else if (o == "--seconds" && a + 1 < argc) seconds = std::atof(argv[++a]);
         else if (o == "--warmup" && a + 1 < argc) warmup = std::atoi(argv[++a]);
         else if (o == "--batch" && a + 1 < argc) batch = std::atoi(argv[++a]);
         else if (o == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
@@ -348,7 +359,7 @@ int main(int argc, char** argv) {
         Gate gate;
         gate.parties = streams;
         for (int s = 0; s < streams; ++s)
-            pool.emplace_back([&, s] { done[s] = play_pipelined(clips[(size_t)s % clips.size()], depth, repeat, true, warmup, &gate, &begin[s], &end[s], device); });
+            pool.emplace_back([&, s] { done[s] = play_pipelined(clips[(size_t)s % clips.size()], depth, repeat, true, warmup, &gate, &begin[s], &end[s], device, seconds); });
         for (auto& t : pool) t.join();
         Clock::time_point first = begin[0], last = end[0];
         for (int s = 1; s < streams; ++s) { if (begin[s] < first) first = begin[s]; if (end[s] > last) last = end[s]; }

@@ -100,11 +100,15 @@ const char* jsp_last_error(void);
  * query reveals it), so the pool measures up to sixteen candidates with the shape (a few milliseconds each) — two frames per
  * allocation, one allocation for all, one per frame, in turn, the slow ones held until it has chosen — and keeps the first that takes what a plain fill
  * takes, or the best.  JSP_POOL_PROBE=0 in the environment: one allocation per frame, first come — what smaller pools (a player's
- * num_buffers + 1) always get. */
+ * num_buffers + 1) always get.  The probe's appetite is bounded (jsp_pool_probe_info). */
 jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf);
 int32_t* jsp_pool_buffer(jsp_pool* p, int i); /* device pointer, width*height ints, zeroed */
 /* GB/s the chosen allocation took from the probe (0: a pool that is not probed); *attempts = allocations tried. */
 double jsp_pool_store_rate(jsp_pool* p, int* attempts);
+/* What placing the pool cost: wall time of the probe, the most device memory it held at one time (rejected candidates are kept until it
+ * has chosen) and what it was allowed to hold — a quarter of the device memory free when it began, JSP_POOL_PROBE_HOLD_GB (GB) if lower,
+ * never more than JSP_POOL_PROBE_MAX candidates (default 16).  All 0 for a pool that is not probed.  Returns 0, -1 for a null pool. */
+int jsp_pool_probe_info(jsp_pool* p, double* probe_ms, uint64_t* held_peak_bytes, uint64_t* hold_limit_bytes);
 int jsp_pool_count(jsp_pool* p);
 void jsp_pool_destroy(jsp_pool* p);
 /* Copy one frame between a device frame buffer and host memory (parity checks, display). */
@@ -151,7 +155,9 @@ int jsp_sync(jsp_codec* c);
  *                        alone could not settle the stream — short streams, end markers, skip codes without a previous
  *                        frame — or the frame's tiles did not report in time);
  *   "lookback_fallbacks" staged MSVideo1 batches re-run through the descriptor kernels after a tile gave up waiting for
- *                        the tiles before it.
+ *                        the tiles before it;
+ *   "sp_groups_held", "sp_spare_decoders"  (ScreenPressor) groups of pictures the asynchronous path keeps a record of, and
+ *                        host decoders on its shelf: both stay bounded however long a stream runs without jsp_sync.
  * Unknown names and null arguments answer -1.  Results never depend on either path having been taken. */
 long long jsp_counter(jsp_codec* c, const char* name);
 
@@ -161,7 +167,11 @@ long long jsp_counter(jsp_codec* c, const char* name);
  * at once with a ticket; jsp_wait(ticket) blocks until that frame is complete and hands back exactly what the
  * synchronous call would have returned (DecoderState, *data_pnt, *significant_changes).  So the host stage of frame
  * n+1 (entropy decode, parse pre-scan, copy into pinned memory) overlaps the uploads and kernels of frame n.
- *   - device frame buffers only; frames complete in submission order; tickets must be waited for in that order;
+ *   - device frame buffers only; tickets must be waited for in submission order, and a frame is complete when its ticket has been
+ *     waited for.  The GPU work of DIFFERENT groups of pictures (ScreenPressor with worker threads: a coded key frame opens a
+ *     group) is queued in the order their host stages finish, not in submission order — so the buffer a frame in flight is decoded
+ *     AGAINST (the previous frame at its submission) must not be handed out as `dst` of a later frame until the frame reading it
+ *     has been waited for, just like its own `dst` (examples/jsp_play and jsplayer_amd/player.py keep both out of circulation);
  *   - at most "async_depth" frames (jsp_set_option, default 4, 1..16) may be in flight: a further submission fails;
  *   - `src` must stay valid and unchanged, and `dst` untouched, until the frame's ticket has been waited for; if `src`
  *     lies in memory from jsp_host_alloc (pinned), it is uploaded from where it is, without a staging copy;

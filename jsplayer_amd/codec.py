@@ -342,6 +342,9 @@ class FramePool:
         tried = C.c_int(0)
         self.store_rate = float(self._lib.jsp_pool_store_rate(self._h, C.byref(tried)))
         self.attempts = tried.value
+        ms, held, limit = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        self._lib.jsp_pool_probe_info(self._h, C.byref(ms), C.byref(held), C.byref(limit))
+        self.probe_ms, self.held_bytes, self.hold_limit = ms.value, held.value, limit.value   # what placing the pool cost
         n = width * height
         self.frames = [torch.as_tensor(_DeviceView(int(self._lib.jsp_pool_buffer(self._h, i)), n), device=f"cuda:{device}") for i in range(count)]
 

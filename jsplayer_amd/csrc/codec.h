@@ -34,9 +34,12 @@ struct jsp_staged {
     jsp::DeviceBuffer d_signif;
     jsp::PinnedBuffer h_signif;
     bool decoded = false;
+    int device = -1;                // HIP device the batch's buffers live on (set when it is staged): what a re-run must activate
     bool verdict_pending = false;   // asynchronous staging whose results are final only after async_finish()
-    void finish_results();  // after the stream has been synchronised
-    virtual void after_sync() {}   // codec-specific checks of what the kernels reported (called by finish_results)
+    // After the stream has been synchronised.  Never throws: when the codec-specific step fails (a HIP error while a batch is re-run
+    // through the descriptor kernels) every frame of the batch reports JSP_ERROR_OCCURED and `why` says what happened.
+    void finish_results() noexcept;
+    virtual void after_sync() {}   // codec-specific checks of what the kernels reported (called by finish_results; may throw)
 };
 
 // One frame in flight on the asynchronous path (jsp_decompress_i_async / _p_async ... jsp_wait).

@@ -1,5 +1,6 @@
 // extern "C" surface of libjsplayer_amd.so (declared in include/jsplayer_amd.h).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
@@ -53,9 +54,19 @@ void jsp_codec::init_device(int device_id) {
 
 void jsp_codec::activate() { JSP_HIP(hipSetDevice(device)); }
 
-void jsp_staged::finish_results() {
+void jsp_staged::finish_results() noexcept {
     if (!decoded) return;
-    after_sync();
+    try {
+        if (device >= 0) JSP_HIP(hipSetDevice(device));   // (a re-run launches kernels: on the batch's device, whatever the caller's thread had current)
+        after_sync();
+    } catch (const std::exception& e) {
+        status.assign(status.size(), JSP_ERROR_OCCURED);
+        adopted.assign(adopted.size(), 0);
+        for (int& s : significant) if (s < 0) s = 0;
+        why = e.what();
+        set_error("%s", e.what());
+        return;
+    }
     const auto* words = static_cast<const uint32_t*>(h_signif.p);
     for (size_t i = 0; i < significant.size(); ++i)
         if (significant[i] < 0) significant[i] = words[i] ? 1 : 0;
@@ -70,6 +81,9 @@ struct jsp_pool {
     int attempts = 0;              // allocations tried
     double fill_rate = 0;          // GB/s of a plain fill over the first candidate: what the probe is held against
     std::vector<double> tried;     // ... and what each of them took
+    double probe_ms = 0;           // wall time of the placement probe (allocations, launches, releases)
+    uint64_t held_peak = 0;        // most device memory the probe held at one time, candidates kept while asking for the next
+    uint64_t hold_limit = 0;       // ... and what it was allowed to hold
 };
 namespace jsp {
 double pool_store_rate(uint32_t* const* d_frames, int nframes, int X, int Y, uint32_t fill);
@@ -126,6 +140,7 @@ int decompress_one(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, boo
     }
     std::vector<jsp_frame_in> frames{f};
     jsp_staged* st = c->stage(frames, c->scratch.get());
+    st->device = c->device;
     if (st != c->scratch.get()) c->scratch.reset(st);
     st->decode(c->stream);
     // the reference paints dst in place, adopted or not: hand back whatever was written
@@ -243,7 +258,12 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         // allocation for all, one per frame), keeps slow candidates
         // allocated while it asks for the next (else the allocator hands the same pages back) and settles for the first that takes
         // what a plain fill of the same memory takes, or the best of sixteen.  JSP_POOL_PROBE=0: one allocation per frame, first come.
-        constexpr int kProbeFrom = 32, kCandidates = 16;
+        // What the probe may hold is bounded: at most JSP_POOL_PROBE_MAX candidates (default 16) and at most a quarter of the device memory that
+        // was free when it began (JSP_POOL_PROBE_HOLD_GB: another limit, in GB) — a caller with 8 such pools to make must not find the
+        // seventh refused because the sixth was still holding 68 GB of rejects.
+        constexpr int kProbeFrom = 32;
+        int kCandidates = 16;
+        if (const char* m = std::getenv("JSP_POOL_PROBE_MAX")) kCandidates = std::max(1, std::min(64, std::atoi(m)));
         const char* env = std::getenv("JSP_POOL_PROBE");
         const bool probe = nbuf >= kProbeFrom && (width & 3) == 0 && (height & 3) == 0 && (size_t)nbuf * (size_t)((width / 4) * (height / 4) + 8191) / 8192 * 256 < (1ull << 32) &&   // (the probe: one launch, fewer than 2^32 lanes)
                            !(env && std::atoi(env) == 0);
@@ -254,9 +274,18 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
             uint32_t** d_table = nullptr;
             int best = -1;
             double yardstick = 0;
+            const auto probe_t0 = std::chrono::steady_clock::now();
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            uint64_t hold_limit = free_b ? (uint64_t)free_b / 4 : ~0ull;
+            if (const char* g = std::getenv("JSP_POOL_PROBE_HOLD_GB")) hold_limit = std::min<uint64_t>(hold_limit, (uint64_t)(std::atof(g) * 1e9));
+            const uint64_t one = (uint64_t)bytes * (uint64_t)nbuf;
+            hold_limit = std::max(hold_limit, one);            // (the pool itself is always allowed)
+            p->hold_limit = hold_limit;
             try {
                 JSP_HIP(hipMalloc(reinterpret_cast<void**>(&d_table), sizeof(uint32_t*) * (size_t)nbuf));
                 for (int a = 0; a < kCandidates; ++a) {
+                    if (best >= 0 && (uint64_t)(cands.size() + 1) * one > hold_limit) break;   // holding another candidate would pass the limit
                     Candidate c;
                     bool ok = true;
                     if (a % 3 == 1) {                          // all frames in one allocation, back to back
@@ -289,6 +318,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     p->tried.push_back(c.rate);
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", a, a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     cands.push_back(std::move(c));
+                    p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)cands.size() * one);
                     if (best < 0 || cands.back().rate > cands[best].rate) best = (int)cands.size() - 1;
                     if (a >= 1 && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill
                                                                                    // takes, 6.9 - 7.0 TB/s; the others 5.4 - 6.5; one candidate in
@@ -307,6 +337,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
             p->allocs = cands[best].allocs;
             p->bufs = cands[best].frames;
             for (int32_t* f : p->bufs) JSP_HIP(hipMemset(f, 0, bytes));
+            p->probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - probe_t0).count();
             return p.release();
         }
         for (int i = 0; i < nbuf; ++i) {
@@ -335,6 +366,13 @@ void jsp_pool_destroy(jsp_pool* p) {
 double jsp_pool_store_rate(jsp_pool* p, int* attempts) {
     if (attempts) *attempts = p ? p->attempts : 0;
     return p ? p->store_rate : 0.0;
+}
+int jsp_pool_probe_info(jsp_pool* p, double* probe_ms, uint64_t* held_peak_bytes, uint64_t* hold_limit_bytes) {
+    if (!p) return -1;
+    if (probe_ms) *probe_ms = p->probe_ms;
+    if (held_peak_bytes) *held_peak_bytes = p->held_peak;
+    if (hold_limit_bytes) *hold_limit_bytes = p->hold_limit;
+    return 0;
 }
 int jsp_download(const int32_t* device_frame, int32_t* host, size_t npixels) {
     return guarded([&] {
@@ -465,6 +503,7 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
     j.redone = j.settled = false;
     j.why.clear();
     jsp_staged* st = c->stage_async(j.frame, j.st.get());
+    st->device = c->device;
     if (st != j.st.get()) j.st.reset(st);
     st->decode(c->stream);
     JSP_HIP(hipEventRecord(j.done, c->stream));
@@ -569,6 +608,7 @@ jsp_staged* stage_batch_into(jsp_codec* c, jsp_staged* reuse, int nframes, const
         if (nframes) c->ptr_mode = 1;
         c->worker_drain();
         jsp_staged* st = c->stage(frames, reuse);
+        st->device = c->device;
         if (reuse && st != reuse) delete reuse;       // (a batch object of another kind: replaced)
         for (int i = 0; i < nframes; ++i) {
             if (!st->cleared.empty() && st->cleared[i]) c->prev_caller = nullptr;
@@ -603,13 +643,15 @@ const char* jsp_staged_kernels(const jsp_staged* s) { return s ? s->kernels.c_st
 
 int jsp_staged_results(jsp_staged* s, int* status, int* adopted, int* significant) {
     if (!s) return JSP_ERROR_OCCURED;
-    s->finish_results();
-    for (size_t i = 0; i < s->status.size(); ++i) {
-        if (status) status[i] = s->status[i];
-        if (adopted) adopted[i] = s->adopted[i];
-        if (significant) significant[i] = s->significant[i] < 0 ? 0 : s->significant[i];
-    }
-    return 0;
+    return guarded([&] {
+        s->finish_results();
+        for (size_t i = 0; i < s->status.size(); ++i) {
+            if (status) status[i] = s->status[i];
+            if (adopted) adopted[i] = s->adopted[i];
+            if (significant) significant[i] = s->significant[i] < 0 ? 0 : s->significant[i];
+        }
+        return 0;
+    });
 }
 
 int jsp_decompress_i_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs, const size_t* lens,
@@ -622,6 +664,7 @@ int jsp_decompress_i_batch(jsp_codec* c, int nframes, const uint8_t* const* srcs
         st->finish_results();
         for (int s : st->status)
             if (s != JSP_ZERO_STATE) rc = s;
+        if (rc != 0 && !st->why.empty()) set_error("%s", st->why.c_str());
     }
     jsp_staged_destroy(st);
     return rc;

@@ -90,6 +90,12 @@ struct SpCodec : jsp_codec {
         std::shared_ptr<Group> before;           // the group in front, until this group's first frame has decoded
         std::deque<jsp_async_job*> tasks;
         bool closed = false, finished = false, first_done = false, successor_settled = false;
+        // the previous frame as the group's frames REALLY left it (device pointer), once its first frame is through: what the next
+        // frame of the group is decoded against.  The submission-time prediction (jsp_async_job::prev_dev_before: from the frame's
+        // first byte) only serves a group's first frame — an inter frame that aborts, or one that finds no entropy coder yet, adopts
+        // nothing whatever its first byte promised, and the frames behind it must copy from the picture that is really there.
+        int32_t* prev = nullptr;
+        bool have_prev = false;
     };
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
@@ -167,7 +173,7 @@ struct SpCodec : jsp_codec {
         SpStaged* st = dynamic_cast<SpStaged*>(j.st.get());
         std::string failed;
         try {
-            int32_t* prev = j.prev_dev_before;
+            int32_t* prev = g.have_prev ? g.prev : j.prev_dev_before;
             jsp_staged* got = stage_impl(std::vector<jsp_frame_in>{j.frame}, st, g.dec, &prev, &outs_local);
             if (got != j.st.get()) j.st.reset(got);
             if (!g.first_done && g.own && j.st->status[0] != JSP_ZERO_STATE) {
@@ -179,7 +185,7 @@ struct SpCodec : jsp_codec {
                     cv_done.wait(lk, [&] { return b->finished; });
                 }
                 g.dec = b->dec;
-                prev = j.prev_dev_before;
+                prev = b->have_prev ? b->prev : j.prev_dev_before;   // (that group is through: what it really left)
                 got = stage_impl(std::vector<jsp_frame_in>{j.frame}, j.st.get(), g.dec, &prev, &outs_local);
                 if (got != j.st.get()) j.st.reset(got);
             } else if (!g.first_done && g.before) {
@@ -188,6 +194,9 @@ struct SpCodec : jsp_codec {
                 g.before.reset();
             }
             g.first_done = true;
+            g.prev = prev;
+            g.have_prev = true;
+            j.st->device = device;
             j.st->decode(stream);
             JSP_HIP(hipEventRecord(j.done, stream));
         } catch (const std::exception& e) {
@@ -228,9 +237,18 @@ struct SpCodec : jsp_codec {
             const Geometry g = host.geo();
             {
                 std::lock_guard<std::mutex> lk(mu);
-                // decoders of groups that are through and whose successor has started well go back to the shelf
-                for (auto& old : groups)
-                    if (old != cur && old->finished && old->successor_settled && old->own) spare.push_back(std::move(old->own));
+                // decoders of groups that are through and whose successor has started well go back to the shelf, and the groups
+                // themselves go: a caller that only ever uses the asynchronous calls never drains, and a stream of key frames would
+                // otherwise keep (and scan, under the lock the workers need) one group per key frame for as long as it runs
+                size_t kept = 0;
+                for (size_t i = 0; i < groups.size(); ++i) {
+                    auto& old = groups[i];
+                    const bool gone = old != cur && old->finished && old->successor_settled;
+                    if (gone && old->own) spare.push_back(std::move(old->own));
+                    if (!gone) { if (kept != i) groups[kept] = std::move(old); ++kept; }
+                }
+                groups.resize(kept);
+                while (spare.size() > 16) spare.pop_back();      // (the shelf need not grow with the stream either)
             }
             if (!spare.empty()) { fresh = std::move(spare.back()); spare.pop_back(); }
             if (fresh && fresh->pinned_version() != 0 && fresh->pinned_version() != stream_version) fresh.reset();   // it served another coder
@@ -293,8 +311,16 @@ struct SpCodec : jsp_codec {
         if (last->dec != &host) std::swap(host, *last->dec);
         for (auto& g : groups)
             if (g->own) spare.push_back(std::move(g->own));
+        prev_dev = last->have_prev ? last->prev : pred_prev_dev;   // what the frames really left (the prediction where nothing ran)
         groups.clear();
-        prev_dev = pred_prev_dev;      // (as predicted; jsp_wait reports what the frames really did)
+    }
+    // jsp_counter: "sp_groups_held" = groups of pictures the asynchronous path still keeps a record of (bounded however long a stream
+    // runs without a drain), "sp_spare_decoders" = decoders on the shelf
+    long long counter(const char* name) override {
+        std::lock_guard<std::mutex> lk(mu);
+        if (std::strcmp(name, "sp_groups_held") == 0) return (long long)groups.size();
+        if (std::strcmp(name, "sp_spare_decoders") == 0) return (long long)spare.size();
+        return -1;
     }
     int is_key_frame(const uint8_t* src, size_t n) override { return HostDecoder::is_key_frame(src, n) ? 1 : 0; }
     int needs_index() override { return 0; }

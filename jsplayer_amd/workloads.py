@@ -189,6 +189,18 @@ class StagedWorkload:
         for c in self.codecs:
             c.sync()
 
+    def lookback_fallbacks(self) -> int:
+        """Staged MSVideo1 batches that were re-run through the descriptor kernels because a tile of the fused kernel gave up waiting
+        (jsp_counter): 0 when the launches named by kernels() are what ran.  ScreenPressor has no such path."""
+        from .codec import CodecError
+        total = 0
+        for c in self.codecs:
+            try:
+                total += c.counter("lookback_fallbacks")
+            except CodecError:
+                pass
+        return total
+
     def kernels(self) -> str:
         return " | ".join(sorted({s.kernels() for s in self.staged}))
 

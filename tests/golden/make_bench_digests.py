@@ -27,7 +27,7 @@ from jsplayer_amd import workloads as wl  # noqa: E402
 from oracle_binding import OracleMSVideo1, OracleScreenPressor  # noqa: E402
 
 OUT = os.path.join(HERE, "bench_digests.json")
-ALL_RANKS = ("msvideo1_16_1080p_keyframes_m1", "screenpressor_v4_1080p_pclip300")   # the 8-stream configurations (the driver runs the first on 1/2/4/8 ranks)
+ALL_RANKS = ("msvideo1_16_1080p_keyframes_m1", "screenpressor_v4_1080p_pclip300", "screenpressor_v4_1080p_iframes")   # the 8-stream configurations, and every workload bench.py's default line carries (the driver runs it on 1/2/4/8 ranks)
 
 
 def oracle_clip(name, clip):

@@ -199,18 +199,11 @@ def test_screenpressor_async_groups_of_pictures_on_worker_threads(version):
         drive(gpu, OracleScreenPressor(w, h, 24), w, h, chunks, keys, depth=8)
 
 
-def test_screenpressor_async_broken_key_frame_lets_older_state_show_through():
-    """A coded key frame that does not decode (cut to a third of its bytes) leaves the decoder the stream had — its
-    "a key frame has been decoded" state included — to the frames behind it: the worker that took the broken frame's group,
-    on a decoder of its own, must go on with the decoder of the group before.  Such a stream is outside what the oracle
-    defines (the reference raises); the bar here is the product's own one-frame-at-a-time path: same states, same errors,
-    same previous-frame identities, same pixels."""
+def _sync_and_async_agree(chunks, keys, w, h, must_show=None):
+    """The same frames through the synchronous calls and through the asynchronous ones (worker threads, 8 in flight), a buffer
+    per frame: same states, same errors, same previous-frame identities, same pixels in EVERY buffer."""
     import torch
-    w, h = 320, 240
-    chunks, keys, _ = sg.sp_clip(64, w, h, 20, version=4, key_every=4)
-    chunks = list(chunks)
-    chunks[12] = chunks[12][:len(chunks[12]) // 3]
-    nbuf = 20
+    nbuf = len(chunks)
     results = []
     for mode in ("sync", "async"):
         gpu = ScreenPressor(w, h, 24)
@@ -245,10 +238,72 @@ def test_screenpressor_async_broken_key_frame_lets_older_state_show_through():
         gpu.StopAndClean()
     (log_s, prev_s, pix_s), (log_a, prev_a, pix_a) = results
     assert log_s == log_a
-    assert any(o == ("state", 2) or o == ("raise",) for _, o in log_s), "the broken key frame must show"
+    if must_show:
+        assert any(must_show(o) for _, o in log_s), "the broken frame must show"
     assert prev_s == prev_a
     for i, (a, b) in enumerate(zip(pix_s, pix_a)):
         assert np.array_equal(a, b), f"buffer {i}"
+    return log_s
+
+
+def test_screenpressor_async_broken_key_frame_lets_older_state_show_through():
+    """A coded key frame that does not decode (cut to a third of its bytes) leaves the decoder the stream had — its
+    "a key frame has been decoded" state included — to the frames behind it: the worker that took the broken frame's group,
+    on a decoder of its own, must go on with the decoder of the group before.  Such a stream is outside what the oracle
+    defines (the reference raises); the bar here is the product's own one-frame-at-a-time path: same states, same errors,
+    same previous-frame identities, same pixels."""
+    w, h = 320, 240
+    chunks, keys, _ = sg.sp_clip(64, w, h, 20, version=4, key_every=4)
+    chunks = list(chunks)
+    chunks[12] = chunks[12][:len(chunks[12]) // 3]
+    _sync_and_async_agree(chunks, keys, w, h, must_show=lambda o: o == ("state", 2) or o == ("raise",))
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_screenpressor_async_frame_that_adopts_nothing_against_its_first_byte(version):
+    """The asynchronous calls PREDICT from a frame's first byte what it does to the previous frame (ScreenPressor.hx:130-159,
+    308-313).  Where the prediction is wrong — an inter frame cut short aborts and adopts nothing; an inter frame behind a
+    flat-only start finds no entropy coder and changes nothing — the frames behind it in the same group of pictures must
+    still be decoded against the picture that is REALLY there (what the synchronous path copies from), not against the
+    failed frame's destination: jsp_wait promises exactly what the synchronous call would have returned, pixels included."""
+    w, h = 320, 240
+    # (a) an inter frame in the middle of a group, cut to a third of its bytes; three more inter frames behind it
+    chunks, keys, _ = sg.sp_clip(66, w, h, 16, version=version, key_every=8)
+    chunks = list(chunks)
+    assert not keys[3]
+    chunks[3] = chunks[3][:max(2, len(chunks[3]) // 3)]
+    log = _sync_and_async_agree(chunks, keys, w, h)
+    assert log[3][1] == ("raise",) or (log[3][1][0] == "p" and log[3][1][1] != 3), "the cut frame must not have been adopted"
+    # (b) a stream that opens with a flat key frame: inter frames behind it have no entropy coder yet
+    chunks, keys, _ = sg.sp_clip(67, w, h, 12, version=version, key_every=5)
+    chunks = [bytes([((version - 1) << 4) | 1, 10, 20, 30])] + list(chunks[1:])     # frame 0: a flat key frame (head, B, G, R)
+    log = _sync_and_async_agree(chunks, keys, w, h)
+    assert all(o == ("p", 0, False) for i, o in log if 0 < i < 5), "inter frames behind the flat start keep showing it"
+
+
+def test_screenpressor_async_only_caller_keeps_no_history():
+    """A caller that only ever uses the asynchronous calls never drains the worker path: the record of finished groups of
+    pictures (one per coded key frame) must not grow with the stream."""
+    import torch
+    w, h = 32, 32
+    chunks, keys, _ = sg.sp_clip(68, w, h, 8, version=4, key_every=1)
+    gpu = ScreenPressor(w, h, 24)
+    gpu.Preinit(36)
+    gpu.set_option("sp_async_threads", "4")
+    gpu.set_option("async_depth", "8")
+    bufs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(24)]
+    tickets, worst = [], 0
+    for i in range(6000):
+        if len(tickets) == 8:
+            assert gpu.wait(tickets.pop(0)) == DecoderState.zero_state
+        tickets.append(gpu.DecompressI_async(chunks[i % 8], bufs[i % 24]))
+        if i % 500 == 499:
+            worst = max(worst, gpu.counter("sp_groups_held"))
+    for t in tickets:
+        gpu.wait(t)
+    assert 0 < worst <= 16, f"{worst} groups of pictures on record after thousands of key frames"
+    assert gpu.counter("sp_spare_decoders") <= 16
+    gpu.StopAndClean()
 
 
 def test_screenpressor_async_and_synchronous_calls_alternate():

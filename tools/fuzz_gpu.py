@@ -22,7 +22,7 @@ def main():
     from jsplayer_amd import ScreenPressor
     from jsplayer_amd import streamgen as sg
     rng = np.random.default_rng(seed)
-    t0, clips, frames_checked, skipped, damaged = time.time(), 0, 0, 0, 0
+    t0, clips, frames_checked, skipped, damaged, async_clips = time.time(), 0, 0, 0, 0, 0
     while time.time() - t0 < budget:
         w = int(rng.choice([int(rng.integers(4, 160)) * 4, int(rng.integers(17, 700)), int(rng.integers(64, 600)) * 4]))
         h = int(rng.integers(9, 200))
@@ -105,7 +105,58 @@ def main():
                 print("BAD: no exact recovery after damaged frames", w, h, version, cfg, flush=True)
                 return 1
             gpu.StopAndClean()
-    print(f"fuzz finished: {clips} clips, {frames_checked} frames, {skipped} skipped as unencodable, {damaged} damaged frames survived, {time.time() - t0:.0f} s, seed {seed}")
+        # ---- the asynchronous calls (worker threads, 8 frames in flight, a buffer per frame) against the synchronous ones on the
+        # same frames, some of them cut short or with a byte flipped: where a frame adopts nothing against what its first byte
+        # promised, the frames behind it must still come out as the one-frame-at-a-time path leaves them — states, errors,
+        # previous-frame identities and the pixels of every buffer
+        if rng.random() < 0.4 and not misalign:
+            from jsplayer_amd import CodecError
+            seq = [bytes(c) for c in chunks]
+            for _ in range(int(rng.integers(0, 3))):
+                i = int(rng.integers(0, n))
+                b = bytearray(seq[i])
+                if rng.random() < 0.6 and len(b) > 2:
+                    b = b[: int(rng.integers(1, len(b)))]
+                elif len(b) > 2:
+                    b[int(rng.integers(1, len(b)))] ^= int(rng.integers(1, 256))
+                seq[i] = bytes(b)
+            threads = str(rng.choice(["1", "2", "4"]))
+            runs = []
+            for mode in ("sync", "async"):
+                gpu = ScreenPressor(w, h, bpp)
+                gpu.Preinit(36)
+                gpu.set_option("sp_async_threads", threads)
+                gpu.set_option("async_depth", "8")
+                bufs = [torch.full((w * h,), 7, dtype=torch.int32, device="cuda") for _ in range(n)]
+                log, tickets = [], []
+
+                def settle(i, fn):
+                    try:
+                        r = fn()
+                        out = ("state", int(r)) if keys[i] else ("p", next((k for k in range(n) if bufs[k] is r.data_pnt), None), r.significant_changes)
+                    except CodecError:
+                        out = ("raise",)
+                    log.append((i, out))
+                for i, (c, k) in enumerate(zip(seq, keys)):
+                    if mode == "sync":
+                        settle(i, (lambda: gpu.DecompressI(c, bufs[i])) if k else (lambda: gpu.DecompressP(c, bufs[i])))
+                    else:
+                        if len(tickets) == 8:
+                            j, t = tickets.pop(0)
+                            settle(j, lambda: gpu.wait(t))
+                        tickets.append((i, (gpu.DecompressI_async if k else gpu.DecompressP_async)(c, bufs[i])))
+                for j, t in tickets:
+                    settle(j, lambda: gpu.wait(t))
+                torch.cuda.synchronize()
+                prev = gpu.PreviousFrame()
+                runs.append((log, next((k for k in range(n) if bufs[k] is prev), None), [x.cpu().numpy() for x in bufs]))
+                gpu.StopAndClean()
+            same = runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and all(np.array_equal(a, b_) for a, b_ in zip(runs[0][2], runs[1][2]))
+            if not same:
+                print(f"BAD: asynchronous calls differ from the synchronous ones: {w}x{h} v{version} bpp{bpp} cfg={cfg} threads={threads}", runs[0][0], runs[1][0], flush=True)
+                return 1
+            async_clips += 1
+    print(f"fuzz finished: {clips} clips, {frames_checked} frames, {skipped} skipped as unencodable, {damaged} damaged frames survived, {async_clips} clips through the asynchronous calls against the synchronous ones, {time.time() - t0:.0f} s, seed {seed}")
     return 0
 
 
