@@ -135,7 +135,12 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *   "sp_inter_fusion" = "on" (default) | "off" : ScreenPressor only.  In a staged batch, consecutive inter
  *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
  *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its
- *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame. */
+ *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame.
+ *   "sp_group_chunk" = "0" (default) | "4" | "8" | "16" : ScreenPressor only.  "0": a workgroup of such a launch walks the whole
+ *       group (the loader-wave kernel).  n: the launch is split along the time axis too — a workgroup emits n frames and exits, and
+ *       finds the pixels it starts from by a last-writer look-back over the block records (every frame of the group then needs a
+ *       buffer of its own).  Measured slower on MI355X; kept as a launch plan that needs no long-lived workgroups.
+ *       Results do not depend on it. */
 /*   "msv1_async" = "auto" (default) | "one_launch_dma" | "one_launch" | "two_launches" : MSVideo1 with "msv1_parse" = "gpu",
  *       asynchronous calls only; frames of up to 128 parse tiles (2 MiB).  auto: one_launch_dma while at most 3 codec instances
  *       of the process use this path, one_launch beyond (many streams: the copy queues are the bottleneck).  one_launch_dma: the copy engine brings the frame's bytes up on a

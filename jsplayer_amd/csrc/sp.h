@@ -55,9 +55,10 @@ enum : uint8_t { PB_SUBRECT = 1, PB_MOTION = 2, PB_DATA = 4 };  // 0 = unchanged
 struct PBlock {        // 16 bytes
     uint8_t flags;
     uint8_t x1, y1, x2, y2;  // changed rectangle relative to the block origin, x2/y2 exclusive
-    uint8_t pad[3];
+    uint8_t pad;
+    uint16_t back;     // group launches (link_group_tables): frames back to the previous record of this block that painted anything, 0 = none
     int16_t mx, my;
-    uint32_t payload;  // index of the rectangle's first literal pixel
+    uint32_t payload;  // index of the rectangle's first literal pixel (group launches: inside the batch's payload, not the frame's)
 };
 static_assert(sizeof(PBlock) == 16, "PBlock is 16 bytes");
 
@@ -213,6 +214,18 @@ struct PGroupFrame {   // one per frame of the group, in decode order
 };
 void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev,
                          const PBlock* d_blocks, const uint32_t* d_payload, bool aligned16, hipStream_t stream);
+// The same frames with the time axis split as well: a workgroup = 8 blocks x `chunk` frames (4, 8 or 16), its starting pixels found
+// by a last-writer look-back over the block records.  Needs the tables linked by link_group_tables() — which also says how many
+// literal words the fullest (8 blocks x chunk) cell of the group holds: the LDS a workgroup needs.
+constexpr int kGroupMaxFrames = 65535;        // PBlock::back is 16 bits
+// Links the block tables of the `nframes` consecutive frames of a group launch (frame f's records at blocks + f * nbx * nby) and
+// makes their literal indices absolute (gframes[f].payload_off is added to every painting record and set to 0: every group kernel
+// adds the two).  Returns the literal words of the fullest cell for chunks of `chunk` frames.
+uint32_t link_group_tables(PBlock* blocks, PGroupFrame* gframes, int nframes, int nbx, int nby, int chunk);
+size_t pframe_chunk_lds_bytes(int chunk, uint32_t lit_words);
+bool pframe_chunks_ok(const Geometry& g, const int32_t* prev, bool aligned16, int chunk, uint32_t lit_words);
+void launch_pframe_chunks(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev, const PBlock* d_blocks,
+                          const uint32_t* d_payload, int chunk, uint32_t lit_words, hipStream_t stream);
 size_t iframe_lds_bytes(const Geometry& g, int band_rows = 0);
 constexpr int kMaxIntraWidth = 8192;  // LDS plan of the row-wavefront kernel
 

@@ -463,6 +463,36 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
     }
 }
 
+uint32_t link_group_tables(PBlock* blocks, PGroupFrame* gframes, int nframes, int nbx, int nby, int chunk) {
+    const size_t nblk = (size_t)nbx * (size_t)nby;
+    const int ngx = (nbx + 7) / 8;                         // block groups per block row (8 blocks per workgroup)
+    std::vector<int32_t> last(nblk, -1);                   // the last frame that painted the block
+    std::vector<uint32_t> cell((size_t)ngx * (size_t)nby, 0u);
+    uint32_t fullest = 0;
+    for (int f = 0; f < nframes; ++f) {
+        PBlock* pb = blocks + (size_t)f * nblk;
+        const uint32_t off = gframes[f].payload_off;
+        if (chunk > 0 && f % chunk == 0) std::fill(cell.begin(), cell.end(), 0u);
+        for (int by = 0; by < nby; ++by)
+            for (int bx = 0; bx < nbx; ++bx) {
+                PBlock& b = pb[(size_t)by * nbx + bx];
+                int32_t& l = last[(size_t)by * nbx + bx];
+                b.back = l >= 0 ? (uint16_t)(f - l) : (uint16_t)0;
+                if (b.flags != 0) {
+                    b.payload += off;
+                    l = f;
+                    if (b.flags & PB_DATA) {
+                        uint32_t& c = cell[(size_t)by * ngx + (bx >> 3)];
+                        c += (uint32_t)(b.x2 - b.x1) * (uint32_t)(b.y2 - b.y1);
+                        if (c > fullest) fullest = c;
+                    }
+                }
+            }
+        gframes[f].payload_off = 0;
+    }
+    return fullest;
+}
+
 void HostDecoder::literalise_motion(FrameOut& out) const {
     if (out.kind != FrameKind::Inter || out.motion_pixels == 0) return;
     const int32_t* pic = shadow_[cur_ ^ 1].data();   // decode_p swapped: this is the frame just decoded

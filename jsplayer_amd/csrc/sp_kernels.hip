@@ -779,6 +779,229 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Inter-frame groups, third form: SHORT-LIVED workgroups — the time axis is split as well.
+//
+// What bounds the two kernels above is not their arithmetic but how long their workgroups keep storing: the same bytes written
+// with the same 16-byte stores reach 6.9 TB/s when a workgroup stores once and leaves, 6.2 with four visits, 5.8 with sixteen,
+// 5.3 with 256 (tools/sp_store_lab.hip, profiles/r03_sp_store_lab.txt) — and a workgroup of the loader-wave kernel stores for
+// all 299 frames of a clip.  Here the grid is (block group) x (chunk of C frames): a workgroup emits C frames and exits.
+// The pixels it starts from — the state of its 8 blocks after frame f0 - 1 — are found WITHOUT running the earlier frames, by a
+// last-writer look-back over the block records: the host stage links every record to the previous record of the same block
+// that painted anything (PBlock::back, frames back; 0 = none since the group began), so a lane hops from writer to writer, takes
+// from each rectangle the pixels it still misses (a rectangle's literal pixels are its final value for that frame: motion
+// rectangles were literalised) and stops when nothing is missing; what is never painted comes from the frame before the group.
+// The look-back is a pure function of the tables: no workgroup waits for another.
+//   phase A (loads only): the chunk's 8 x C records and their literal pixels straight into LDS (global_load_lds, every request
+//                         out before any is waited for), the look-back chain per lane beside it;
+//   phase B (stores only): C frames from registers + LDS, two 16-byte row stores per lane and frame — the loop holds no load.
+constexpr int G3_BLOCKS = 8;
+constexpr int G3_WG = 256;
+constexpr int G3_CMAX = 16;                    // frames per chunk, at most (8 x 16 records = two per lane of a wave)
+
+template <int C>
+__global__ __launch_bounds__(G3_WG) void sp_pframe_chunk_kernel(const PGroupFrame* __restrict__ frames, int nframes,
+                                                               const uint32_t* __restrict__ prev,
+                                                               const PBlock* __restrict__ blocks,
+                                                               const uint32_t* __restrict__ payload, int X, int Y, int nbx,
+                                                               int lit_words) {
+    static_assert(C >= 1 && C <= G3_CMAX, "chunk length");
+    constexpr int NITEM = C * G3_BLOCKS;                   // (frame, block) records of the chunk, frame-major
+    constexpr int PER_LANE = (NITEM + 63) / 64;            // ... one or two per lane of a wave
+    extern __shared__ __align__(16) uint8_t g3_lds[];
+    PBlock* s_rec = reinterpret_cast<PBlock*>(g3_lds);                                   // [NITEM]
+    uint32_t* s_lit_at = reinterpret_cast<uint32_t*>(g3_lds + sizeof(PBlock) * NITEM);   // [NITEM]
+    uint32_t** s_dst = reinterpret_cast<uint32_t**>(s_lit_at + NITEM);                   // [C]
+    uint32_t* s_lits = reinterpret_cast<uint32_t*>(s_dst + C);                           // [lit_words]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int by = blockIdx.y;
+    const int f0 = (int)blockIdx.z * C;
+    const int nf = nframes - f0 < C ? nframes - f0 : C;
+    const int nb_here = nbx - (int)blockIdx.x * G3_BLOCKS < G3_BLOCKS ? nbx - (int)blockIdx.x * G3_BLOCKS : G3_BLOCKS;
+    const uint32_t block_off0 = frames[0].block_off, nblocks_frame = (uint32_t)nbx * (uint32_t)gridDim.y;
+    // lane = 16-byte chunk of two rows (r and r + 8 of the block row), as in the loader-wave kernel
+    const int r = tid >> 5, ch = tid & 31;
+    const int kb = ch >> 2;
+    const int cx0 = (ch & 3) * 4;
+    const int bx = blockIdx.x * G3_BLOCKS + kb;
+    const int x0 = bx * 16 + cx0;
+    const int ya = by * 16 + r, yb2 = ya + 8;
+    const bool col = bx < nbx && x0 < X;
+    const bool mine_a = col && ya < Y, mine_b = col && yb2 < Y;
+    const size_t ia = (size_t)ya * X + x0, ib = (size_t)yb2 * X + x0;
+
+    // ---- phase A.1: the records — the lane's own block at frame f0 (entry of the look-back) and the chunk's table
+    const PBlock* my_rec0 = blocks + (size_t)block_off0 + (size_t)by * nbx + (col ? bx : 0);   // my block in frame 0 of the group
+    PBlock entry{};
+    if (col) entry = my_rec0[(size_t)f0 * nblocks_frame];
+    if (tid < nf) s_dst[tid] = reinterpret_cast<uint32_t*>(frames[f0 + tid].dst);
+    PBlock item_rec[PER_LANE];
+#pragma unroll
+    for (int h = 0; h < PER_LANE; ++h) {
+        const int item = lane * PER_LANE + h, f = item >> 3, k = item & 7;
+        PBlock pb{};
+        if (item < nf * G3_BLOCKS && k < nb_here)
+            pb = blocks[(size_t)block_off0 + (size_t)(f0 + f) * nblocks_frame + (size_t)by * nbx + blockIdx.x * G3_BLOCKS + k];
+        item_rec[h] = pb;
+    }
+    // ---- phase A.2: where each changed rectangle's literals go (every wave computes the same scan: no hand-over), then the
+    //      literal pixels, rectangle by rectangle, 64 words per LDS-DMA; wave w asks for the rectangles of lanes = w (mod 4)
+    uint32_t need[PER_LANE], from[PER_LANE], sum = 0;
+#pragma unroll
+    for (int h = 0; h < PER_LANE; ++h) {
+        need[h] = from[h] = 0;
+        const PBlock& pb = item_rec[h];
+        if (pb.flags & PB_DATA) {
+            need[h] = (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
+            from[h] = pb.payload;                          // (absolute inside `payload`: see link_group_tables)
+        }
+        sum += need[h];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+    }
+    uint32_t at[PER_LANE];
+    at[0] = incl - sum;
+#pragma unroll
+    for (int h = 1; h < PER_LANE; ++h) at[h] = at[h - 1] + need[h - 1];
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < PER_LANE; ++h) {
+            const int item = lane * PER_LANE + h;
+            if (item < NITEM) { s_rec[item] = item_rec[h]; s_lit_at[item] = at[h]; }
+        }
+    }
+#pragma unroll 1
+    for (int h = 0; h < PER_LANE; ++h) {
+        unsigned long long m = __ballot(need[h] != 0u && at[h] + need[h] <= (uint32_t)lit_words && (lane & 3) == wave);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)need[h], l);
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)at[h], l);
+            const uint32_t* src = payload + (uint32_t)__builtin_amdgcn_readlane((int)from[h], l);
+            for (uint32_t i = 0; i < n; i += 64)
+                if (i + lane < n) __builtin_amdgcn_global_load_lds((g2_gvoid*)(src + i + lane), (g2_lvoid*)&s_lits[a + i], 4, 0, 0);
+        }
+    }
+
+    // ---- phase A.3: the look-back.  `miss` = the lane's pixels without a value yet (bits 0..3 row a, 4..7 row b)
+    uint32_t pa[4] = {0, 0, 0, 0}, pb4[4] = {0, 0, 0, 0};
+    uint32_t miss = (mine_a ? 0x0Fu : 0u) | (mine_b ? 0xF0u : 0u);
+    {
+        int t = f0;
+        uint32_t back = entry.back;                        // frames back from f0 to the last record that painted this block
+        PBlock w{};
+        bool have = miss != 0u && back != 0u;
+        if (have) { t -= (int)back; w = my_rec0[(size_t)t * nblocks_frame]; }
+        while (__builtin_amdgcn_ballot_w64(have)) {
+            PBlock nxt{};
+            bool more = false;
+            uint32_t take = 0;
+            if (have) {
+                // which of the missing pixels this rectangle supplies
+                const bool cols = cx0 < w.x2 && cx0 + 4 > w.x1;
+                if (cols) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rx = cx0 + j;
+                        const bool in = rx >= w.x1 && rx < w.x2;
+                        if (in && r >= w.y1 && r < w.y2) take |= 1u << j;
+                        if (in && r + 8 >= w.y1 && r + 8 < w.y2) take |= 16u << j;
+                    }
+                }
+                take &= miss;
+                miss &= ~take;
+                more = miss != 0u && w.back != 0u;
+                if (more) nxt = my_rec0[(size_t)(t - (int)w.back) * nblocks_frame];   // the next hop goes out before this one's pixels
+                if (take) {
+                    const int wd = w.x2 - w.x1;
+                    const uint32_t* lit = payload + w.payload + (cx0 - (int)w.x1);
+                    if (take & 0x0Fu) {
+                        const uint32_t* la = lit + (r - (int)w.y1) * wd;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (take & (1u << j)) pa[j] = load1_global(la + j);
+                    }
+                    if (take & 0xF0u) {
+                        const uint32_t* lb = lit + (r + 8 - (int)w.y1) * wd;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (take & (16u << j)) pb4[j] = load1_global(lb + j);
+                    }
+                }
+                t -= (int)w.back;
+            }
+            w = nxt;
+            have = more;
+        }
+    }
+    // never painted since the group began: the frame before the group
+    if (miss & 0x0Fu) {
+        const uint4 q = *reinterpret_cast<const uint4*>(prev + ia);
+        if (miss & 1u) pa[0] = q.x;
+        if (miss & 2u) pa[1] = q.y;
+        if (miss & 4u) pa[2] = q.z;
+        if (miss & 8u) pa[3] = q.w;
+    }
+    if (miss & 0xF0u) {
+        const uint4 q = *reinterpret_cast<const uint4*>(prev + ib);
+        if (miss & 16u) pb4[0] = q.x;
+        if (miss & 32u) pb4[1] = q.y;
+        if (miss & 64u) pb4[2] = q.z;
+        if (miss & 128u) pb4[3] = q.w;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every load of this workgroup is in before its first store goes out
+    __syncthreads();
+
+    // ---- phase B: C frames, stores only
+    if (col) {
+        for (int f = 0; f < nf; ++f) {
+            const PBlock pb = s_rec[f * G3_BLOCKS + kb];
+            uint32_t* out = s_dst[f];
+            if (pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
+                const int w = pb.x2 - pb.x1;
+                const uint32_t a = s_lit_at[f * G3_BLOCKS + kb];
+                const uint32_t n = (uint32_t)w * (uint32_t)(pb.y2 - pb.y1);
+                if (a + n <= (uint32_t)lit_words) {
+                    const uint32_t* lit0 = s_lits + a - pb.x1;
+                    if (r >= pb.y1 && r < pb.y2) {
+                        const uint32_t* lit = lit0 + (uint32_t)((r - pb.y1) * w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pa[j] = lit[rx]; }
+                    }
+                    if (r + 8 >= pb.y1 && r + 8 < pb.y2) {
+                        const uint32_t* lit = lit0 + (uint32_t)((r + 8 - pb.y1) * w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pb4[j] = lit[rx]; }
+                    }
+                } else {
+                    // (cannot happen with the launch's LDS plan — link_group_tables sizes it for the fullest chunk —: kept so that a
+                    // plan that is wrong is slow, not wrong)
+                    const uint32_t* lit0 = payload + pb.payload - pb.x1;
+                    if (r >= pb.y1 && r < pb.y2) {
+                        const uint32_t* lit = lit0 + (uint32_t)((r - pb.y1) * w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pa[j] = load1_global(lit + rx); }
+                    }
+                    if (r + 8 >= pb.y1 && r + 8 < pb.y2) {
+                        const uint32_t* lit = lit0 + (uint32_t)((r + 8 - pb.y1) * w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pb4[j] = load1_global(lit + rx); }
+                    }
+                }
+            }
+            if (mine_a) store4_global(out + ia, make_uint4(pa[0], pa[1], pa[2], pa[3]));
+            if (mine_b) store4_global(out + ib, make_uint4(pb4[0], pb4[1], pb4[2], pb4[3]));
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -865,6 +1088,35 @@ void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const P
     dim3 grid((g.nbx + 3) / 4, g.nby);
     hipLaunchKernelGGL(sp_pframe_kernel, grid, dim3(PWG), 0, stream, reinterpret_cast<uint32_t*>(dst),
                        reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec);
+}
+
+size_t pframe_chunk_lds_bytes(int chunk, uint32_t lit_words) {
+    return (size_t)chunk * G3_BLOCKS * (sizeof(PBlock) + 4) + (size_t)chunk * sizeof(void*) + (size_t)lit_words * 4;
+}
+bool pframe_chunks_ok(const Geometry& g, const int32_t* prev, bool aligned16, int chunk, uint32_t lit_words) {
+    return (g.X & 3) == 0 && aligned16 && (reinterpret_cast<uintptr_t>(prev) & 15) == 0 && (chunk == 4 || chunk == 8 || chunk == 16) &&
+           pframe_chunk_lds_bytes(chunk, lit_words) <= 150 * 1024;
+}
+void launch_pframe_chunks(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev, const PBlock* d_blocks,
+                          const uint32_t* d_payload, int chunk, uint32_t lit_words, hipStream_t stream) {
+    if (nframes <= 0) return;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_chunk_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_chunk_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_chunk_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    // x = block group fastest, then block row, then chunk: the workgroups of a chunk are dispatched together, so the launch's write
+    // fronts stand in the 2 - 3 chunks in flight, not in all frames at once
+    const dim3 grid((g.nbx + G3_BLOCKS - 1) / G3_BLOCKS, g.nby, (nframes + chunk - 1) / chunk);
+    const size_t lds = pframe_chunk_lds_bytes(chunk, lit_words);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(prev);
+    if (chunk == 4)
+        hipLaunchKernelGGL(sp_pframe_chunk_kernel<4>, grid, dim3(G3_WG), lds, stream, d_frames, nframes, p, d_blocks, d_payload, g.X, g.Y, g.nbx, (int)lit_words);
+    else if (chunk == 8)
+        hipLaunchKernelGGL(sp_pframe_chunk_kernel<8>, grid, dim3(G3_WG), lds, stream, d_frames, nframes, p, d_blocks, d_payload, g.X, g.Y, g.nbx, (int)lit_words);
+    else
+        hipLaunchKernelGGL(sp_pframe_chunk_kernel<16>, grid, dim3(G3_WG), lds, stream, d_frames, nframes, p, d_blocks, d_payload, g.X, g.Y, g.nbx, (int)lit_words);
 }
 
 void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev,

@@ -33,11 +33,11 @@ for step in "$@"; do
     profile:*)
       W="${step#profile:}"
       cd /tmp
-      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$W" -o p -- python3 "$R/bench.py" --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > "$O/${T}_${W}_bench_under_rocprof.json" 2> "$O/${T}_${W}_rocprof.err" || { tail -20 "$O/${T}_${W}_rocprof.err"; exit 1; }
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$W" -o p -- python3 "$R/bench.py" --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-also > "$O/${T}_${W}_bench_under_rocprof.json" 2> "$O/${T}_${W}_rocprof.err" || { tail -20 "$O/${T}_${W}_rocprof.err"; exit 1; }
       find "$O/prof_$W" -name "*kernel_stats.csv" -exec cp {} "$O/${T}_${W}_kernel_stats.csv" \;
       rm -rf "$O/prof_$W"
-      timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > /dev/null 2> "$O/${T}_${W}_pmc_f.err" || { tail -20 "$O/${T}_${W}_pmc_f.err"; exit 1; }
-      timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > /dev/null 2> "$O/${T}_${W}_pmc_w.err" || { tail -20 "$O/${T}_${W}_pmc_w.err"; exit 1; }
+      timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --no-also > /dev/null 2> "$O/${T}_${W}_pmc_f.err" || { tail -20 "$O/${T}_${W}_pmc_f.err"; exit 1; }
+      timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --no-also > /dev/null 2> "$O/${T}_${W}_pmc_w.err" || { tail -20 "$O/${T}_${W}_pmc_w.err"; exit 1; }
       cd "$R"
       python tools/pmc_summary.py "$O/pmc_f_$W" "$O/pmc_w_$W" "$O/${T}_${W}_bench_under_rocprof.json" "$O/${T}_${W}_traffic.json" || exit 1
       rm -rf "$O/pmc_f_$W" "$O/pmc_w_$W"
