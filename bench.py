@@ -355,6 +355,24 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
                            f"{ncap}-frame sample, the others {nshort}-frame clips of other seeds), every stream playing its file over and over for the same {secs} s"}
     if not one:
         return {"all_threads": all_threads}
+    # what the bus itself delivers on this box: pinned host-to-device copies, nothing else queued (jsp_measure_h2d)
+    h2d = None
+    try:
+        import ctypes as C
+        from jsplayer_amd import _native as N
+        table, best = {}, 0.0
+        for mb in (0.5, 4, 64):
+            for ns in (1, 2, 4):
+                rate = C.c_double(0.0)
+                nbytes = int(mb * (1 << 20))
+                if N.lib().jsp_measure_h2d(job.local_rank, nbytes, ns, max(2, int((256 << 20) / nbytes / ns)), C.byref(rate)) == 0:
+                    table[f"{mb}MB_x{ns}"] = round(rate.value, 1)
+                    best = max(best, rate.value)
+        if best > 0:
+            h2d = {"value": round(best, 1), "unit": "GB/s", "by_copy_size_and_streams": table,
+                   "note": "pinned hipMemcpyAsync host-to-device, 0.5 / 4 / 64 MB per copy on 1 / 2 / 4 streams side by side, wall clock, best of three passes (jsp_measure_h2d)"}
+    except Exception as e:
+        print(f"[bench] bus ceiling not measured: {e}", file=sys.stderr)
     e2e = {"value": round(float(tot[0]), 1), "unit": "Mpixels/s", "streams": args.gpus, "frames": one["frames"],
            "ms_per_frame": round(one["seconds"] * 1e3 / one["frames"], 4),
            "uploaded_bytes_per_s": round(float(tot[2])),
@@ -365,6 +383,10 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
                        "uploaded_bytes_per_s = compressed bytes handed to the decoders per second (what crosses the bus)"}
     if batch_api:
         e2e["batch_api"] = batch_api
+    if h2d:
+        e2e["h2d_ceiling_GBs"] = h2d
+        e2e["uploaded_fraction_of_h2d_ceiling"] = round(float(tot[2]) / max(1, args.gpus) / 1e9 / h2d["value"], 3)
+        e2e["all_threads"]["uploaded_fraction_of_h2d_ceiling"] = round(float(tot[3]) / max(1, args.gpus) / 1e9 / h2d["value"], 3)
     return e2e
 
 

@@ -9,6 +9,11 @@
 //                                end-to-end rate: T independent streams (threads, a codec instance each) play the clip R
 //                                times (or over and over for S seconds, all streams for the same interval) from the file's
 //                                bytes in pinned memory; prints one JSON line
+//   jsp_play a.avi,b.avi --pipelined --devices 0,1,... [--streams T] [--quiet ...]
+//                                streams sharded one per GPU inside this process: stream s plays file s (mod their number) on
+//                                device devices[s mod G], a host thread, a codec instance and a frame pool each; the per-device
+//                                (frames, pixels) counters are summed through jsp_reduce_counters (RCCL all-reduce when it loads).
+//                                Without --quiet every stream's per-frame lines are printed under a "# stream s device d file" header
 //
 // It restates, in this project's own words, only what touches the codec:
 //   * the container facts that select and feed it (AVIParser.hx:42-88,142-171; ParserUtils.hx:24-27):
@@ -135,8 +140,15 @@ struct Gate { std::atomic<int> waiting{0}; int parties = 1; };
 using Clock = std::chrono::steady_clock;
 // `seconds` > 0: the timed passes start the file over until that much time has passed since the gate opened and stop where they are (frames
 // in flight are collected) — streams with files of different lengths then all run for the same interval.
+// `sink`: the per-frame lines go there instead of stdout (several streams printing side by side).
 long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int warmup = 0, Gate* gate = nullptr, Clock::time_point* t0 = nullptr,
-                    Clock::time_point* t1 = nullptr, int device = 0, double seconds = 0) {
+                    Clock::time_point* t1 = nullptr, int device = 0, double seconds = 0, std::string* sink = nullptr) {
+    auto say = [&](const char* fmt, auto... a) {
+        if (!sink) { std::printf(fmt, a...); return; }
+        char line[256];
+        std::snprintf(line, sizeof line, fmt, a...);
+        *sink += line;
+    };
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
                                       (int)clip.palette.size(), device);
     if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return -1; }
@@ -165,7 +177,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
         int signif = -1, shown = f.slot;
         const int state = jsp_wait(dec, f.ticket, &shown_ptr, &signif);
         if (f.key) {
-            if (state != JSP_ZERO_STATE) { if (!quiet) std::printf("%zu key error %d %s\n", f.index, state, jsp_last_error()); return; }
+            if (state != JSP_ZERO_STATE) { if (!quiet) say("%zu key error %d %s\n", f.index, state, jsp_last_error()); return; }
             signif = -1;
             if (!quiet) {   // frames_differ_significantly, Manager.hx:392-421
                 const uint8_t* src = clip.bytes.data() + clip.frames[f.index].first;
@@ -178,7 +190,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
                 else jsp_frames_differ(jsp_pool_buffer(pool, f.slot), f.prev, (size_t)kInsignificantLines * clip.X, npx, &signif, nullptr);
             }
         } else {
-            if (state != JSP_ZERO_STATE) { if (!quiet) std::printf("%zu inter raised %s\n", f.index, jsp_last_error()); return; }
+            if (state != JSP_ZERO_STATE) { if (!quiet) say("%zu inter raised %s\n", f.index, jsp_last_error()); return; }
             if (shown_ptr && shown_ptr == f.prev && f.prev_slot >= 0) shown = f.prev_slot;
             else if (!shown_ptr) shown = -1;
         }
@@ -187,7 +199,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
         uint32_t crc = 0;
         if (shown >= 0 && jsp_download(jsp_pool_buffer(pool, shown), host.data(), npx) == 0)
             crc = crc32(reinterpret_cast<const uint8_t*>(host.data()), npx * 4);
-        std::printf("%zu %s %d %d %08x\n", f.index, f.key ? "key" : "inter", shown, signif, crc);
+        say("%zu %s %d %d %08x\n", f.index, f.key ? "key" : "inter", shown, signif, crc);
     };
     Clock::time_point deadline{};
     bool timed_out = false;
@@ -324,8 +336,9 @@ int main(int argc, char** argv) {
     }
     const Clip& clip = clips[0];
     bool pipelined = false, quiet = false;
-    int depth = 4, streams = 1, repeat = 1, warmup = 1, batch = 0, device = 0;
+    int depth = 4, streams = 0, repeat = 1, warmup = 1, batch = 0, device = 0;
     double seconds = 0;
+    std::vector<int> devices;                                 // --devices: streams sharded one per GPU (stream s -> devices[s mod G])
     for (int a = 2; a < argc; ++a) {
         const std::string o = argv[a];
         if (o == "--pipelined") pipelined = true;
@@ -337,6 +350,15 @@ int main(int argc, char** argv) {
         else if (o == "--warmup" && a + 1 < argc) warmup = std::atoi(argv[++a]);
         else if (o == "--batch" && a + 1 < argc) batch = std::atoi(argv[++a]);
         else if (o == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
+        else if (o == "--devices" && a + 1 < argc) {
+            const std::string list = argv[++a];
+            for (size_t at = 0; at <= list.size();) {
+                const size_t comma = list.find(',', at);
+                devices.push_back(std::atoi(list.substr(at, comma == std::string::npos ? std::string::npos : comma - at).c_str()));
+                if (comma == std::string::npos) break;
+                at = comma + 1;
+            }
+        }
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
     }
     if (batch > 0) {
@@ -349,6 +371,39 @@ int main(int argc, char** argv) {
                     frames * (double)clip.X * clip.Y / sec / 1e6);
         return 0;
     }
+    if (!devices.empty()) {
+        const int have = jsp_device_count();
+        for (int d : devices)
+            if (d < 0 || d >= have) { std::fprintf(stderr, "--devices: no device %d (%d visible)\n", d, have); return 2; }
+        if (!pipelined || batch > 0) { std::fprintf(stderr, "--devices goes with --pipelined\n"); return 2; }
+        if (streams <= 0) streams = (int)devices.size();      // one stream per listed device unless told otherwise
+    }
+    if (pipelined && !devices.empty() && !quiet) {
+        // every stream prints what a single-device run of its file prints, under a header of its own
+        depth = depth < 1 ? 1 : (depth > 16 ? 16 : depth);
+        std::vector<std::string> lines(streams);
+        std::vector<long> done(streams, 0);
+        std::vector<std::thread> pool;
+        for (int s = 0; s < streams; ++s)
+            pool.emplace_back([&, s] {
+                done[s] = play_pipelined(clips[(size_t)s % clips.size()], depth, 1, false, 0, nullptr, nullptr, nullptr,
+                                         jsp_assign_stream(s, devices.data(), (int)devices.size()), 0, &lines[s]);
+            });
+        for (auto& t : pool) t.join();
+        std::vector<uint64_t> per((size_t)devices.size() * 2, 0);
+        for (int s = 0; s < streams; ++s) {
+            if (done[s] < 0) return 1;
+            const Clip& c = clips[(size_t)s % clips.size()];
+            std::printf("# stream %d device %d file %zu\n%s", s, jsp_assign_stream(s, devices.data(), (int)devices.size()), (size_t)s % clips.size(), lines[s].c_str());
+            per[2 * ((size_t)s % devices.size())] += (uint64_t)done[s];
+            per[2 * ((size_t)s % devices.size()) + 1] += (uint64_t)done[s] * (uint64_t)c.X * (uint64_t)c.Y;
+        }
+        uint64_t total[2] = {0, 0};
+        int via = 0;
+        if (jsp_reduce_counters(devices.data(), (int)devices.size(), per.data(), total, &via) != JSP_ZERO_STATE) { std::fprintf(stderr, "counter reduce failed: %s\n", jsp_shard_last_error()); return 1; }
+        std::printf("# total frames %llu pixels %llu reduce %s\n", (unsigned long long)total[0], (unsigned long long)total[1], via ? "rccl" : "host");
+        return 0;
+    }
     if (pipelined) {
         depth = depth < 1 ? 1 : (depth > 16 ? 16 : depth);
         if (!quiet) return play_pipelined(clip, depth, 1, false) < 0 ? 1 : 0;
@@ -359,7 +414,10 @@ int main(int argc, char** argv) {
         Gate gate;
         gate.parties = streams;
         for (int s = 0; s < streams; ++s)
-            pool.emplace_back([&, s] { done[s] = play_pipelined(clips[(size_t)s % clips.size()], depth, repeat, true, warmup, &gate, &begin[s], &end[s], device, seconds); });
+            pool.emplace_back([&, s] {
+                const int dev = devices.empty() ? device : jsp_assign_stream(s, devices.data(), (int)devices.size());
+                done[s] = play_pipelined(clips[(size_t)s % clips.size()], depth, repeat, true, warmup, &gate, &begin[s], &end[s], dev, seconds);
+            });
         for (auto& t : pool) t.join();
         Clock::time_point first = begin[0], last = end[0];
         for (int s = 1; s < streams; ++s) { if (begin[s] < first) first = begin[s]; if (end[s] > last) last = end[s]; }
@@ -374,9 +432,30 @@ int main(int argc, char** argv) {
             for (const auto& fr : c.frames) per_pass += (double)fr.second;
             compressed += per_pass * (c.frames.empty() ? 0.0 : (double)done[s] / (double)c.frames.size());
         }
+        // streams sharded over several devices: the per-device counters, summed by the library (RCCL all-reduce when it loads)
+        std::string shard;
+        if (!devices.empty()) {
+            std::vector<uint64_t> per(devices.size() * 2, 0);
+            for (int s = 0; s < streams; ++s) {
+                const Clip& c = clips[(size_t)s % clips.size()];
+                per[2 * ((size_t)s % devices.size())] += (uint64_t)done[s];
+                per[2 * ((size_t)s % devices.size()) + 1] += (uint64_t)done[s] * (uint64_t)c.X * (uint64_t)c.Y;
+            }
+            uint64_t total[2] = {0, 0};
+            int via = 0;
+            if (jsp_reduce_counters(devices.data(), (int)devices.size(), per.data(), total, &via) != JSP_ZERO_STATE || total[0] != (uint64_t)frames) {
+                std::fprintf(stderr, "counter reduce failed: %s\n", jsp_shard_last_error());
+                return 1;
+            }
+            shard = ", \"devices\": [";
+            for (size_t i = 0; i < devices.size(); ++i) shard += (i ? ", " : "") + std::to_string(devices[i]);
+            shard += "], \"per_device_frames\": [";
+            for (size_t i = 0; i < devices.size(); ++i) shard += (i ? ", " : "") + std::to_string(per[2 * i]);
+            shard += "], \"total_pixels\": " + std::to_string(total[1]) + ", \"counter_reduce\": \"" + (via ? "rccl" : "host") + "\"";
+        }
         std::printf("{\"streams\": %d, \"files\": %zu, \"depth\": %d, \"frames\": %ld, \"warmup_passes\": %d, \"seconds\": %.6f, \"mpixels_per_s\": %.1f, "
-                    "\"compressed_bytes\": %.0f, \"uploaded_bytes_per_s\": %.0f}\n", streams, clips.size(), depth, frames,
-                    warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6, compressed, compressed / sec);
+                    "\"compressed_bytes\": %.0f, \"uploaded_bytes_per_s\": %.0f%s}\n", streams, clips.size(), depth, frames,
+                    warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6, compressed, compressed / sec, shard.c_str());
         return 0;
     }
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),

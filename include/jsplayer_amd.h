@@ -263,12 +263,29 @@ int jsp_display_convert(const int32_t* frame, int32_t* out, int width, int heigh
 int jsp_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, size_t npixels, int* differ,
                       void* hip_stream);
 
+/* ---- streams sharded one per GPU inside ONE process (the caller side of Manager.hx:97-142: a Manager and a decoder per
+ * stream).  Streams are independent — a codec instance, its previous-frame chain and its entropy models each — so stream i simply
+ * lives on devices[i mod ndev] (jsp_codec_create / jsp_pool_create take the device; every call activates its codec's device), one
+ * host thread per stream, and no frame ever crosses xGMI.  The one collective is the sum of the per-device counters. */
+int jsp_device_count(void);                                             /* HIP devices visible to the process (0: none) */
+int jsp_assign_stream(int stream_index, const int* devices, int ndev);  /* devices[stream_index mod ndev]; -1 on bad arguments */
+/* per_device = ndev pairs (frames, pixels), entry i belonging to devices[i]; total[0..1] = their sums.  When librccl can be loaded
+ * the sums are ALSO computed on the GPUs — one RCCL communicator per distinct device, ncclAllReduce(ncclSum) of the two counters
+ * over xGMI — and must agree with the host's (*via_rccl = 1; a mismatch is JSP_ERROR_OCCURED); without RCCL, or when it declines
+ * (jsp_shard_last_error says why), *via_rccl = 0 and the host's sums stand.  Returns JSP_ZERO_STATE or JSP_ERROR_OCCURED. */
+int jsp_reduce_counters(const int* devices, int ndev, const uint64_t* per_device, uint64_t* total, int* via_rccl);
+const char* jsp_shard_last_error(void);
+
 /* Library/build identification: "jsplayer_amd <version> gfx950". */
 /* Measurement helper (no reference counterpart): the store rate this GPU reaches when asked for nothing else — `reps` launches
  * that fill `nbytes` of `device` (16-byte aligned) with one 16-byte store per lane, workgroups in address order, timed with HIP
  * events on `hip_stream`; best of three passes, GB/s.  bench.py reports it next to the 8 TB/s the roofline is priced against
  * (the boxes of one pool differ by a fifth in what their memory delivers). */
 int jsp_measure_fill(int32_t* device, size_t nbytes, int reps, double* gbytes_per_s, void* hip_stream);
+/* ... and what the BUS delivers (no reference counterpart): `copies` pinned host-to-device copies of `bytes_per_copy` on each of `nstreams`
+ * (1..16) HIP streams of the device side by side, wall clock, best of three passes, GB/s — the ceiling of every end-to-end rate, where
+ * the compressed bytes are all that crosses (bench.py: e2e.h2d_ceiling_GBs). */
+int jsp_measure_h2d(int device_id, size_t bytes_per_copy, int nstreams, int copies, double* gbytes_per_s);
 
 const char* jsp_version(void);
 

@@ -66,6 +66,11 @@ SIGNATURES = {
     "jsp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "jsp_sync": (C.c_int, [C.c_void_p]),
     "jsp_counter": (C.c_longlong, [C.c_void_p, C.c_char_p]),
+    "jsp_measure_h2d": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "jsp_device_count": (C.c_int, []),
+    "jsp_assign_stream": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "jsp_reduce_counters": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "jsp_shard_last_error": (C.c_char_p, []),
     "jsp_decompress_i_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]),
     "jsp_decompress_p_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]),
     "jsp_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

@@ -329,3 +329,67 @@ def test_cpp_player_pipelined_shows_the_same_pictures(what, tmp_path):
     assert res.returncode == 0, res.stderr.decode()
     rate = json.loads(res.stdout.decode())
     assert rate["streams"] == 3 and rate["frames"] == 3 * 2 * len(outs[0]) and rate["mpixels_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_cpp_player_shards_streams_over_devices(tmp_path):
+    """examples/jsp_play --devices: independent streams sharded one per listed device inside one process (a host thread, a codec
+    instance and a frame pool each; stream s plays file s on devices[s mod G]), the per-device counters summed through
+    jsp_reduce_counters.  With the one device of this box listed twice every stream must print exactly what a single-device run
+    of its file prints; the counters must add up; and the reduce itself must go through RCCL when a communicator can be had."""
+    import ctypes as C
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "jsp_play")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    paths = []
+    chunks, keys, _ = sg.sp_clip(41, 320, 240, 10, version=4, key_every=4, unchanged_at=(2,))
+    paths.append(tmp_path / "a.avi")
+    paths[-1].write_bytes(avi.write_avi(320, 240, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys))
+    frames, pal = config0_clip(16, 24)
+    probe = ORACLE_CLASSES[0](320, 240)
+    paths.append(tmp_path / "b.avi")
+    paths[-1].write_bytes(avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=16, palette=pal, key_flags=[i == 0 or probe.IsKeyFrame(f) for i, f in enumerate(frames)]))
+    single = []
+    for p in paths:
+        res = subprocess.run([exe, str(p), "--pipelined", "--depth", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert res.returncode == 0, res.stderr.decode()
+        single.append(res.stdout.decode().splitlines())
+    res = subprocess.run([exe, ",".join(str(p) for p in paths), "--pipelined", "--depth", "3", "--devices", "0,0", "--streams", "3"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode == 0, res.stderr.decode()
+    out = res.stdout.decode().splitlines()
+    streams, cur = {}, None
+    for ln in out:
+        if ln.startswith("# stream"):
+            cur = int(ln.split()[2])
+            assert ln.split()[3:5] == ["device", "0"]
+            streams[cur] = []
+        elif ln.startswith("# total"):
+            total = ln.split()
+        elif ln[:1].isdigit():               # (RCCL prints a version banner of its own on stdout when the communicator is made)
+            streams[cur].append(ln)
+    assert sorted(streams) == [0, 1, 2]
+    assert streams[0] == single[0] and streams[1] == single[1] and streams[2] == single[0]      # stream 2 plays file 0 again
+    nframes = 2 * len(single[0]) + len(single[1])
+    assert int(total[3]) == nframes and int(total[5]) == nframes * 320 * 240 and total[7] in ("rccl", "host")
+    # throughput form: the JSON line carries the per-device counters
+    res = subprocess.run([exe, ",".join(str(p) for p in paths), "--pipelined", "--quiet", "--devices", "0,0", "--streams", "4", "--repeat", "2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode == 0, res.stderr.decode()
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["devices"] == [0, 0] and sum(line["per_device_frames"]) == line["frames"] == 2 * (2 * len(single[0]) + 2 * len(single[1]))
+    assert line["total_pixels"] == line["frames"] * 320 * 240
+    bad = subprocess.run([exe, str(paths[0]), "--pipelined", "--devices", "0,99"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert bad.returncode == 2
+    # the collective itself: one rank per distinct device; on this box one device, so a communicator of one rank — the all-reduce runs on the GPU
+    from jsplayer_amd import _native as N
+    lib = N.lib()
+    assert lib.jsp_device_count() >= 1
+    devs, per = (C.c_int * 2)(0, 0), (C.c_uint64 * 4)(5, 500, 7, 700)
+    tot, via = (C.c_uint64 * 2)(), C.c_int(0)
+    assert lib.jsp_reduce_counters(devs, 2, per, tot, C.byref(via)) == 0 and list(tot) == [12, 1200]
+    assert via.value == 1, "RCCL all-reduce not used: " + lib.jsp_shard_last_error().decode()

@@ -82,3 +82,24 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert doc["n_gpus"] == 2 and doc["dry_run"] is True and doc["value"] is None
     assert len(doc["per_rank_frames"]) == 2 and doc["per_rank_frames"][0] == doc["per_rank_frames"][1] > 0
     assert doc["total_frames"] == sum(doc["per_rank_frames"])
+
+
+def test_native_stream_assignment_and_counter_reduce_without_a_gpu():
+    """The native (one process, several devices) form of the same sharding, jsp_assign_stream / jsp_reduce_counters of the C ABI:
+    stream i -> devices[i mod G]; the counters' sums are the host's when no device (hence no RCCL communicator) is there."""
+    import ctypes as C
+    from jsplayer_amd import _native as N
+    lib = N.lib()
+    devs = (C.c_int * 3)(4, 0, 2)
+    assert [lib.jsp_assign_stream(i, devs, 3) for i in range(7)] == [4, 0, 2, 4, 0, 2, 4]
+    for rank in range(3):      # the same rule as the one-process-per-GPU form (sharding.assign_streams)
+        assert [i for i in range(7) if lib.jsp_assign_stream(i, devs, 3) == devs[rank]] == assign_streams(7, 3, rank)
+    assert lib.jsp_assign_stream(-1, devs, 3) == -1 and lib.jsp_assign_stream(0, None, 3) == -1 and lib.jsp_assign_stream(0, devs, 0) == -1
+    per = (C.c_uint64 * 6)(10, 1000, 20, 2000, 12, 1200)
+    total, via = (C.c_uint64 * 2)(), C.c_int(7)
+    assert lib.jsp_reduce_counters(devs, 3, per, total, C.byref(via)) == 0
+    assert list(total) == [42, 4200]
+    import torch
+    if not torch.cuda.is_available():
+        assert via.value == 0 and lib.jsp_device_count() == 0
+    assert lib.jsp_reduce_counters(None, 3, per, total, None) != 0
