@@ -21,7 +21,8 @@
 //   * the frame-buffer pool of NUM_BUFFERS + 1 device frames that never hands out the buffer holding the
 //     previous frame (Manager.hx:114-118,424-443,470-477);
 //   * the DecompressI / DecompressP protocol with its identity test (Manager.hx:499-524) and
-//     frames_differ_significantly for key frames (Manager.hx:392-421) on the GPU (jsp_frames_differ).
+//     frames_differ_significantly for key frames (Manager.hx:392-421): its pixel loop comes with the decode (option
+//     "key_frame_compare", jsp_key_frame_differs / jsp_wait) — no pass of the player's own over the two frames.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -160,6 +161,8 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
     char dbuf[16];
     std::snprintf(dbuf, sizeof dbuf, "%d", depth);
     jsp_set_option(dec, "async_depth", dbuf);
+    std::snprintf(dbuf, sizeof dbuf, "%d", kInsignificantLines);
+    if (!quiet) jsp_set_option(dec, "key_frame_compare", dbuf);   // key frames are compared with the frame before them as they are decoded
     jsp_pool* pool = jsp_pool_create(device, clip.X, clip.Y, kNumBuffers + 1 + depth);
     if (!pool) { std::fprintf(stderr, "jsp_pool_create: %s\n", jsp_last_error()); jsp_codec_destroy(dec); return -1; }
     const int nbuf = jsp_pool_count(pool);
@@ -178,6 +181,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
         const int state = jsp_wait(dec, f.ticket, &shown_ptr, &signif);
         if (f.key) {
             if (state != JSP_ZERO_STATE) { if (!quiet) say("%zu key error %d %s\n", f.index, state, jsp_last_error()); return; }
+            const int compared = signif;             // (option "key_frame_compare": the key frame against the frame before it)
             signif = -1;
             if (!quiet) {   // frames_differ_significantly, Manager.hx:392-421
                 const uint8_t* src = clip.bytes.data() + clip.frames[f.index].first;
@@ -187,7 +191,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
                     const uint8_t* psrc = clip.bytes.data() + clip.frames[f.index - 1].first;
                     signif = !(clip.frames[f.index - 1].second == len && !std::memcmp(psrc, src, len));
                 } else if (!f.prev) signif = 1;
-                else jsp_frames_differ(jsp_pool_buffer(pool, f.slot), f.prev, (size_t)kInsignificantLines * clip.X, npx, &signif, nullptr);
+                else signif = compared;
             }
         } else {
             if (state != JSP_ZERO_STATE) { if (!quiet) say("%zu inter raised %s\n", f.index, jsp_last_error()); return; }
@@ -462,6 +466,11 @@ int main(int argc, char** argv) {
                                       (int)clip.palette.size(), 0);
     if (!dec) { std::fprintf(stderr, "jsp_codec_create: %s\n", jsp_last_error()); return 1; }
     jsp_preinit(dec, kInsignificantLines);
+    {
+        char row[16];
+        std::snprintf(row, sizeof row, "%d", kInsignificantLines);
+        jsp_set_option(dec, "key_frame_compare", row);
+    }
     jsp_pool* pool = jsp_pool_create(0, clip.X, clip.Y, kNumBuffers + 1);
     if (!pool) { std::fprintf(stderr, "jsp_pool_create: %s\n", jsp_last_error()); return 1; }
     const int nbuf = jsp_pool_count(pool);
@@ -499,7 +508,7 @@ int main(int argc, char** argv) {
             if (i == 0) signif = 1;
             else if (last_was_key && prev_key) signif = !(prev_key_len == len && !std::memcmp(prev_key, src, len));
             else if (!prev) signif = 1;
-            else jsp_frames_differ(dst, prev, (size_t)kInsignificantLines * clip.X, npx, &signif, nullptr);
+            else { signif = jsp_key_frame_differs(dec); if (signif < 0) signif = 1; }
             prev_key = src;
             prev_key_len = len;
         } else {

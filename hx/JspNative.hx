@@ -39,6 +39,7 @@ extern class JspNative {
     @:native("jsp_decompress_p_async") static function decompressPAsync(c:RawPointer<JspCodec>, src:RawConstPointer<UInt8>, n:SizeT, dst:RawPointer<cpp.Int32>, ticket:RawPointer<UInt64>):Int;
     @:native("jsp_wait")               static function wait(c:RawPointer<JspCodec>, ticket:UInt64, dataPnt:RawPointer<RawPointer<cpp.Int32>>, significant:RawPointer<Int>):Int;
     // frame pool in HBM (Manager.hx:114-118) and the two Manager passes that follow the codec
+    @:native("jsp_key_frame_differs")  static function keyFrameDiffers(c:RawPointer<JspCodec>):Int;
     @:native("jsp_device_count")       static function deviceCount():Int;
     @:native("jsp_assign_stream")      static function assignStream(streamIndex:Int, devices:RawPointer<Int>, ndev:Int):Int;
     @:native("jsp_reduce_counters")    static function reduceCounters(devices:RawPointer<Int>, ndev:Int, perDevice:RawPointer<cpp.UInt64>, total:RawPointer<cpp.UInt64>, viaRccl:RawPointer<Int>):Int;

@@ -149,12 +149,22 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       synchronous re-run.  one_launch: the same launch reads the bytes from the caller's pinned memory itself (no copy
  *       queued at all; the bus transfer then sits inside the kernel).  two_launches: a scout launch, then the decode
  *       launch it may veto (what larger frames always get).  Results do not depend on it. */
+/*   "key_frame_compare" = "off" (default) | "<first row>" : any codec; nothing may be in flight.  With a first row set (Manager uses
+ *       INSIGNIFICANT_LINES = 36), every key frame is also compared with the previous frame as the call found it — the pixel loop of
+ *       frames_differ_significantly (Manager.hx:413-419: any dst[i] != prev[i], i >= row * width) — without a pass of the caller's
+ *       own: ScreenPressor's host stage holds both pictures and answers itself (synchronous calls), otherwise the compare is queued on
+ *       the codec's stream right behind the frame's kernels (no extra wait; the frame is still in the Infinity Cache).  The answer:
+ *       jsp_key_frame_differs() after a synchronous DecompressI; *significant_changes of jsp_wait for an asynchronous one (a key
+ *       frame with no previous frame to be compared with counts as a change: Manager.hx:399-411).  Staged batches are not compared. */
 /*   "async_depth" = "1".."16" (default "4") : any codec.  Frames that may be in flight between jsp_decompress_*_async and
  *       jsp_wait. */
 int jsp_set_option(jsp_codec* c, const char* key, const char* value);
 /* Block until everything queued by this codec has finished (frames in flight on the asynchronous path stay to be
  * collected with jsp_wait). */
 int jsp_sync(jsp_codec* c);
+/* The last key frame decoded through jsp_decompress_i, or collected with jsp_wait, against the frame before it (option
+ * "key_frame_compare"): 1 differs, 0 does not, -1 nothing to compare with (no previous frame, the frame failed, option off). */
+int jsp_key_frame_differs(jsp_codec* c);
 /* Diagnostics (no reference counterpart): how often this codec instance took one of its slow paths since it was created.
  *   "async_reruns"       frames of the asynchronous per-frame calls that were re-run through the synchronous path (the GPU
  *                        alone could not settle the stream — short streams, end markers, skip codes without a previous

@@ -200,6 +200,13 @@ class _NativeCodec:
         if self._lib.jsp_sync(self._h) != 0:
             raise CodecError(N.last_error())
 
+    def KeyFrameDiffers(self) -> Optional[bool]:
+        """With option "key_frame_compare" = "<first row>": whether the last key frame (DecompressI, or the last one collected with
+        wait) differs from the frame before it from that row on — the pixel loop of Manager.frames_differ_significantly
+        (Manager.hx:413-419), worked out with the decode; None when there was nothing to compare with (jsp_key_frame_differs)."""
+        v = int(self._lib.jsp_key_frame_differs(self._h))
+        return None if v < 0 else bool(v)
+
     def counter(self, name: str) -> int:
         """How often this instance took one of its slow paths ("async_reruns", "lookback_fallbacks"): jsp_counter."""
         v = int(self._lib.jsp_counter(self._h, name.encode()))

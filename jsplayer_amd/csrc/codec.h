@@ -13,6 +13,7 @@ struct jsp_frame_in {
     size_t n;
     bool key;      // DecompressI (true) or DecompressP (false) semantics
     int32_t* dst;  // DEVICE pointer
+    const int32_t* caller_host_dst = nullptr;   // host-pointer mode: the caller's own buffer (`dst` is then an internal HBM frame)
 };
 
 // A staged batch: descriptor tables resident in HBM + the launch plan.
@@ -29,6 +30,9 @@ struct jsp_staged {
     std::vector<int> status, adopted, significant;
     std::string why;           // what made a frame fail, for jsp_last_error()
     std::vector<int> cleared;  // frame i ended with prevFrame == null (ScreenPressor RenewI + failure)
+    // key-frame compare (jsp_codec::key_compare_row): what the host stage already knows about frame i — 1 / 0: differs / does not from
+    // the previous frame at or after that row, -1: there was no previous frame; empty or -2: not known (the GPU pass answers)
+    std::vector<int> key_differs;
     // significance words written by the kernels (one per frame); -1 in `significant`
     // marks "take it from the device word"
     jsp::DeviceBuffer d_signif;
@@ -56,6 +60,8 @@ struct jsp_async_job {
     int status = 0, significant = 0;
     std::string why;                     // error text of a final non-zero status
     bool by_worker = false;              // the frame's host stage and launches run on a worker thread of the codec (async_by_workers)
+    int key_differs = -1;                // key-frame compare of this frame (jsp_wait hands it back as *significant_changes)
+    bool key_compare_queued = false;     // ... is being worked out by the pass queued behind the frame's kernels
 };
 
 struct jsp_codec {
@@ -79,6 +85,14 @@ struct jsp_codec {
     std::vector<jsp_async_job> jobs;
     int async_depth = 4;
     uint64_t next_ticket = 1, oldest_ticket = 1;   // [oldest_ticket, next_ticket) are in flight
+
+    // Key-frame compare (option "key_frame_compare"; Manager.hx:392-421, the pixel loop :413-419): with a first row set, every key
+    // frame is also compared with the previous frame as the call found it — by the host stage where it holds both pictures anyway,
+    // else by a pass queued on the codec's stream right behind the frame's kernels (no extra wait, the frame still in the Infinity Cache).
+    int key_compare_row = -1;                      // -1: off
+    int last_key_differs = -1;                     // jsp_key_frame_differs(): the last synchronous key frame (1 / 0; -1: nothing to compare with / off)
+    jsp::DeviceBuffer d_keyflag;                   // one word per frame in flight
+    jsp::PinnedBuffer h_keyflag;
 
     virtual ~jsp_codec();
     virtual int preinit(int lines) = 0;
@@ -125,6 +139,10 @@ struct jsp_codec {
 
     void init_device(int device_id);
     void activate();
+    // queues the compare of key frame `dst` with `prev` (rows from key_compare_row on) behind what is queued on `stream`; the answer
+    // lands in word `slot` of h_keyflag (valid once the stream has got there).  Both buffers exist from the moment the option is set.
+    void queue_key_compare(const int32_t* dst, const int32_t* prev, int slot);
+    int read_key_compare(int slot) const { return static_cast<const uint32_t*>(h_keyflag.p)[slot] ? 1 : 0; }
 };
 
 // Factories (one per codec family).

@@ -90,6 +90,16 @@ __global__ __launch_bounds__(256) void pool_probe_kernel(uint32_t* const* __rest
 }  // namespace
 
 namespace jsp {
+// The pixel loop of frames_differ_significantly (Manager.hx:413-419), queued: *d_flag (zeroed here, on the stream) is OR-ed with 1 when
+// a[i] != b[i] for some first_pixel <= i < npixels.  Asynchronous on `stream`.
+void launch_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, size_t npixels, uint32_t* d_flag, hipStream_t stream) {
+    JSP_HIP(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream));
+    if (first_pixel >= npixels) return;
+    const size_t count = npixels - first_pixel;
+    const int grid = (int)std::min<size_t>((count / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(frames_differ_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(a), reinterpret_cast<const uint32_t*>(b),
+                       first_pixel, npixels, d_flag);
+}
 // GB/s of pool_probe_kernel over the `nframes` frames of X x Y pixels whose addresses are in the device table `d_frames` (X, Y
 // multiples of 4, 16-byte aligned frames); leaves the frames filled with `fill`.  Synchronous.
 double pool_store_rate(uint32_t* const* d_frames, int nframes, int X, int Y, uint32_t fill) {

@@ -88,6 +88,12 @@ struct jsp_pool {
 namespace jsp {
 double pool_store_rate(uint32_t* const* d_frames, int nframes, int X, int Y, uint32_t fill);
 double pool_fill_rate(uint32_t* slab, size_t nbytes);
+void launch_frames_differ(const int32_t* a, const int32_t* b, size_t first_pixel, size_t npixels, uint32_t* d_flag, hipStream_t stream);
+}
+void jsp_codec::queue_key_compare(const int32_t* dst, const int32_t* prev, int slot) {
+    uint32_t* d = static_cast<uint32_t*>(d_keyflag.p) + slot;
+    jsp::launch_frames_differ(dst, prev, (size_t)key_compare_row * (size_t)X, (size_t)X * (size_t)Y, d, stream);
+    JSP_HIP(hipMemcpyAsync(static_cast<uint32_t*>(h_keyflag.p) + slot, d, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 }
 
 namespace {
@@ -135,19 +141,28 @@ int decompress_one(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, boo
         int32_t* d0 = static_cast<int32_t*>(c->compat[0].p);
         int32_t* d1 = static_cast<int32_t*>(c->compat[1].p);
         f.dst = (c->prev_dev == d0) ? d1 : d0;
+        f.caller_host_dst = dst;
         if (c->may_leave_pixels(f))
             JSP_HIP(hipMemcpyAsync(f.dst, dst, npx * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
     std::vector<jsp_frame_in> frames{f};
+    const int32_t* prev_before = c->prev_dev;          // what a key frame is compared with (Manager.hx:470, 499-504)
     jsp_staged* st = c->stage(frames, c->scratch.get());
     st->device = c->device;
     if (st != c->scratch.get()) c->scratch.reset(st);
     st->decode(c->stream);
+    int key_known = -1;
+    bool key_queued = false;
+    if (key && c->key_compare_row >= 0 && st->status[0] == JSP_ZERO_STATE && st->adopted[0] && prev_before) {
+        key_known = st->key_differs.empty() ? -2 : st->key_differs[0];
+        if (key_known == -2) { c->queue_key_compare(f.dst, prev_before, 0); key_queued = true; }
+    }
     // the reference paints dst in place, adopted or not: hand back whatever was written
     if (mode == 2 && (st->info.units_coded || st->info.units_copied))
         JSP_HIP(hipMemcpyAsync(dst, f.dst, npx * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     JSP_HIP(hipStreamSynchronize(c->stream));
     st->finish_results();
+    if (key) c->last_key_differs = key_queued ? c->read_key_compare(0) : key_known;
     if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
     if (st->adopted[0]) c->prev_caller = dst;
     if (data_pnt) *data_pnt = c->prev_caller;
@@ -397,6 +412,24 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream) {
 
 int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
     if (!c || !key || !value) return -1;
+    if (std::strcmp(key, "key_frame_compare") == 0) {
+        if (c->next_ticket != c->oldest_ticket) return -1;
+        int row = -1;
+        if (std::strcmp(value, "off") != 0) {
+            char* end = nullptr;
+            const long v = std::strtol(value, &end, 10);
+            if (end == value || *end || v < 0 || v > (1 << 24)) return -1;
+            row = (int)v;
+        }
+        return guarded([&] {
+            c->activate();
+            c->worker_drain();
+            if (row >= 0) { c->d_keyflag.reserve(16 * sizeof(uint32_t)); c->h_keyflag.reserve(16 * sizeof(uint32_t)); }
+            c->key_compare_row = row;
+            c->last_key_differs = -1;
+            return 0;
+        }, -1);
+    }
     if (std::strcmp(key, "async_depth") == 0) {
         char* end = nullptr;
         const long v = std::strtol(value, &end, 10);
@@ -406,6 +439,8 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
     }
     return c->set_option(key, value);
 }
+
+int jsp_key_frame_differs(jsp_codec* c) { return c ? c->last_key_differs : -1; }
 
 long long jsp_counter(jsp_codec* c, const char* name) {
     if (!c || !name) return -1;
@@ -431,6 +466,8 @@ void redo_from(jsp_codec* c, uint64_t from) {
         int sig = 0;
         j.status = decompress_one(c, j.frame.src, j.frame.n, j.frame.dst, j.frame.key, &data, &sig);
         j.significant = sig;
+        j.key_differs = c->last_key_differs;
+        j.key_compare_queued = false;
         if (j.status != JSP_ZERO_STATE) j.why = last_error_slot();
         j.prev_caller_after = c->prev_caller;
         j.redone = true;
@@ -453,6 +490,7 @@ void settle(jsp_codec* c, uint64_t t) {
         // what the frame really did to the previous frame (frames are settled in submission order)
         if (!j.st->cleared.empty() && j.st->cleared[0]) c->settled_prev = nullptr;
         if (j.st->adopted[0]) c->settled_prev = j.frame.dst;
+        if (j.key_compare_queued) { j.key_differs = c->read_key_compare((int)(t % c->async_depth)); j.key_compare_queued = false; }
         j.prev_caller_after = c->settled_prev;
         if (t + 1 == c->next_ticket) c->prev_caller = c->settled_prev;   // (nothing submitted behind it: the prediction gives way)
         j.settled = true;
@@ -461,6 +499,7 @@ void settle(jsp_codec* c, uint64_t t) {
     JSP_HIP(hipEventSynchronize(j.done));
     j.st->finish_results();
     if (!c->async_finish(j.st.get())) { redo_from(c, t); return; }
+    if (j.key_compare_queued) { j.key_differs = c->read_key_compare((int)(t % c->async_depth)); j.key_compare_queued = false; }
     j.status = j.st->status[0];
     j.significant = j.st->significant[0] < 0 ? 0 : j.st->significant[0];
     if (j.status != JSP_ZERO_STATE) j.why = j.st->why.empty() ? "decode aborted: the reference raises on this stream" : j.st->why;
@@ -487,6 +526,8 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
         j.prev_dev_before = c->prev_dev;
         j.redone = j.settled = false;
         j.by_worker = true;
+        j.key_differs = -1;
+        j.key_compare_queued = false;
         j.why.clear();
         c->worker_submit(j);
         j.prev_caller_after = c->prev_caller;
@@ -502,10 +543,17 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
     j.prev_dev_before = c->prev_dev;
     j.redone = j.settled = false;
     j.why.clear();
+    j.key_differs = -1;
+    j.key_compare_queued = false;
     jsp_staged* st = c->stage_async(j.frame, j.st.get());
     st->device = c->device;
     if (st != j.st.get()) j.st.reset(st);
     st->decode(c->stream);
+    if (key && c->key_compare_row >= 0 && st->status[0] == JSP_ZERO_STATE && st->adopted[0] && j.prev_dev_before) {
+        // (a frame the GPU may still veto leaves `dst` untouched and is re-run through the synchronous path, which compares again)
+        j.key_differs = st->key_differs.empty() ? -2 : st->key_differs[0];
+        if (j.key_differs == -2) { c->queue_key_compare(dst, j.prev_dev_before, (int)(c->next_ticket % c->async_depth)); j.key_compare_queued = true; }
+    }
     JSP_HIP(hipEventRecord(j.done, c->stream));
     if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
     if (st->adopted[0]) c->prev_caller = dst;
@@ -543,6 +591,11 @@ int wait_ticket(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* signific
     j.ticket = 0;
     if (data_pnt) *data_pnt = j.prev_caller_after;
     if (significant_changes) *significant_changes = j.significant;
+    if (j.frame.key) {
+        c->last_key_differs = c->key_compare_row >= 0 && j.status == JSP_ZERO_STATE ? j.key_differs : -1;
+        // a key frame with nothing to be compared with counts as a change (Manager.hx:399-411: the first frame, no previous frame)
+        if (c->key_compare_row >= 0 && significant_changes) *significant_changes = j.key_differs != 0 ? 1 : 0;
+    }
     return j.status;
 }
 }  // namespace

@@ -13,6 +13,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -94,6 +95,7 @@ struct FrameOut {
     uint64_t motion_pixels = 0;      // Inter: part of prev_pixels that is motion-compensated
     uint64_t stream_bytes = 0;
     bool literalised = false;        // Inter: literalise_motion() has been applied
+    int key_differs = -2;            // key frames with HostDecoder::set_key_compare_row: 1 / 0 against the picture before, -1 there was none; -2 not worked out
     const char* error = nullptr;
     // Back to the empty state WITHOUT giving the tables' memory back: a stream's frames need about the same room one
     // after the other, and megabyte-sized allocations per frame (page faults, allocator locks shared by the host
@@ -101,7 +103,7 @@ struct FrameOut {
     void reset() {
         kind = FrameKind::None; status = 0; adopted = prev_cleared = significant = false; flat_colour = 0;
         runs.clear(); stream_runs = 0; row_run.clear(); seeds.clear(); band_rows = 0; span_px = 0; tile_idx.clear(); left.clear();
-        blocks.clear(); payload.clear(); prev_pixels = data_pixels = motion_pixels = stream_bytes = 0; literalised = false; error = nullptr;
+        blocks.clear(); payload.clear(); prev_pixels = data_pixels = motion_pixels = stream_bytes = 0; literalised = false; key_differs = -2; error = nullptr;
     }
 };
 
@@ -128,6 +130,17 @@ public:
     // ---- decoding the GOPs of a batch side by side (decode_frames below) ----
     HostDecoder(HostDecoder&&) = default;
     HostDecoder& operator=(HostDecoder&&) = default;
+    // The ONE place where an inter frame reads its destination before writing it (ScreenPressor.hx:436-449): a data rectangle in
+    // block column 0 whose predictor looks "left" / "above-left" of x = 0 reads, through the linear index, the LAST pixel of the row
+    // above — a block this frame has not reached yet, i.e. whatever the caller's buffer held.  `column()` answers with column X - 1
+    // of the destination as it stands before the frame (Y entries), or null when that is not known (the decoder then reads its own
+    // shadow of the position: the picture two frames back, what a caller rotating two buffers would have there).  Asked lazily,
+    // at most once per frame.
+    void set_destination_column(std::function<const int32_t*()> column) { dst_column_ = std::move(column); }
+    void last_column(int32_t* out) const;                       // column X - 1 of the picture the last decoded frame left
+    // Key frames are also compared with the picture before them, rows from `row` on (the pixel loop of Manager.hx:413-419): the stage
+    // holds both pictures.  Only meaningful on the decoder that decoded the frame before (the stream's own, frame after frame).  -1: off.
+    void set_key_compare_row(int row) { key_compare_row_ = row; }
     int pinned_version() const { return version_; }            // 0: no coded key frame has chosen the entropy coder yet
     bool pin_version(int version) { return ec_ ? version_ == version : init_entropy(version); }
     void adopt_settings(const HostDecoder& o) {                 // Preinit and key-frame layout of the stream's decoder
@@ -137,6 +150,7 @@ public:
     }
 
 private:
+    void note_key_compare(FrameOut& out, bool had_prev) const;
     int32_t literal();
     bool init_entropy(int version);
     void renew_i();
@@ -154,6 +168,8 @@ private:
     std::vector<int32_t> bts_;
     std::vector<uint8_t> stale_;     // per 16x16 block: shadow_[cur_] may differ from shadow_[1-cur_] there
     int stall_ = 0;
+    std::function<const int32_t*()> dst_column_;
+    int key_compare_row_ = -1;
     int band_rows_ = 0, span_px_ = 0;
     std::vector<IRun> tiled_;        // scratch of the tile regrouping (kept: no per-frame allocation)
     std::vector<uint32_t> cursor_;
@@ -169,11 +185,18 @@ private:
 // state that run would leave it in (the decoder that took the last group takes its place).  A group whose key frame does
 // not decode (its failure leaves older state showing through) is re-run in order.  `literalise`: inter frames that move at
 // most a quarter of their pixels get literalise_motion() applied (what the staged batch's group launches need).
-struct HostFrame { const uint8_t* src; size_t n; bool key; };
+struct HostFrame { const uint8_t* src; size_t n; bool key; const void* dst = nullptr; const int32_t* dst_host = nullptr; };
+// What the caller's destination buffers hold in their last column (see HostDecoder::set_destination_column): asked before a frame is
+// decoded into `dst`, told after.  Implemented by the codec (which knows the buffers); may be called from several host threads.
+struct DstColumns {
+    virtual ~DstColumns() = default;
+    virtual const int32_t* before(const HostFrame& f) = 0;
+    virtual void after(const HostFrame& f, const HostDecoder& d, const FrameOut& out) = 0;
+};
 bool starts_group(const HostFrame& f);   // a coded key frame
-void decode_single(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise);   // one frame through decoder `d` (what decode_frames does per frame)
+void decode_single(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise, DstColumns* cols = nullptr);   // one frame through decoder `d` (what decode_frames does per frame)
 void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<HostDecoder>>& spare, const HostFrame* frames,
-                   int count, FrameOut* outs, int threads, bool literalise);
+                   int count, FrameOut* outs, int threads, bool literalise, DstColumns* cols = nullptr);
 
 // ---- kernels (sp_kernels.hip), asynchronous on `stream` -------------------------------------
 struct IFrameArgs {    // one per frame of an intra launch (grid.x = frame, grid.y = band)

@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 
 #include "codec.h"
@@ -66,8 +67,43 @@ struct SpStaged : jsp_staged {
 
 std::atomic<int> g_sp_async_streams{0};   // ScreenPressor codec instances of this process whose asynchronous calls run on worker threads
 
-struct SpCodec : jsp_codec {
+struct SpCodec : jsp_codec, DstColumns {
     HostDecoder host;
+    // ---- what the caller's frame buffers hold in their last column (DstColumns) ------------------------------------------------
+    // The reference's inter frames read ONE kind of pixel from their destination before writing it (HostDecoder::
+    // set_destination_column); to hand back what the reference hands back whatever the caller's buffer rotation, the codec remembers
+    // the last column of every picture it has decoded into a buffer, and fetches the column of a buffer it has never written
+    // (the caller's own content) from the device the first time it is asked for.  4 bytes per row and buffer.
+    std::mutex col_mu;
+    std::unordered_map<const void*, std::vector<int32_t>> last_col;
+    const int32_t* before(const HostFrame& f) override {
+        std::lock_guard<std::mutex> lk(col_mu);
+        std::vector<int32_t>& col = last_col[f.dst_host ? static_cast<const void*>(f.dst_host) : f.dst];
+        if (f.dst_host) {                              // host-pointer mode: the caller's buffer is right there (read afresh: it is the caller's to change)
+            col.resize((size_t)Y);
+            for (int y = 0; y < Y; ++y) col[y] = f.dst_host[(size_t)y * X + X - 1];
+            return col.data();
+        }
+        if (col.size() != (size_t)Y) {                 // never decoded into by this codec: the caller's content, as it stands in HBM
+            col.assign((size_t)Y, 0);
+            if (hipSetDevice(device) != hipSuccess ||
+                hipMemcpy2D(col.data(), sizeof(int32_t), static_cast<const int32_t*>(f.dst) + (X - 1), sizeof(int32_t) * (size_t)X, sizeof(int32_t), (size_t)Y,
+                            hipMemcpyDeviceToHost) != hipSuccess) {
+                (void)hipGetLastError();
+                col.clear();
+                return nullptr;                        // (not known: the decoder reads its own shadow of the position)
+            }
+        }
+        return col.data();
+    }
+    void after(const HostFrame& f, const HostDecoder& d, const FrameOut& out) override {
+        if (!out.adopted || f.dst_host) return;        // nothing was written there (host mode: the buffer is read afresh every time)
+        std::lock_guard<std::mutex> lk(col_mu);
+        if (last_col.size() > 8192) last_col.clear();  // (a caller that keeps handing in new buffers: forget, fetch again when asked)
+        std::vector<int32_t>& col = last_col[f.dst];
+        col.resize((size_t)Y);
+        d.last_column(col.data());
+    }
     std::vector<FrameOut> outs;                          // what the host stage says about the frames in hand (their tables keep their memory)
     std::vector<std::unique_ptr<HostDecoder>> spare;     // decoders for the groups of pictures of a batch decoded side by side
     int opt_host_threads = 0;                            // 0 = auto
@@ -179,6 +215,7 @@ struct SpCodec : jsp_codec {
         std::string failed;
         try {
             int32_t* prev = g.have_prev ? g.prev : j.prev_dev_before;
+            const int32_t* prev_in = prev;             // what a key frame is compared with (option "key_frame_compare")
             jsp_staged* got = stage_impl(std::vector<jsp_frame_in>{j.frame}, st, g.dec, &prev, &outs_local);
             if (got != j.st.get()) j.st.reset(got);
             if (!g.first_done && g.own && j.st->status[0] != JSP_ZERO_STATE) {
@@ -191,6 +228,7 @@ struct SpCodec : jsp_codec {
                 }
                 g.dec = b->dec;
                 prev = b->have_prev ? b->prev : j.prev_dev_before;   // (that group is through: what it really left)
+                prev_in = prev;
                 got = stage_impl(std::vector<jsp_frame_in>{j.frame}, j.st.get(), g.dec, &prev, &outs_local);
                 if (got != j.st.get()) j.st.reset(got);
             } else if (!g.first_done && g.before) {
@@ -203,6 +241,10 @@ struct SpCodec : jsp_codec {
             g.have_prev = true;
             j.st->device = device;
             j.st->decode(stream);
+            if (j.frame.key && key_compare_row >= 0 && j.st->status[0] == JSP_ZERO_STATE && j.st->adopted[0] && prev_in) {
+                queue_key_compare(j.frame.dst, prev_in, (int)(&j - jobs.data()));
+                j.key_compare_queued = true;
+            }
             JSP_HIP(hipEventRecord(j.done, stream));
         } catch (const std::exception& e) {
             failed = e.what();
@@ -409,6 +451,7 @@ struct SpCodec : jsp_codec {
         st->adopted.assign(nf, 0);
         st->significant.assign(nf, 0);
         st->cleared.assign(nf, 0);
+        st->key_differs.assign(nf, -2);
         st->info = jsp_staged_info{};
 
         auto &runs = st->runs;
@@ -427,6 +470,9 @@ struct SpCodec : jsp_codec {
         const bool tiles = iframe_tiles_ok(st->geo);   // key frames as independent tiles (needs aligned buffers)
         if (tiles && g.Y > 4096 && (band_rows <= 0 || band_rows > 4096)) band_rows = 4096;   // a tile's row index lives in LDS
         host.set_iframe_layout(band_rows, tiles ? iframe_tile_span(st->geo) : 0);
+        // the key-frame compare by the host stage: only where this decoder also decoded the frame before — the stream's own decoder
+        // taking one frame at a time (a group of pictures on a decoder of its own does not hold the picture before its key frame)
+        host.set_key_compare_row(!one && nf == 1 ? key_compare_row : -1);
         // Inter frames are fused per launch when the batch has several of them; a frame that moves more
         // than a quarter of its pixels keeps its motion blocks (literal pixels for them would rival the
         // frame in size) and gets a launch of its own.
@@ -435,9 +481,14 @@ struct SpCodec : jsp_codec {
         // The host stage runs over the batch in waves: up to `threads` groups of pictures (a coded key frame and what follows it)
         // side by side, at most 64 frames, then their tables are taken into the batch in stream order.
         std::vector<HostFrame> hf(nf);
-        for (int i = 0; i < nf; ++i) hf[i] = HostFrame{frames[i].src, frames[i].n, frames[i].key};
+        for (int i = 0; i < nf; ++i) hf[i] = HostFrame{frames[i].src, frames[i].n, frames[i].key, frames[i].dst, frames[i].caller_host_dst};
         int threads = opt_host_threads;
         if (threads <= 0) { threads = usable_cpus(); threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads); }
+        if (nf > 1) {   // a buffer used twice in the batch: what it holds when its second frame is decoded is what the first left — in order only
+            std::unordered_set<const void*> seen;
+            for (const auto& f : frames)
+                if (!seen.insert(f.dst).second) { threads = 1; break; }
+        }
         for (int w0 = 0; w0 < nf;) {
             int w1 = w0 + 1, groups = 1;
             while (w1 < nf && w1 - w0 < 64) {
@@ -445,8 +496,8 @@ struct SpCodec : jsp_codec {
                 ++w1;
             }
             if ((int)outs.size() < w1 - w0) outs.resize(w1 - w0);
-            if (one) decode_single(host, hf[w0], outs[0], fuse_inter);
-            else decode_frames(host, spare, hf.data() + w0, w1 - w0, outs.data(), threads, fuse_inter);
+            if (one) decode_single(host, hf[w0], outs[0], fuse_inter, this);
+            else decode_frames(host, spare, hf.data() + w0, w1 - w0, outs.data(), threads, fuse_inter, this);
         for (int i = w0; i < w1; ++i) {
             const jsp_frame_in& f = frames[i];
             FrameOut& fo = outs[i - w0];
@@ -454,6 +505,7 @@ struct SpCodec : jsp_codec {
             st->adopted[i] = fo.adopted ? 1 : 0;
             st->significant[i] = fo.significant ? 1 : 0;
             st->cleared[i] = fo.prev_cleared ? 1 : 0;
+            st->key_differs[i] = fo.key_differs;
             if (fo.status != JSP_ZERO_STATE && fo.error) { set_error("%s", fo.error); st->why = fo.error; }
             if (fo.prev_cleared) prev_dev = nullptr;
             st->info.stream_bytes += fo.stream_bytes;

@@ -86,6 +86,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             last_flat_ = true;
             decoded_i_ = true;
             cur_ ^= 1;
+            note_key_compare(out, had_prev);
             std::fill(stale_.begin(), stale_.end(), 1);
             return;
         }
@@ -298,6 +299,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
         has_prev_ = true;
         decoded_i_ = true;
         cur_ ^= 1;
+        note_key_compare(out, had_prev);
         std::fill(stale_.begin(), stale_.end(), 1);
     } catch (const DecodeAbort& a) {
         out.reset();
@@ -347,6 +349,17 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
         out.payload.clear();
         auto rdp = [&](long i) -> int32_t { return (i >= 0 && i < end) ? prev[i] : 0; };
         auto rdd = [&](long i) -> int32_t { return (i >= 0 && i < end) ? dst[i] : 0; };
+        // a read "left of x = 0": linear index i = pixel (X - 1, ry).  Rows of the block row above are this frame's already; rows of
+        // the current block row belong to a block not decoded yet: what the caller's buffer holds (set_destination_column)
+        const int32_t* dst_col = nullptr;
+        bool dst_col_asked = false;
+        auto wrapped = [&](long i, int ry, int y16) -> int32_t {
+            if (ry >= y16 && g_.nbx > 1 && dst_column_) {
+                if (!dst_col_asked) { dst_col = dst_column_(); dst_col_asked = true; }
+                if (dst_col) return dst_col[ry];
+            }
+            return rdd(i);
+        };
         auto need_prev = [&] { if (!has_prev_) throw DecodeAbort{"block copied from a previous frame that does not exist"}; };
         int32_t clr = 0;
         cx_ = cx1_ = 0;
@@ -420,19 +433,20 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
                             if (y >= y2) throw DecodeAbort{"run crosses the end of its rectangle"};
                             const long di = (long)y * X + x;
                             switch (pt) {
-                                case 1: clr = rdd(di - 1); break;
+                                case 1: clr = x == 0 ? wrapped(di - 1, y - 1, y16) : rdd(di - 1); break;
                                 case 2: clr = rdd(di - X); break;
                                 case 3: need_prev(); clr = rdp(di); break;
                                 case 4: {
                                     const long l = di - 1, u = di - X, ul = di - X - 1;
                                     if (l < 0 || u < 0 || ul < 0) { clr = 0; break; }  // NaN bytes
-                                    const uint32_t a = (uint32_t)dst[l], b = (uint32_t)dst[u], cc = (uint32_t)dst[ul];
+                                    const uint32_t a = (uint32_t)(x == 0 ? wrapped(l, y - 1, y16) : dst[l]), b = (uint32_t)dst[u],
+                                                   cc = (uint32_t)(x == 0 ? wrapped(ul, y - 2, y16) : dst[ul]);
                                     clr = (int32_t)((((a & 0xFF) + (b & 0xFF) - (cc & 0xFF)) & 0xFF) |
                                                     ((((a >> 8) & 0xFF) + ((b >> 8) & 0xFF) - ((cc >> 8) & 0xFF)) & 0xFF) << 8 |
                                                     ((((a >> 16) & 0xFF) + ((b >> 16) & 0xFF) - ((cc >> 16) & 0xFF)) & 0xFF) << 16);
                                     break;
                                 }
-                                case 5: clr = rdd(di - X - 1); break;
+                                case 5: clr = x == 0 ? wrapped(di - X - 1, y - 2, y16) : rdd(di - X - 1); break;
                                 default: break;
                             }
                             dst[di] = clr;  // inside the frame: the rectangle was checked above
@@ -461,6 +475,20 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
         out.error = a.why;
         std::fill(stale_.begin(), stale_.end(), 1);   // the frame being written is in an unknown state
     }
+}
+
+// (after a key frame has decoded and the shadows have swapped: shadow_[cur_ ^ 1] is the new picture, shadow_[cur_] the one before it,
+// complete — it is what the inter frames of the group before read)
+void HostDecoder::note_key_compare(FrameOut& out, bool had_prev) const {
+    if (key_compare_row_ < 0) return;
+    if (!had_prev) { out.key_differs = -1; return; }
+    const size_t first = (size_t)key_compare_row_ * (size_t)g_.X, end = (size_t)g_.X * (size_t)g_.Y;
+    out.key_differs = first < end && std::memcmp(shadow_[cur_ ^ 1].data() + first, shadow_[cur_].data() + first, (end - first) * sizeof(int32_t)) != 0 ? 1 : 0;
+}
+
+void HostDecoder::last_column(int32_t* out) const {
+    const int32_t* pic = shadow_[cur_ ^ 1].data();            // (the decoders swap after a frame: this is the picture just decoded)
+    for (int y = 0; y < g_.Y; ++y) out[y] = pic[(size_t)y * g_.X + g_.X - 1];
 }
 
 uint32_t link_group_tables(PBlock* blocks, PGroupFrame* gframes, int nframes, int nbx, int nby, int chunk) {
@@ -512,9 +540,13 @@ void HostDecoder::literalise_motion(FrameOut& out) const {
 
 // ---- groups of pictures side by side ---------------------------------------------------------------------------------
 namespace {
-void decode_one(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise) {
+void decode_one(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise, DstColumns* cols) {
+    if (cols && !f.key && (f.dst || f.dst_host)) d.set_destination_column([cols, &f] { return cols->before(f); });
+    else d.set_destination_column(nullptr);
     if (f.key) d.decode_i(f.src, f.n, out);
     else d.decode_p(f.src, f.n, out);
+    d.set_destination_column(nullptr);
+    if (cols && (f.dst || f.dst_host)) cols->after(f, d, out);
     const Geometry& g = d.geo();
     if (literalise && out.kind == FrameKind::Inter && out.motion_pixels * 4 <= (uint64_t)g.X * g.Y) {
         d.literalise_motion(out);
@@ -522,11 +554,11 @@ void decode_one(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literali
     }
 }
 }  // namespace
-void decode_single(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise) { decode_one(d, f, out, literalise); }
+void decode_single(HostDecoder& d, const HostFrame& f, FrameOut& out, bool literalise, DstColumns* cols) { decode_one(d, f, out, literalise, cols); }
 bool starts_group(const HostFrame& f) { return f.key && f.n > 0 && (f.src[0] & 0xF) == 2; }   // a CODED key frame (flat ones renew nothing)
 
 void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<HostDecoder>>& spare, const HostFrame* frames,
-                   int count, FrameOut* outs, int threads, bool literalise) {
+                   int count, FrameOut* outs, int threads, bool literalise, DstColumns* cols) {
     // groups: [0, first coded key frame) continues whatever the stream decoder holds; then one group per coded key frame
     std::vector<int> begin;
     begin.push_back(0);
@@ -540,7 +572,7 @@ void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<Host
         if (starts_group(frames[i])) version = (frames[i].src[0] >> 4) + 1;
     const bool side_by_side = threads > 1 && ngroups > 1 && version >= 2 && version <= 4;
     if (!side_by_side) {
-        for (int i = 0; i < count; ++i) decode_one(stream_decoder, frames[i], outs[i], literalise);
+        for (int i = 0; i < count; ++i) decode_one(stream_decoder, frames[i], outs[i], literalise, cols);
         return;
     }
     const Geometry g = stream_decoder.geo();
@@ -558,7 +590,7 @@ void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<Host
         if (!usable[grp]) return;
         HostDecoder& d = decoder_of(grp);
         try {
-            for (int i = begin[grp]; i < begin[grp + 1]; ++i) decode_one(d, frames[i], outs[i], literalise);
+            for (int i = begin[grp]; i < begin[grp + 1]; ++i) decode_one(d, frames[i], outs[i], literalise, cols);
         } catch (...) {            // (out of memory on a thread of its own must not end the process: the group is decoded again, in order)
             if (grp > 0) usable[grp] = 0;
             else throw;
@@ -594,7 +626,7 @@ void decode_frames(HostDecoder& stream_decoder, std::vector<std::unique_ptr<Host
         last_good = grp;
     }
     if (last_good > 0) std::swap(stream_decoder, *spare[last_good - 1]);   // the stream goes on from the last group that stands
-    for (int i = begin[last_good + 1]; i < count; ++i) decode_one(stream_decoder, frames[i], outs[i], literalise);
+    for (int i = begin[last_good + 1]; i < count; ++i) decode_one(stream_decoder, frames[i], outs[i], literalise, cols);
 }
 
 }  // namespace jsp::sp

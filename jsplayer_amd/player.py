@@ -54,6 +54,11 @@ class Manager:
         self.buffers = [alloc(vi.X * vi.Y) for _ in range(num_buffers + 1)]
         self.holds: List[Optional[range]] = [None] * len(self.buffers)  # frames each slot currently shows
         self.decoder.Preinit(INSIGNIFICANT_LINES)
+        # HIP codecs compare a key frame with the frame before it while they decode it (option "key_frame_compare"): no pass of the
+        # Manager's own over the two frames (Manager.hx:413-419)
+        self._fused_compare = hasattr(self.decoder, "KeyFrameDiffers")
+        if self._fused_compare:
+            self.decoder.set_option("key_frame_compare", str(INSIGNIFICANT_LINES))
         self.next_frame_to_decode = 0
         self.frame_of_interest = 0
         self.log: List[DecodedFrame] = []
@@ -101,6 +106,9 @@ class Manager:
                     sig = prev_key_bytes != frame
                 elif prev is None:
                     sig = True
+                elif self._fused_compare:
+                    sig = dec.KeyFrameDiffers()
+                    sig = True if sig is None else sig
                 else:
                     sig = _differ(new, prev, INSIGNIFICANT_LINES * self.vi.X)
             out = DecodedFrame(index, True, free, sig, state)
@@ -158,6 +166,9 @@ class Manager:
                         sig = prev_blob != blob
                     elif prev is None:
                         sig = True
+                    elif self._fused_compare:
+                        sig = dec.KeyFrameDiffers()      # (of the key frame just collected)
+                        sig = True if sig is None else sig
                     else:
                         sig = _differ(self.buffers[slot], prev, INSIGNIFICANT_LINES * self.vi.X)
                 out = DecodedFrame(index, True, slot, sig, state)

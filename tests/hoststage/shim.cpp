@@ -11,6 +11,7 @@
 using namespace jsp::sp;
 
 struct Shim {
+    std::vector<int32_t> dst_column;                     // hs_set_dst_column: what the destination holds in its last column (empty: not known)
     HostDecoder host;
     FrameOut out;
     std::vector<FrameOut> outs;                          // hs_decode_batch
@@ -37,8 +38,13 @@ void hs_fetch_seeds(void* p, uint32_t* seeds) {
     if (seeds && !o.seeds.empty()) std::memcpy(seeds, o.seeds.data(), o.seeds.size() * 4);
 }
 // returns status; fills meta: [kind, adopted, significant, prev_cleared, nruns, nrows, nblocks, npayload, flat_colour]
+void hs_set_dst_column(void* p, const int32_t* col, int n) {
+    auto* s = (Shim*)p;
+    s->dst_column.assign(col, col + (col ? n : 0));
+}
 int hs_decode(void* p, int key, const uint8_t* src, size_t n, uint64_t* meta) {
     auto* s = (Shim*)p;
+    s->host.set_destination_column([s]() -> const int32_t* { return s->dst_column.empty() ? nullptr : s->dst_column.data(); });
     if (key) s->host.decode_i(src, n, s->out); else s->host.decode_p(src, n, s->out);
     const FrameOut& o = s->out;
     meta[0] = (uint64_t)o.kind; meta[1] = o.adopted; meta[2] = o.significant; meta[3] = o.prev_cleared;

@@ -43,6 +43,7 @@ def lib():
         L.hs_seed_words.restype = C.c_size_t
         L.hs_seed_words.argtypes = [C.c_void_p]
         L.hs_fetch_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        L.hs_set_dst_column.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -80,6 +81,15 @@ class HostStage:
             d["literalised"] = bool(meta[12])
             outs.append(d)
         return outs
+
+    def set_dst_column(self, column):
+        """What the destination of the following frames holds in its last column (int32 per row; None: not known) —
+        HostDecoder::set_destination_column."""
+        if column is None:
+            self.L.hs_set_dst_column(self.h, None, 0)
+        else:
+            col = np.ascontiguousarray(column, dtype=np.int32)
+            self.L.hs_set_dst_column(self.h, col.ctypes.data, int(col.size))
 
     def decode(self, key: bool, src: bytes):
         meta = np.zeros(12, dtype=np.uint64)

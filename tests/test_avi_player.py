@@ -393,3 +393,70 @@ def test_cpp_player_shards_streams_over_devices(tmp_path):
     tot, via = (C.c_uint64 * 2)(), C.c_int(0)
     assert lib.jsp_reduce_counters(devs, 2, per, tot, C.byref(via)) == 0 and list(tot) == [12, 1200]
     assert via.value == 1, "RCCL all-reduce not used: " + lib.jsp_shard_last_error().decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["play", "pipelined", "pipelined_workers"])
+def test_key_frames_compared_with_the_frame_before_them_while_they_decode(how):
+    """Manager.frames_differ_significantly (Manager.hx:392-421) without a pass of the Manager's own: option "key_frame_compare"
+    has the codec compare every key frame with the frame before it as it decodes it (ScreenPressor's host stage holds both
+    pictures; otherwise a compare queued behind the frame's kernels).  A clip built for the pixel loop: a key frame that repeats
+    the picture before it (behind an inter frame, so the byte shortcut does not apply) -> no change; a key frame that differs
+    only in the rows the Manager ignores -> no change; one that differs below them -> change; flat key frames; key frames
+    back to back.  The log must be the one the Manager writes over the CPU oracle with its own numpy compare."""
+    import torch
+    from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
+    w, h = 320, 240
+    rng = sg.SplitMix64(sg.SEED_BASE + 777)
+    enc = sg.SpEncoder(w, h, 24, 4)
+    a = sg.desktop_frame(rng, w, h, 24).astype(np.uint32).reshape(h, w)
+    top = a.copy()
+    top[5:20, 10:200] ^= 0x00101010          # rows 5..19 only (the buffer is bottom-up: rows below INSIGNIFICANT_LINES = 36 do not count)
+    low = a.copy()
+    low[100:120, 30:90] ^= 0x00202020
+    seq = [("i", a), ("p", a), ("i", a), ("p", a), ("i", top), ("p", top), ("i", low), ("i", low), ("flat", 0x336699), ("p", None), ("i", a)]
+    chunks, keys = [], []
+    cur = None
+    for kind, img in seq:
+        if kind == "i":
+            chunks.append(enc.encode_i(img)); keys.append(True); cur = img
+        elif kind == "flat":
+            chunks.append(enc.encode_flat(img)); keys.append(True); cur = enc.current().reshape(h, w).copy()
+        else:
+            chunks.append(enc.encode_p(cur)); keys.append(False)
+    enc.close()
+    blob = avi.write_avi(w, h, chunks, fourcc=b"SCPR", bpp=24, key_flags=keys)
+    vi, got = avi.read_avi(blob)
+    cpu = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
+    cpu.play(got, key_flags=keys)
+    dec = player.make_decoder(vi, (MSVideo1_16bit, MSVideo1_8bit, ScreenPressor))
+    depth = 3
+    if how != "play":
+        dec.set_option("sp_async_threads", "4" if how == "pipelined_workers" else "1")
+    gpu = player.Manager(vi, dec, lambda n: torch.zeros(n, dtype=torch.int32, device="cuda"), num_buffers=player.NUM_BUFFERS + depth)
+    assert gpu._fused_compare
+    if how == "play":
+        gpu.play(got, key_flags=keys)
+    else:
+        gpu.play_pipelined(got, depth=depth, key_flags=keys)
+    assert [(d.index, d.key, d.significant_changes, d.state) for d in cpu.log] == [(d.index, d.key, d.significant_changes, d.state) for d in gpu.log]
+    sig = {d.index: d.significant_changes for d in cpu.log if d.key}
+    assert sig[2] is False and sig[4] is False and sig[6] is True and sig[7] is False and sig[8] is True and sig[10] is True
+    # the same through MSVideo1 (16-bit): key frames behind inter frames, decoded through the asynchronous one-launch path
+    frames, pal = config0_clip(16, 30)
+    probe = ORACLE_CLASSES[0](320, 240)
+    mk = [i == 0 or probe.IsKeyFrame(f) for i, f in enumerate(frames)]
+    frames = list(frames[:6]) + [frames[0]] + list(frames[6:12]) + [frames[0], frames[0]]      # key frames again, behind inter frames
+    mk = mk[:6] + [True] + mk[6:12] + [True, True]
+    blob = avi.write_avi(320, 240, frames, fourcc=b"CRAM", bpp=16, palette=pal, key_flags=mk)
+    vi, got = avi.read_avi(blob)
+    cpu = player.Manager(vi, player.make_decoder(vi, ORACLE_CLASSES), lambda n: np.zeros(n, dtype=np.int32))
+    cpu.play(got, key_flags=mk)
+    dec = player.make_decoder(vi, (MSVideo1_16bit, MSVideo1_8bit, ScreenPressor))
+    gpu = player.Manager(vi, dec, lambda n: torch.zeros(n, dtype=torch.int32, device="cuda"), num_buffers=player.NUM_BUFFERS + depth)
+    if how == "play":
+        gpu.play(got, key_flags=mk)
+    else:
+        gpu.play_pipelined(got, depth=depth, key_flags=mk)
+    assert [(d.index, d.key, d.significant_changes, d.state) for d in cpu.log] == [(d.index, d.key, d.significant_changes, d.state) for d in gpu.log]
+    assert any(d.key and d.index > 0 and d.significant_changes is True for d in cpu.log)

@@ -293,11 +293,12 @@ def oracle_with_rotation(w, h, chunks, nbuf, fill=0x123456):
 
 @pytest.mark.parametrize("version", [2, 4])
 def test_left_of_column_zero_is_the_destinations_old_content(version):
-    """The documented deviation, pinned down: the reference reads the caller's destination buffer
-    there, so its result depends on how the caller rotates its buffers; the product's host stage reads its own shadow of
-    that position — the picture two frames back — whatever the caller does.  With two buffers in rotation both see the same
-    thing (and the stream decodes to what the encoder meant); with three the reference reads older content and differs in
-    exactly that pixel."""
+    """The one place where an inter frame READS its destination: the reference reads the caller's buffer
+    there, so its result depends on how the caller rotates its buffers.  With two buffers in rotation it sees the picture two
+    frames back (and the stream decodes to what the encoder meant); with three it reads older content and differs in exactly
+    that pixel.  The product's host stage is told what the destination holds in its last column (the codec keeps track,
+    SpCodec::before / after) and then decodes what the reference decodes, whatever the rotation; told nothing, it reads its
+    own shadow of the position — the two-buffer picture."""
     w, h, y0, chunks, frames = column0_clip(version)
     two = oracle_with_rotation(w, h, chunks, 2)
     assert np.array_equal(two, frames[2])
@@ -314,6 +315,17 @@ def test_left_of_column_zero_is_the_destinations_old_content(version):
         prev = hs.expand_iframe(d, w, h) if i == 0 else hs.expand_pframe(d, prev, w, h)
     host.close()
     assert np.array_equal(np.asarray(prev).view(np.uint32).reshape(h, w), two)
+    # ... and told what a third buffer holds (its fill): as the reference with three buffers
+    host = hs.HostStage(w, h, 24)
+    host.preinit(36)
+    prev = None
+    for i, c in enumerate(chunks):
+        host.set_dst_column(np.full(h, 0x123456, np.int32) if i == 2 else None)
+        d = host.decode(i == 0, c)
+        assert d["status"] == 0
+        prev = hs.expand_iframe(d, w, h) if i == 0 else hs.expand_pframe(d, prev, w, h)
+    host.close()
+    assert np.array_equal(np.asarray(prev).view(np.uint32).reshape(h, w), three)
 
 
 def test_group_tables_linked_for_the_look_back():

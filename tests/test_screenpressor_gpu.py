@@ -410,21 +410,51 @@ def test_batches_staged_into_one_batch_object():
     st.close()
 
 
-@pytest.mark.parametrize("nbuf", [2, 3])
-def test_left_of_column_zero_reads_the_picture_two_frames_back(nbuf):
-    """The documented deviation (tests/test_screenpressor_cpu.py::test_left_of_column_zero_is_the_destinations_old_content) through
-    the C ABI: whatever the caller's buffer rotation, the product decodes the crafted stream as the reference does for a caller
-    that rotates two buffers."""
+@pytest.mark.parametrize("how", ["sync", "async", "async_workers", "host_pointers", "batch"])
+@pytest.mark.parametrize("nbuf", [2, 3, 4])
+def test_left_of_column_zero_reads_what_the_callers_buffer_holds(nbuf, how):
+    """The one place where an inter frame reads its destination before writing it (tests/test_screenpressor_cpu.py::
+    test_left_of_column_zero_is_the_destinations_old_content), through the C ABI: whatever the caller's buffer rotation — two
+    buffers (the picture two frames back), three or four (the buffer's fill shows through) — the product hands back what the
+    reference hands back, through the synchronous calls, the asynchronous ones (host stage inside the call, or on worker
+    threads), host frame buffers and a staged batch.  (Round 3 read the picture two frames back whatever the rotation.)"""
     import torch
     from test_screenpressor_cpu import column0_clip, oracle_with_rotation
     w, h, y0, chunks, frames = column0_clip(4)
-    want = oracle_with_rotation(w, h, chunks, 2)
+    want = oracle_with_rotation(w, h, chunks, nbuf)
+    if nbuf > 2:
+        assert int(want[y0, 0]) == 0x123456          # the third buffer's fill shows through in the reference
     gpu = ScreenPressor(w, h, 24)
     gpu.Preinit(36)
-    bufs = [torch.full((w * h,), 0x123456, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-    assert gpu.DecompressI(chunks[0], bufs[0]) == 0
-    gpu.DecompressP(chunks[1], bufs[1])
-    gpu.DecompressP(chunks[2], bufs[2 % nbuf])
-    got = gpu.PreviousFrame().cpu().numpy().view(np.uint32).reshape(h, w)
+    if how == "host_pointers":
+        bufs = [np.full(w * h, 0x123456, dtype=np.int32) for _ in range(nbuf)]
+    else:
+        bufs = [torch.full((w * h,), 0x123456, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    order = [bufs[0], bufs[1], bufs[2 % nbuf]]
+    if how in ("sync", "host_pointers"):
+        assert gpu.DecompressI(chunks[0], order[0]) == 0
+        gpu.DecompressP(chunks[1], order[1])
+        gpu.DecompressP(chunks[2], order[2])
+    elif how == "batch":
+        if nbuf == 2:
+            # (the same buffer twice in one batch: staged in order)
+            pass
+        st = gpu.stage_batch(chunks, order, is_key=[True, False, False])
+        st.decode()
+        gpu.sync()
+        assert st.results()[0] == [0, 0, 0]
+        st.close()
+    else:
+        gpu.set_option("sp_async_threads", "4" if how == "async_workers" else "1")
+        tickets = [gpu.DecompressI_async(chunks[0], order[0]), gpu.DecompressP_async(chunks[1], order[1])]
+        if nbuf == 2:
+            for t in tickets:
+                gpu.wait(t)                          # (its destination is the first frame's buffer: not while that is in flight)
+            tickets = []
+        tickets.append(gpu.DecompressP_async(chunks[2], order[2]))
+        for t in tickets:
+            gpu.wait(t)
+    got = gpu.PreviousFrame()
+    got = (got if how == "host_pointers" else got.cpu().numpy()).view(np.uint32).reshape(h, w)
     assert np.array_equal(got, want)
     gpu.StopAndClean()
