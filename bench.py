@@ -151,7 +151,8 @@ def resident_leg(job: Job, name: str, nfr_override=None, nclips=None):
     t_gen = time.perf_counter() - t_gen
 
     t_stage = time.perf_counter()
-    work = wl.StagedWorkload(name, clips, device=job.local_rank, hip_stream=job.stream.cuda_stream)   # host stage + H2D: outside the timed region
+    options = dict(kv.split("=", 1) for kv in os.environ.get("JSP_BENCH_OPTIONS", "").split(",") if "=" in kv)    # experiment knob: codec options, "key=value,key=value"
+    work = wl.StagedWorkload(name, clips, device=job.local_rank, hip_stream=job.stream.cuda_stream, options=options or None)   # host stage + H2D: outside the timed region
     t_stage = time.perf_counter() - t_stage
     infos, nfr, step = work.infos, work.frames_per_step, work.step
     for _ in range(args.warmup):

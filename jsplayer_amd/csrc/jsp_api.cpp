@@ -500,6 +500,7 @@ void settle(jsp_codec* c, uint64_t t) {
     j.st->finish_results();
     if (!c->async_finish(j.st.get())) { redo_from(c, t); return; }
     if (j.key_compare_queued) { j.key_differs = c->read_key_compare((int)(t % c->async_depth)); j.key_compare_queued = false; }
+    else if (j.key_differs == -3) j.key_differs = j.st->key_differs.empty() ? -1 : j.st->key_differs[0];
     j.status = j.st->status[0];
     j.significant = j.st->significant[0] < 0 ? 0 : j.st->significant[0];
     if (j.status != JSP_ZERO_STATE) j.why = j.st->why.empty() ? "decode aborted: the reference raises on this stream" : j.st->why;
@@ -551,7 +552,7 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
     st->decode(c->stream);
     if (key && c->key_compare_row >= 0 && st->status[0] == JSP_ZERO_STATE && st->adopted[0] && j.prev_dev_before) {
         // (a frame the GPU may still veto leaves `dst` untouched and is re-run through the synchronous path, which compares again)
-        j.key_differs = st->key_differs.empty() ? -2 : st->key_differs[0];
+        j.key_differs = st->key_differs.empty() ? -2 : st->key_differs[0];   // (-3: the frame's own kernels compare; async_finish() knows)
         if (j.key_differs == -2) { c->queue_key_compare(dst, j.prev_dev_before, (int)(c->next_ticket % c->async_depth)); j.key_compare_queued = true; }
     }
     JSP_HIP(hipEventRecord(j.done, c->stream));

@@ -169,6 +169,7 @@ struct Msv1AsyncStaged : jsp_staged {
     int ntiles = 0, insignificant_blocks = 0;
     size_t nbytes = 0;
     bool have_prev = false, compare = false, key = false;
+    bool key_compare = false;                 // a key frame whose stage-2 compare answers option "key_frame_compare" (the kernel compares as it decodes)
     uint32_t* d_poison = nullptr;             // the codec's veto word (see msv1_launch_fused)
     DeviceBuffer d_stream, d_meta, d_agg;     // d_meta = [tile records | Msv1AsyncInfo] (two-launch form)
     PinnedBuffer h_stream, h_meta, h_info;
@@ -405,6 +406,11 @@ struct Msv1Codec : jsp_codec {
         // inter frames with a previous frame are compared against it in any case (whether the result counts is known
         // only with the stage-1 flag the kernel reports)
         st->compare = geo.bits == 16 && insign_lines_set && !f.key && prev_dev != nullptr;
+        // option "key_frame_compare": a key frame is compared with the frame before it by the very kernel that decodes it (the stage-2
+        // compare of the inter frames, MSVideo1.hx:195-204, from the Manager's row on) — when the block grid covers the frame
+        st->key_compare = f.key && key_compare_row >= 0 && prev_dev != nullptr && ps.changes && (X & 3) == 0 && (Y & 3) == 0;
+        st->key_differs.assign(1, st->key_compare ? -3 : -2);   // -3: async_finish() says (jsp_api.cpp)
+        if (st->key_compare) st->compare = true;
         const size_t n_even = f.n & ~size_t(1);
         const int nt = (int)((f.n + tile_bytes - 1) / tile_bytes);
         st->ntiles = nt;
@@ -438,7 +444,7 @@ struct Msv1Codec : jsp_codec {
             r.k = (uint32_t)k;
             r.first_tile = 0;
             r.ntiles = (uint32_t)nt;
-            r.cmp_row_lo = st->compare ? (uint32_t)std::max(insign_lines, 0) : 0xFFFFFFFFu;
+            r.cmp_row_lo = st->key_compare ? (uint32_t)key_compare_row : st->compare ? (uint32_t)std::max(insign_lines, 0) : 0xFFFFFFFFu;
             r.flags = 0;
             r.dst = f.dst;
             r.prev = prev_dev;
@@ -511,6 +517,7 @@ struct Msv1Codec : jsp_codec {
             // 8-bit: NaN loop bound -> no pixel is compared -> false
         }
         st->significant[0] = sg;
+        if (st->key_compare) st->key_differs[0] = in.signif ? 1 : 0;
         return true;
     }
 

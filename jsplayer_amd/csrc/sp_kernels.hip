@@ -272,12 +272,19 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         for (int q = 0; q < WMAX; ++q) {
             const int kq = lane + 64 * q, kk = kq < w.wn ? kq : (w.wn > 0 ? w.wn - 1 : 0);
             const uint2* src = gruns + w.w0 + kk;              // (always a record of this tile)
+#if defined(JSP_SP_LAB_NOFETCH)   // lab (with JSP_SP_LAB_STOREONLY): the row loop without its record fetches — no load at all behind the row stores
+            wva[q] = (unsigned long long)(uintptr_t)src;
+#else
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wva[q]) : "v"(src) : "memory");
+#endif
         }
         return w;
     };
     // wait until at most `stores_behind` vector-memory operations of this wave are outstanding (the newest ones)
     auto settle_window = [&](int stores_behind) {
+#if defined(JSP_SP_LAB_NOFETCH)
+        return;
+#endif
         switch (stores_behind < 16 ? stores_behind : 16) {     // (more than 16 rows per window: waiting down to 16 is just as exact)
 #define JSP_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
             JSP_VM(0) JSP_VM(1) JSP_VM(2) JSP_VM(3) JSP_VM(4) JSP_VM(5) JSP_VM(6) JSP_VM(7) JSP_VM(8)
