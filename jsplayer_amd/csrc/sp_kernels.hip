@@ -397,6 +397,253 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Key frames, tile path with a LOADER wave (round 4).  Taken apart on the frames of the placed pool (profiles/r04_sp_tile_parts.txt)
+// the kernel above is bound by its row stores — everything but them 0.235 ms, nothing but them 0.441 ms, the whole 0.466 ms per 256
+// frames — and those stores take 0.342 ms when the record-window fetches are not issued between them: a CU's loads and stores share
+// one in-order queue, so every window's records (asked for a window ahead) still travel behind the row stores in front of them, and
+// the wave idles.  Here a workgroup is TW tile waves plus one loader wave: the loader plans each tile's windows exactly as the tile
+// does (same function of the tile's row index), brings the records of the next window straight into LDS (global_load_lds: no
+// registers, its vmcnt only ever holds loads) into one of the tile's two window buffers, and publishes a counter; the tile waves'
+// row loop holds no load at all — it waits for the counter (LDS), uses the buffer, and says when it is through with it.
+typedef __attribute__((address_space(1))) const void tl_gvoid;
+typedef __attribute__((address_space(3))) void tl_lvoid;
+struct TileWindow { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
+__device__ __forceinline__ TileWindow plan_tile_window(const uint32_t* idx, const uint32_t* left, int yb, int ye, int from, int win_cap, int lane) {
+    constexpr uint32_t OFF = ~kRowRepeats;
+    TileWindow w;
+    const int k = from + lane;
+    w.ve = idx[(k < ye ? k : ye) - yb];
+    w.vl = left[(k < ye ? k : ye - 1) - yb];
+    w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ve) & OFF;
+    const bool fits = lane >= 1 && k <= ye && (int)((w.ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
+    const unsigned long long m = __ballot(fits) >> 1;
+    int n = __builtin_ctzll(~m);                           // (bit 63 of ~m is always set: at most 63 rows)
+    w.direct = n == 0;                                     // the first row alone is too much for the window
+    if (n == 0) n = 1;
+    w.n = n;
+    w.wn = w.direct ? 0 : (int)(((uint32_t)__builtin_amdgcn_readlane((int)w.ve, n) & OFF) - w.w0);
+    return w;
+}
+
+template <int TW>
+__global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_loader_kernel(const IFrameArgs* __restrict__ args, int X, int Y, int band_rows, int nspans,
+                                                                              int ntiles, int win_cap, int tile_words, int nbuf, int store_limit) {
+    constexpr int PPL = 4, SPAN = 64 * PPL;
+    constexpr int SPIN = 1 << 22;
+    extern __shared__ __align__(16) uint32_t lds[];
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    const IFrameArgs fa = args[blockIdx.x];
+    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // per tile wave: [head: SPAN words][idx: band_rows + 1][left: band_rows][window 0: win_cap records][window 1]; then the counters
+    const int idx_words = (band_rows + 1 + 3) & ~3, left_words = (band_rows + 3) & ~3;
+    lds_vu32* s_ready = (lds_vu32*)(lds + (size_t)TW * tile_words);     // [TW] windows the loader has filled, per tile
+    lds_vu32* s_done = s_ready + TW;                                    // [TW] windows the tile is through with
+    if (threadIdx.x < 2 * TW) s_ready[threadIdx.x] = 0u;
+    auto tile_of = [&](int w) { return (int)blockIdx.y * TW + w; };     // tiles of a frame in band-major order, TW per workgroup
+    if (fa.flat) {                                                      // (uniform over the workgroup)
+        if (wave < TW && tile_of(wave) < ntiles) {
+            const int tile = tile_of(wave), band = tile / nspans, span = tile - band * nspans;
+            const int yb = band * band_rows, ye = yb + band_rows < Y ? yb + band_rows : Y, x0 = span * SPAN + lane * PPL;
+            if (x0 < X)
+                for (int y = yb; y < ye; ++y) store4_global(dst + (size_t)y * X + x0, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
+        }
+        return;
+    }
+    const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
+    constexpr uint32_t OFF = ~kRowRepeats;
+
+    if (wave < TW) {
+        // ------------------------------------------ tile wave ------------------------------------------
+        const int tile = tile_of(wave);
+        const bool live = tile < ntiles;
+        const int band = live ? tile / nspans : 0, span = live ? tile - band * nspans : 0;
+        const int yb = band * band_rows;
+        const int ye = yb + band_rows < Y ? yb + band_rows : Y;
+        const int xs = span * SPAN, x0 = xs + lane * PPL;
+        const bool active = live && x0 < X;
+        uint32_t* head = lds + (size_t)wave * tile_words;
+        uint32_t* idx = head + SPAN;
+        uint32_t* left = idx + idx_words;
+        uint2* win0 = reinterpret_cast<uint2*>(left + left_words);
+        uint32_t p[PPL] = {0, 0, 0, 0};
+        if (live) {
+            const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
+            const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
+            for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
+            for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
+            *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
+            if (yb > 0 && active) {
+                const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + j);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the last loads this wave ever waits for
+        __syncthreads();                                   // every tile's row index is in LDS: the loader may plan
+        if (!live) return;
+        uint32_t d24[PPL] = {0, 0, 0, 0}, dlo[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
+        const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+        int y = yb;
+        uint32_t nwin = 0;                                 // windows taken so far
+        while (y < ye) {
+            const TileWindow cw = plan_tile_window(idx, left, yb, ye, y, win_cap, lane);
+            const uint2* win = win0 + (size_t)(nwin % (uint32_t)nbuf) * win_cap;
+            if (!cw.direct) {
+                int spin = 0;
+                for (; s_ready[wave] <= nwin && spin < SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
+                if (spin >= SPIN) return;                 // (cannot happen: bounded so that a mistake ends the launch)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 0);
+            uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 1);
+            {
+                const int nfirst = (int)((e1 & OFF) - cw.w0);
+                if (cw.direct) {                           // a row with more records than a window holds: scattered straight from memory
+                    for (int r = lane; r < nfirst; r += 64) {
+                        const uint2 q = load2_global(gruns + cw.w0 + r);
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!cw.direct)
+                    for (int r = lane; r < nfirst; r += 64) {
+                        const uint2 q = win[r];
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
+                    }
+            }
+            for (int r = 0; r < cw.n; ++r, ++y) {
+                const bool more = r + 1 < cw.n;
+                const uint32_t e2 = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2) : e1;
+                const bool repeat = (e0 & kRowRepeats) != 0u;
+                const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw.vl, r);
+                const int n_next = (int)((e2 & OFF) - (e1 & OFF));
+                const int next_at = (int)((e1 & OFF) - cw.w0);
+                uint2 nrec = make_uint2(0, 0);
+                if (lane < n_next) nrec = win[next_at + lane];
+                uint32_t u0 = lane_to_the_left(p[PPL - 1]);
+                u0 = lane == 0 ? eg : u0;
+                if (!repeat) {
+                    const uint4 hv = *reinterpret_cast<const uint4*>(head + lane * PPL);
+                    *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
+                    const uint32_t h[PPL] = {hv.x, hv.y, hv.z, hv.w};
+                    uint32_t last = h[0];
+#pragma unroll
+                    for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
+                    const unsigned long long seen = __ballot(last != 0u);
+                    const uint32_t below_lo = (uint32_t)seen & lt_lo, below_hi = (uint32_t)(seen >> 32) & lt_hi;
+                    const uint32_t lead = min(ffbh(below_hi), ffbh(below_lo) + 32u);
+                    uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(~lead << 2), (int)last);
+#pragma unroll
+                    for (int j = 0; j < PPL; ++j) {
+                        w = h[j] ? h[j] : w;
+                        d24[j] = w;
+                        dlo[j] = w & 0x007F7F7Fu;
+                        m_above[j] = (uint32_t)((int32_t)(w << 7) >> 31);
+                        m_left[j] = (uint32_t)((int32_t)(w << 6) >> 31);
+                    }
+                }
+                uint32_t q[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
+                    q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
+                }
+                // Store throttle: this wave issues nothing but row stores, so its vmcnt counts exactly the rows still on their way; keeping
+                // that number small keeps the CU's one in-order memory queue short — it is the queue the loader's record requests stand in.
+                switch (store_limit) {
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    default: break;
+                }
+                if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) p[j] = q[j];
+                if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + nrec.x) = nrec.y;
+                for (int k = lane + 64; k < n_next; k += 64) {
+                    const uint2 q2 = win[next_at + k];
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q2.x) = q2.y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                e0 = e1;
+                e1 = e2;
+            }
+            ++nwin;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the window's last LDS reads are in: its buffer may be refilled
+            if (lane == 0) s_done[wave] = nwin;
+        }
+        return;
+    }
+
+    // ------------------------------------------ loader wave ------------------------------------------
+    __syncthreads();                                       // the tiles' row indices are in LDS
+    int ynext[TW], yend[TW], ybase[TW];
+    uint32_t issued[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int tile = tile_of(t);
+        const int band = tile < ntiles ? tile / nspans : 0;
+        ybase[t] = band * band_rows;
+        yend[t] = tile < ntiles ? (ybase[t] + band_rows < Y ? ybase[t] + band_rows : Y) : 0;
+        ynext[t] = tile < ntiles ? ybase[t] : 0;
+        issued[t] = 0;
+    }
+    for (int guard = 0; guard < SPIN; ++guard) {
+        bool any_left = false, any_issued = false;
+        // a round: first every plan (LDS reads: one issued after an LDS-DMA would be made to wait for it), then every request
+        uint32_t pw0[TW];
+        int pwn[TW];
+        bool take[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            take[t] = false;
+            pw0[t] = 0;
+            pwn[t] = 0;
+            if (ynext[t] >= yend[t]) continue;
+            any_left = true;
+            const uint32_t through = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_done[t]);
+            // (signed: a tile that takes a window straight from memory — a row with more records than a buffer holds — does not wait for
+            // the loader and may be a window ahead of it)
+            if ((int)(issued[t] - through) >= nbuf) continue;   // all of the tile's buffers hold windows it has not finished
+            const uint32_t* idx = lds + (size_t)t * tile_words + SPAN;
+            const TileWindow w = plan_tile_window(idx, idx + idx_words, ybase[t], yend[t], ynext[t], win_cap, lane);
+            take[t] = true;
+            pw0[t] = w.w0;
+            pwn[t] = w.direct ? 0 : __builtin_amdgcn_readfirstlane(w.wn);
+            ynext[t] += __builtin_amdgcn_readfirstlane(w.n);
+            any_issued = true;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            if (!take[t]) continue;
+            uint2* buf = reinterpret_cast<uint2*>(lds + (size_t)t * tile_words + SPAN + idx_words + left_words) + (size_t)(issued[t] % (uint32_t)nbuf) * win_cap;
+            const int nchunks = (pwn[t] + 1) >> 1;         // 16 bytes = two records per lane
+            for (int c0 = 0; c0 < nchunks; c0 += 64)
+                if (c0 + lane < nchunks)
+                    __builtin_amdgcn_global_load_lds((tl_gvoid*)(gruns + pw0[t] + 2 * (c0 + lane)), (tl_lvoid*)(buf + 2 * c0), 16, 0, 0);
+            ++issued[t];
+        }
+        if (!any_left) break;
+        if (any_issued) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the windows asked for in this round have landed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+                if (lane == 0) s_ready[t] = issued[t];
+        } else {
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
+
 constexpr int PWG = 256;  // 16 rows x 16 chunks of 4 pixels = 4 blocks side by side
 
 __global__ __launch_bounds__(PWG) void sp_pframe_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ prev,
@@ -1061,6 +1308,7 @@ bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; 
 // each with a longer serial row step)
 int iframe_tile_span(const Geometry&) { return 256; }   // (8 pixels per lane, 512-column spans: 0.71 vs 0.54 ms, profiles/r03_fused_notes.txt)
 namespace {
+constexpr int SPAN_WORDS = 256;
 struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {
     TilePlan t;
@@ -1082,6 +1330,34 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     if (nframes <= 0) return;
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
+    static const int loader_tw = [] { const char* e = std::getenv("JSP_SP_TILE_LOADER"); return e ? std::atoi(e) : 0; }();   // lab: 0 = one wave per tile, no loader wave
+    static const int nbuf = [] { const char* e = std::getenv("JSP_SP_TILE_NBUF"); const int v = e ? std::atoi(e) : 2; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
+    static const int store_limit = [] { const char* e = std::getenv("JSP_SP_TILE_VMCNT"); return e ? std::atoi(e) : 0; }();
+    if ((loader_tw == 4 || loader_tw == 7) && nframes <= 65535) {
+        // TW tile waves + a loader wave per workgroup; a tile's LDS: head row, row index, left column, two record windows
+        const int TW = loader_tw;
+        const int idx_words = (t.rows + 1 + 3) & ~3, left_words = (t.rows + 3) & ~3;
+        const int budget_words = (TW == 4 ? 26 * 1024 : 37 * 1024) / 4 / TW;      // 6 (TW = 4) / 4 (TW = 7) workgroups per CU
+        int cap = (budget_words - SPAN_WORDS - idx_words - left_words) / (2 * nbuf);
+        cap = cap > 384 ? 384 : cap;
+        cap &= ~1;
+        if (cap >= 96) {
+            const int tile_words = SPAN_WORDS + idx_words + left_words + 2 * nbuf * cap;
+            const int ntiles = bands * t.nspans;
+            const dim3 grid(nframes, (ntiles + TW - 1) / TW);
+            const size_t lds = ((size_t)TW * tile_words + 2 * TW + 4) * 4;
+            static std::once_flag attr_once;
+            std::call_once(attr_once, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_loader_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_loader_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            });
+            if (TW == 4)
+                hipLaunchKernelGGL(sp_iframe_tile_loader_kernel<4>, grid, dim3(5 * 64), lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, ntiles, cap, tile_words, nbuf, store_limit);
+            else
+                hipLaunchKernelGGL(sp_iframe_tile_loader_kernel<7>, grid, dim3(8 * 64), lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, ntiles, cap, tile_words, nbuf, store_limit);
+            return;
+        }
+    }
     const char* e = std::getenv("JSP_SP_TILE_FASTEST");                 // lab: which index runs fastest in the launch order (read at every launch)
     const int tile_fastest = e && std::atoi(e) != 0 && nframes <= 65535;   // (frames fastest: 0.616 of 8 TB/s, tiles fastest 0.573, same buffers; rotating the bands per frame: no change)
     const dim3 grid = tile_fastest ? dim3(bands * t.nspans, nframes) : dim3(nframes, bands * t.nspans);
