@@ -331,6 +331,9 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         }
 #if defined(JSP_SP_LAB_STOREONLY)   // lab: the row stores and nothing else
         for (int r = 0; r < cw.n; ++r, ++y) {
+#if defined(JSP_SP_LAB_SLEEP)      // lab: the wave sleeps between its row stores for as long as the row's arithmetic takes it in the full kernel (no VALU used)
+            for (int z = 0; z < JSP_SP_LAB_SLEEP; ++z) __builtin_amdgcn_s_sleep(16);
+#endif
             if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(p[0], p[1], p[2], p[3]));
             ++rows_since_fetch;
         }
@@ -398,14 +401,15 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Key frames, tile path with a LOADER wave (round 4).  Taken apart on the frames of the placed pool (profiles/r04_sp_tile_parts.txt)
-// the kernel above is bound by its row stores — everything but them 0.235 ms, nothing but them 0.441 ms, the whole 0.466 ms per 256
-// frames — and those stores take 0.342 ms when the record-window fetches are not issued between them: a CU's loads and stores share
-// one in-order queue, so every window's records (asked for a window ahead) still travel behind the row stores in front of them, and
-// the wave idles.  Here a workgroup is TW tile waves plus one loader wave: the loader plans each tile's windows exactly as the tile
-// does (same function of the tile's row index), brings the records of the next window straight into LDS (global_load_lds: no
-// registers, its vmcnt only ever holds loads) into one of the tile's two window buffers, and publishes a counter; the tile waves'
-// row loop holds no load at all — it waits for the counter (LDS), uses the buffer, and says when it is through with it.
+// Key frames, tile path with a STORER wave (round 4).  The shader counters of the kernel above, whole against the build without its
+// row stores (profiles/r04_sp_tile_sq_whole_vs_nostore.txt): the same instructions, the same s_waitcnt time — and 822 M more
+// quad-cycles per launch in which a wave stands at an instruction it cannot issue: its row store, ~1 500 cycles each time, because
+// the memory pipe is full.  A wave that stands at its store does not compute its next row, and with eight waves on a SIMD the
+// arithmetic (0.235 ms alone) and the stores (0.342 ms alone) then share the time (0.466 ms) instead of overlapping.  Here a
+// workgroup is TW resolver waves and one storer wave: a resolver writes its finished row into a ring of K rows in LDS and goes on —
+// it never issues a store —, the storer reads rows out of the rings and does nothing but issue row stores (and stand at them).
+// (A loader-wave form — record fetches taken out of the tile waves instead — was measured first and was slower in every
+// configuration: profiles/r04_sp_tile_loader_ab.txt.)
 typedef __attribute__((address_space(1))) const void tl_gvoid;
 typedef __attribute__((address_space(3))) void tl_lvoid;
 struct TileWindow { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
@@ -426,22 +430,24 @@ __device__ __forceinline__ TileWindow plan_tile_window(const uint32_t* idx, cons
     return w;
 }
 
-template <int TW>
-__global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_loader_kernel(const IFrameArgs* __restrict__ args, int X, int Y, int band_rows, int nspans,
-                                                                              int ntiles, int win_cap, int tile_words, int nbuf, int store_limit) {
+template <int TW, int K>
+__global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_storer_kernel(const IFrameArgs* __restrict__ args, int X, int Y, int band_rows, int nspans,
+                                                                              int ntiles, int win_cap, int tile_words) {
     constexpr int PPL = 4, SPAN = 64 * PPL;
     constexpr int SPIN = 1 << 22;
+    constexpr int WMAX = 4;                                // win_cap <= 64 * WMAX (the launcher hands out 256 records per window)
+    static_assert((K & (K - 1)) == 0, "ring of 2^k rows");
     extern __shared__ __align__(16) uint32_t lds[];
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // per tile wave: [head: SPAN words][idx: band_rows + 1][left: band_rows][window 0: win_cap records][window 1]; then the counters
+    // per resolver: [head: SPAN words][idx: band_rows + 1][left: band_rows][window: win_cap records][ring: K rows of SPAN words]; then the counters
     const int idx_words = (band_rows + 1 + 3) & ~3, left_words = (band_rows + 3) & ~3;
-    lds_vu32* s_ready = (lds_vu32*)(lds + (size_t)TW * tile_words);     // [TW] windows the loader has filled, per tile
-    lds_vu32* s_done = s_ready + TW;                                    // [TW] windows the tile is through with
-    if (threadIdx.x < 2 * TW) s_ready[threadIdx.x] = 0u;
+    lds_vu32* s_prod = (lds_vu32*)(lds + (size_t)TW * tile_words);      // [TW] rows a resolver has put into its ring
+    lds_vu32* s_cons = s_prod + TW;                                     // [TW] rows the storer has taken out of it
+    if (threadIdx.x < 2 * TW) s_prod[threadIdx.x] = 0u;
     auto tile_of = [&](int w) { return (int)blockIdx.y * TW + w; };     // tiles of a frame in band-major order, TW per workgroup
     if (fa.flat) {                                                      // (uniform over the workgroup)
         if (wave < TW && tile_of(wave) < ntiles) {
@@ -452,61 +458,70 @@ __global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_loader_kernel(co
         }
         return;
     }
+    __syncthreads();                                       // the counters are zero before anybody looks at them
     const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
     constexpr uint32_t OFF = ~kRowRepeats;
 
     if (wave < TW) {
-        // ------------------------------------------ tile wave ------------------------------------------
+        // ------------------------------------------ resolver wave ------------------------------------------
         const int tile = tile_of(wave);
-        const bool live = tile < ntiles;
-        const int band = live ? tile / nspans : 0, span = live ? tile - band * nspans : 0;
+        if (tile >= ntiles) return;
+        const int band = tile / nspans, span = tile - band * nspans;
         const int yb = band * band_rows;
         const int ye = yb + band_rows < Y ? yb + band_rows : Y;
         const int xs = span * SPAN, x0 = xs + lane * PPL;
-        const bool active = live && x0 < X;
+        const bool active = x0 < X;
         uint32_t* head = lds + (size_t)wave * tile_words;
         uint32_t* idx = head + SPAN;
         uint32_t* left = idx + idx_words;
-        uint2* win0 = reinterpret_cast<uint2*>(left + left_words);
+        uint2* win = reinterpret_cast<uint2*>(left + left_words);
+        uint32_t* ring = reinterpret_cast<uint32_t*>(win + win_cap);
+        const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
+        const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
+        for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
+        for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
+        *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
         uint32_t p[PPL] = {0, 0, 0, 0};
-        if (live) {
-            const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
-            const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
-            for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
-            for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
-            *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
-            if (yb > 0 && active) {
-                const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
+        if (yb > 0 && active) {
+            const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
 #pragma unroll
-                for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + j);
-            }
+            for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + j);
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the last loads this wave ever waits for
-        __syncthreads();                                   // every tile's row index is in LDS: the loader may plan
-        if (!live) return;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_wave_barrier();
         uint32_t d24[PPL] = {0, 0, 0, 0}, dlo[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
         const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
-        int y = yb;
-        uint32_t nwin = 0;                                 // windows taken so far
-        while (y < ye) {
-            const TileWindow cw = plan_tile_window(idx, left, yb, ye, y, win_cap, lane);
-            const uint2* win = win0 + (size_t)(nwin % (uint32_t)nbuf) * win_cap;
-            if (!cw.direct) {
-                int spin = 0;
-                for (; s_ready[wave] <= nwin && spin < SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
-                if (spin >= SPIN) return;                 // (cannot happen: bounded so that a mistake ends the launch)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the next window's records travel while the current window's rows are worked out (this wave issues nothing but these loads)
+        uint2 wv[WMAX];
+        auto fetch = [&](const TileWindow& w) {
+#pragma unroll
+            for (int q = 0; q < WMAX; ++q) {
+                const int kq = lane + 64 * q;
+                wv[q] = kq < w.wn ? load2_global(gruns + w.w0 + kq) : make_uint2(0, 0);
             }
+        };
+        TileWindow nw = plan_tile_window(idx, left, yb, ye, yb, win_cap, lane);
+        fetch(nw);
+        int y = yb;
+        uint32_t rows_out = 0;                             // rows put into the ring so far
+        uint32_t cons_seen = 0;                            // the storer's progress as last read
+        while (y < ye) {
+            const TileWindow cw = nw;
+#pragma unroll
+            for (int q = 0; q < WMAX; ++q) {
+                const int k = lane + 64 * q;
+                if (k < cw.wn) win[k] = wv[q];
+            }
+            if (y + cw.n < ye) { nw = plan_tile_window(idx, left, yb, ye, y + cw.n, win_cap, lane); fetch(nw); }
             uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 0);
             uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 1);
             {
                 const int nfirst = (int)((e1 & OFF) - cw.w0);
-                if (cw.direct) {                           // a row with more records than a window holds: scattered straight from memory
+                if (cw.direct) {                           // a row with more records than the window holds: scattered straight from memory
                     for (int r = lane; r < nfirst; r += 64) {
                         const uint2 q = load2_global(gruns + cw.w0 + r);
                         *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
                     }
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (!cw.direct)
@@ -552,18 +567,19 @@ __global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_loader_kernel(co
                     const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
                     q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
                 }
-                // Store throttle: this wave issues nothing but row stores, so its vmcnt counts exactly the rows still on their way; keeping
-                // that number small keeps the CU's one in-order memory queue short — it is the queue the loader's record requests stand in.
-                switch (store_limit) {
-                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                    default: break;
+                // the row goes into the ring (slot rows_out mod K) once the storer is through with what the slot held
+                if (rows_out - cons_seen >= (uint32_t)K) {
+                    int spin = 0;
+                    for (; spin < SPIN; ++spin) {
+                        cons_seen = s_cons[wave];
+                        if (rows_out - cons_seen < (uint32_t)K) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (spin >= SPIN) return;             // (cannot happen: bounded so that a mistake ends the launch)
                 }
-                if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));
+                *reinterpret_cast<uint4*>(ring + (size_t)(rows_out & (K - 1)) * SPAN + lane * PPL) = make_uint4(q[0], q[1], q[2], q[3]);
+                ++rows_out;
+                if (lane == 0) s_prod[wave] = rows_out;    // (a wave's LDS operations execute in order: the row is there before the count)
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) p[j] = q[j];
                 if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + nrec.x) = nrec.y;
@@ -575,72 +591,55 @@ __global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_loader_kernel(co
                 e0 = e1;
                 e1 = e2;
             }
-            ++nwin;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the window's last LDS reads are in: its buffer may be refilled
-            if (lane == 0) s_done[wave] = nwin;
         }
         return;
     }
 
-    // ------------------------------------------ loader wave ------------------------------------------
-    __syncthreads();                                       // the tiles' row indices are in LDS
-    int ynext[TW], yend[TW], ybase[TW];
-    uint32_t issued[TW];
+    // ------------------------------------------ storer wave ------------------------------------------
+    uint32_t taken[TW], total[TW];
+    uint32_t* out[TW];
+    bool col[TW];
+    int open = 0;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
         const int tile = tile_of(t);
-        const int band = tile < ntiles ? tile / nspans : 0;
-        ybase[t] = band * band_rows;
-        yend[t] = tile < ntiles ? (ybase[t] + band_rows < Y ? ybase[t] + band_rows : Y) : 0;
-        ynext[t] = tile < ntiles ? ybase[t] : 0;
-        issued[t] = 0;
+        taken[t] = 0;
+        total[t] = 0;
+        out[t] = dst;
+        col[t] = false;
+        if (tile < ntiles) {
+            const int band = tile / nspans, span = tile - band * nspans;
+            const int yb = band * band_rows, ye = yb + band_rows < Y ? yb + band_rows : Y, x0 = span * SPAN + lane * PPL;
+            total[t] = (uint32_t)(ye - yb);
+            out[t] = dst + (size_t)yb * X + x0;
+            col[t] = x0 < X;
+            ++open;
+        }
     }
-    for (int guard = 0; guard < SPIN; ++guard) {
-        bool any_left = false, any_issued = false;
-        // a round: first every plan (LDS reads: one issued after an LDS-DMA would be made to wait for it), then every request
-        uint32_t pw0[TW];
-        int pwn[TW];
-        bool take[TW];
+    for (int guard = 0; guard < SPIN && open > 0; ++guard) {
+        bool any = false;
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
-            take[t] = false;
-            pw0[t] = 0;
-            pwn[t] = 0;
-            if (ynext[t] >= yend[t]) continue;
-            any_left = true;
-            const uint32_t through = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_done[t]);
-            // (signed: a tile that takes a window straight from memory — a row with more records than a buffer holds — does not wait for
-            // the loader and may be a window ahead of it)
-            if ((int)(issued[t] - through) >= nbuf) continue;   // all of the tile's buffers hold windows it has not finished
-            const uint32_t* idx = lds + (size_t)t * tile_words + SPAN;
-            const TileWindow w = plan_tile_window(idx, idx + idx_words, ybase[t], yend[t], ynext[t], win_cap, lane);
-            take[t] = true;
-            pw0[t] = w.w0;
-            pwn[t] = w.direct ? 0 : __builtin_amdgcn_readfirstlane(w.wn);
-            ynext[t] += __builtin_amdgcn_readfirstlane(w.n);
-            any_issued = true;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (taken[t] >= total[t]) continue;
+            const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_prod[t]);
+            if (have == taken[t]) continue;
+            any = true;
+            const uint32_t* ring = lds + (size_t)t * tile_words + SPAN + idx_words + left_words + 2 * (size_t)win_cap;
+            // every row the resolver has ready: read out of the ring first (then its slots are free), stored after
+            uint4 rows[K];
+            const uint32_t n = have - taken[t];            // 1 .. K
 #pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            if (!take[t]) continue;
-            uint2* buf = reinterpret_cast<uint2*>(lds + (size_t)t * tile_words + SPAN + idx_words + left_words) + (size_t)(issued[t] % (uint32_t)nbuf) * win_cap;
-            const int nchunks = (pwn[t] + 1) >> 1;         // 16 bytes = two records per lane
-            for (int c0 = 0; c0 < nchunks; c0 += 64)
-                if (c0 + lane < nchunks)
-                    __builtin_amdgcn_global_load_lds((tl_gvoid*)(gruns + pw0[t] + 2 * (c0 + lane)), (tl_lvoid*)(buf + 2 * c0), 16, 0, 0);
-            ++issued[t];
-        }
-        if (!any_left) break;
-        if (any_issued) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the windows asked for in this round have landed
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            for (int k = 0; k < K; ++k)
+                if ((uint32_t)k < n) rows[k] = *reinterpret_cast<const uint4*>(ring + (size_t)((taken[t] + k) & (K - 1)) * SPAN + lane * PPL);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) s_cons[t] = have;
 #pragma unroll
-            for (int t = 0; t < TW; ++t)
-                if (lane == 0) s_ready[t] = issued[t];
-        } else {
-            __builtin_amdgcn_s_sleep(4);
+            for (int k = 0; k < K; ++k)
+                if ((uint32_t)k < n && col[t]) store4_global(out[t] + (size_t)(taken[t] + k) * X, rows[k]);
+            taken[t] = have;
+            if (taken[t] >= total[t]) --open;
         }
+        if (!any) __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -1330,33 +1329,28 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     if (nframes <= 0) return;
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
-    static const int loader_tw = [] { const char* e = std::getenv("JSP_SP_TILE_LOADER"); return e ? std::atoi(e) : 0; }();   // lab: 0 = one wave per tile, no loader wave
-    static const int nbuf = [] { const char* e = std::getenv("JSP_SP_TILE_NBUF"); const int v = e ? std::atoi(e) : 2; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
-    static const int store_limit = [] { const char* e = std::getenv("JSP_SP_TILE_VMCNT"); return e ? std::atoi(e) : 0; }();
-    if ((loader_tw == 4 || loader_tw == 7) && nframes <= 65535) {
-        // TW tile waves + a loader wave per workgroup; a tile's LDS: head row, row index, left column, two record windows
-        const int TW = loader_tw;
+    static const int storer_tw = [] { const char* e = std::getenv("JSP_SP_TILE_STORER"); return e ? std::atoi(e) : 4; }();   // lab: 0 = one wave per tile, no storer wave
+    static const int ring_rows = [] { const char* e = std::getenv("JSP_SP_TILE_RING"); const int v = e ? std::atoi(e) : 4; return v == 2 || v == 4 || v == 8 ? v : 4; }();
+    if ((storer_tw == 4 || storer_tw == 7) && nframes <= 65535) {
+        // TW resolver waves + a storer wave per workgroup; a resolver's LDS: head row, row index, left column, a record window, a ring of K rows
+        const int TW = storer_tw, K = ring_rows;
         const int idx_words = (t.rows + 1 + 3) & ~3, left_words = (t.rows + 3) & ~3;
-        const int budget_words = (TW == 4 ? 26 * 1024 : 37 * 1024) / 4 / TW;      // 6 (TW = 4) / 4 (TW = 7) workgroups per CU
-        int cap = (budget_words - SPAN_WORDS - idx_words - left_words) / (2 * nbuf);
-        cap = cap > 384 ? 384 : cap;
-        cap &= ~1;
-        if (cap >= 96) {
-            const int tile_words = SPAN_WORDS + idx_words + left_words + 2 * nbuf * cap;
-            const int ntiles = bands * t.nspans;
-            const dim3 grid(nframes, (ntiles + TW - 1) / TW);
-            const size_t lds = ((size_t)TW * tile_words + 2 * TW + 4) * 4;
-            static std::once_flag attr_once;
-            std::call_once(attr_once, [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_loader_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_loader_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            });
-            if (TW == 4)
-                hipLaunchKernelGGL(sp_iframe_tile_loader_kernel<4>, grid, dim3(5 * 64), lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, ntiles, cap, tile_words, nbuf, store_limit);
-            else
-                hipLaunchKernelGGL(sp_iframe_tile_loader_kernel<7>, grid, dim3(8 * 64), lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, ntiles, cap, tile_words, nbuf, store_limit);
-            return;
-        }
+        int cap = 256;                                                   // records per window (2 KB)
+        const int tile_words = SPAN_WORDS + idx_words + left_words + 2 * cap + K * SPAN_WORDS;
+        const int ntiles = bands * t.nspans;
+        const dim3 grid(nframes, (ntiles + TW - 1) / TW);
+        const size_t lds = ((size_t)TW * tile_words + 2 * TW + 4) * 4;
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] {
+#define JSP_ATTR(TW_, K_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_storer_kernel<TW_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+            JSP_ATTR(4, 2); JSP_ATTR(4, 4); JSP_ATTR(4, 8); JSP_ATTR(7, 2); JSP_ATTR(7, 4); JSP_ATTR(7, 8);
+#undef JSP_ATTR
+        });
+#define JSP_GO(TW_, K_) hipLaunchKernelGGL((sp_iframe_tile_storer_kernel<TW_, K_>), grid, dim3((TW_ + 1) * 64), lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, ntiles, cap, tile_words)
+        if (TW == 4) { if (K == 2) JSP_GO(4, 2); else if (K == 4) JSP_GO(4, 4); else JSP_GO(4, 8); }
+        else { if (K == 2) JSP_GO(7, 2); else if (K == 4) JSP_GO(7, 4); else JSP_GO(7, 8); }
+#undef JSP_GO
+        return;
     }
     const char* e = std::getenv("JSP_SP_TILE_FASTEST");                 // lab: which index runs fastest in the launch order (read at every launch)
     const int tile_fastest = e && std::atoi(e) != 0 && nframes <= 65535;   // (frames fastest: 0.616 of 8 TB/s, tiles fastest 0.573, same buffers; rotating the bands per frame: no change)
