@@ -400,248 +400,10 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Key frames, tile path with a STORER wave (round 4).  The shader counters of the kernel above, whole against the build without its
-// row stores (profiles/r04_sp_tile_sq_whole_vs_nostore.txt): the same instructions, the same s_waitcnt time — and 822 M more
-// quad-cycles per launch in which a wave stands at an instruction it cannot issue: its row store, ~1 500 cycles each time, because
-// the memory pipe is full.  A wave that stands at its store does not compute its next row, and with eight waves on a SIMD the
-// arithmetic (0.235 ms alone) and the stores (0.342 ms alone) then share the time (0.466 ms) instead of overlapping.  Here a
-// workgroup is TW resolver waves and one storer wave: a resolver writes its finished row into a ring of K rows in LDS and goes on —
-// it never issues a store —, the storer reads rows out of the rings and does nothing but issue row stores (and stand at them).
-// (A loader-wave form — record fetches taken out of the tile waves instead — was measured first and was slower in every
-// configuration: profiles/r04_sp_tile_loader_ab.txt.)
-typedef __attribute__((address_space(1))) const void tl_gvoid;
-typedef __attribute__((address_space(3))) void tl_lvoid;
-struct TileWindow { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
-__device__ __forceinline__ TileWindow plan_tile_window(const uint32_t* idx, const uint32_t* left, int yb, int ye, int from, int win_cap, int lane) {
-    constexpr uint32_t OFF = ~kRowRepeats;
-    TileWindow w;
-    const int k = from + lane;
-    w.ve = idx[(k < ye ? k : ye) - yb];
-    w.vl = left[(k < ye ? k : ye - 1) - yb];
-    w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ve) & OFF;
-    const bool fits = lane >= 1 && k <= ye && (int)((w.ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
-    const unsigned long long m = __ballot(fits) >> 1;
-    int n = __builtin_ctzll(~m);                           // (bit 63 of ~m is always set: at most 63 rows)
-    w.direct = n == 0;                                     // the first row alone is too much for the window
-    if (n == 0) n = 1;
-    w.n = n;
-    w.wn = w.direct ? 0 : (int)(((uint32_t)__builtin_amdgcn_readlane((int)w.ve, n) & OFF) - w.w0);
-    return w;
-}
-
-template <int TW, int K>
-__global__ __launch_bounds__((TW + 1) * 64) void sp_iframe_tile_storer_kernel(const IFrameArgs* __restrict__ args, int X, int Y, int band_rows, int nspans,
-                                                                              int ntiles, int win_cap, int tile_words) {
-    constexpr int PPL = 4, SPAN = 64 * PPL;
-    constexpr int SPIN = 1 << 22;
-    constexpr int WMAX = 4;                                // win_cap <= 64 * WMAX (the launcher hands out 256 records per window)
-    static_assert((K & (K - 1)) == 0, "ring of 2^k rows");
-    extern __shared__ __align__(16) uint32_t lds[];
-    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    const IFrameArgs fa = args[blockIdx.x];
-    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // per resolver: [head: SPAN words][idx: band_rows + 1][left: band_rows][window: win_cap records][ring: K rows of SPAN words]; then the counters
-    const int idx_words = (band_rows + 1 + 3) & ~3, left_words = (band_rows + 3) & ~3;
-    lds_vu32* s_prod = (lds_vu32*)(lds + (size_t)TW * tile_words);      // [TW] rows a resolver has put into its ring
-    lds_vu32* s_cons = s_prod + TW;                                     // [TW] rows the storer has taken out of it
-    if (threadIdx.x < 2 * TW) s_prod[threadIdx.x] = 0u;
-    auto tile_of = [&](int w) { return (int)blockIdx.y * TW + w; };     // tiles of a frame in band-major order, TW per workgroup
-    if (fa.flat) {                                                      // (uniform over the workgroup)
-        if (wave < TW && tile_of(wave) < ntiles) {
-            const int tile = tile_of(wave), band = tile / nspans, span = tile - band * nspans;
-            const int yb = band * band_rows, ye = yb + band_rows < Y ? yb + band_rows : Y, x0 = span * SPAN + lane * PPL;
-            if (x0 < X)
-                for (int y = yb; y < ye; ++y) store4_global(dst + (size_t)y * X + x0, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
-        }
-        return;
-    }
-    __syncthreads();                                       // the counters are zero before anybody looks at them
-    const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
-    constexpr uint32_t OFF = ~kRowRepeats;
-
-    if (wave < TW) {
-        // ------------------------------------------ resolver wave ------------------------------------------
-        const int tile = tile_of(wave);
-        if (tile >= ntiles) return;
-        const int band = tile / nspans, span = tile - band * nspans;
-        const int yb = band * band_rows;
-        const int ye = yb + band_rows < Y ? yb + band_rows : Y;
-        const int xs = span * SPAN, x0 = xs + lane * PPL;
-        const bool active = x0 < X;
-        uint32_t* head = lds + (size_t)wave * tile_words;
-        uint32_t* idx = head + SPAN;
-        uint32_t* left = idx + idx_words;
-        uint2* win = reinterpret_cast<uint2*>(left + left_words);
-        uint32_t* ring = reinterpret_cast<uint32_t*>(win + win_cap);
-        const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
-        const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
-        for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
-        for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
-        *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
-        uint32_t p[PPL] = {0, 0, 0, 0};
-        if (yb > 0 && active) {
-            const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + j);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_wave_barrier();
-        uint32_t d24[PPL] = {0, 0, 0, 0}, dlo[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
-        const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
-        // the next window's records travel while the current window's rows are worked out (this wave issues nothing but these loads)
-        uint2 wv[WMAX];
-        auto fetch = [&](const TileWindow& w) {
-#pragma unroll
-            for (int q = 0; q < WMAX; ++q) {
-                const int kq = lane + 64 * q;
-                wv[q] = kq < w.wn ? load2_global(gruns + w.w0 + kq) : make_uint2(0, 0);
-            }
-        };
-        TileWindow nw = plan_tile_window(idx, left, yb, ye, yb, win_cap, lane);
-        fetch(nw);
-        int y = yb;
-        uint32_t rows_out = 0;                             // rows put into the ring so far
-        uint32_t cons_seen = 0;                            // the storer's progress as last read
-        while (y < ye) {
-            const TileWindow cw = nw;
-#pragma unroll
-            for (int q = 0; q < WMAX; ++q) {
-                const int k = lane + 64 * q;
-                if (k < cw.wn) win[k] = wv[q];
-            }
-            if (y + cw.n < ye) { nw = plan_tile_window(idx, left, yb, ye, y + cw.n, win_cap, lane); fetch(nw); }
-            uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 0);
-            uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 1);
-            {
-                const int nfirst = (int)((e1 & OFF) - cw.w0);
-                if (cw.direct) {                           // a row with more records than the window holds: scattered straight from memory
-                    for (int r = lane; r < nfirst; r += 64) {
-                        const uint2 q = load2_global(gruns + cw.w0 + r);
-                        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (!cw.direct)
-                    for (int r = lane; r < nfirst; r += 64) {
-                        const uint2 q = win[r];
-                        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
-                    }
-            }
-            for (int r = 0; r < cw.n; ++r, ++y) {
-                const bool more = r + 1 < cw.n;
-                const uint32_t e2 = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2) : e1;
-                const bool repeat = (e0 & kRowRepeats) != 0u;
-                const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw.vl, r);
-                const int n_next = (int)((e2 & OFF) - (e1 & OFF));
-                const int next_at = (int)((e1 & OFF) - cw.w0);
-                uint2 nrec = make_uint2(0, 0);
-                if (lane < n_next) nrec = win[next_at + lane];
-                uint32_t u0 = lane_to_the_left(p[PPL - 1]);
-                u0 = lane == 0 ? eg : u0;
-                if (!repeat) {
-                    const uint4 hv = *reinterpret_cast<const uint4*>(head + lane * PPL);
-                    *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
-                    const uint32_t h[PPL] = {hv.x, hv.y, hv.z, hv.w};
-                    uint32_t last = h[0];
-#pragma unroll
-                    for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
-                    const unsigned long long seen = __ballot(last != 0u);
-                    const uint32_t below_lo = (uint32_t)seen & lt_lo, below_hi = (uint32_t)(seen >> 32) & lt_hi;
-                    const uint32_t lead = min(ffbh(below_hi), ffbh(below_lo) + 32u);
-                    uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(~lead << 2), (int)last);
-#pragma unroll
-                    for (int j = 0; j < PPL; ++j) {
-                        w = h[j] ? h[j] : w;
-                        d24[j] = w;
-                        dlo[j] = w & 0x007F7F7Fu;
-                        m_above[j] = (uint32_t)((int32_t)(w << 7) >> 31);
-                        m_left[j] = (uint32_t)((int32_t)(w << 6) >> 31);
-                    }
-                }
-                uint32_t q[PPL];
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) {
-                    const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
-                    q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
-                }
-                // the row goes into the ring (slot rows_out mod K) once the storer is through with what the slot held
-                if (rows_out - cons_seen >= (uint32_t)K) {
-                    int spin = 0;
-                    for (; spin < SPIN; ++spin) {
-                        cons_seen = s_cons[wave];
-                        if (rows_out - cons_seen < (uint32_t)K) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (spin >= SPIN) return;             // (cannot happen: bounded so that a mistake ends the launch)
-                }
-                *reinterpret_cast<uint4*>(ring + (size_t)(rows_out & (K - 1)) * SPAN + lane * PPL) = make_uint4(q[0], q[1], q[2], q[3]);
-                ++rows_out;
-                if (lane == 0) s_prod[wave] = rows_out;    // (a wave's LDS operations execute in order: the row is there before the count)
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) p[j] = q[j];
-                if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + nrec.x) = nrec.y;
-                for (int k = lane + 64; k < n_next; k += 64) {
-                    const uint2 q2 = win[next_at + k];
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q2.x) = q2.y;
-                }
-                __builtin_amdgcn_wave_barrier();
-                e0 = e1;
-                e1 = e2;
-            }
-        }
-        return;
-    }
-
-    // ------------------------------------------ storer wave ------------------------------------------
-    uint32_t taken[TW], total[TW];
-    uint32_t* out[TW];
-    bool col[TW];
-    int open = 0;
-#pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        const int tile = tile_of(t);
-        taken[t] = 0;
-        total[t] = 0;
-        out[t] = dst;
-        col[t] = false;
-        if (tile < ntiles) {
-            const int band = tile / nspans, span = tile - band * nspans;
-            const int yb = band * band_rows, ye = yb + band_rows < Y ? yb + band_rows : Y, x0 = span * SPAN + lane * PPL;
-            total[t] = (uint32_t)(ye - yb);
-            out[t] = dst + (size_t)yb * X + x0;
-            col[t] = x0 < X;
-            ++open;
-        }
-    }
-    for (int guard = 0; guard < SPIN && open > 0; ++guard) {
-        bool any = false;
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            if (taken[t] >= total[t]) continue;
-            const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_prod[t]);
-            if (have == taken[t]) continue;
-            any = true;
-            const uint32_t* ring = lds + (size_t)t * tile_words + SPAN + idx_words + left_words + 2 * (size_t)win_cap;
-            // every row the resolver has ready: read out of the ring first (then its slots are free), stored after
-            uint4 rows[K];
-            const uint32_t n = have - taken[t];            // 1 .. K
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if ((uint32_t)k < n) rows[k] = *reinterpret_cast<const uint4*>(ring + (size_t)((taken[t] + k) & (K - 1)) * SPAN + lane * PPL);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) s_cons[t] = have;
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if ((uint32_t)k < n && col[t]) store4_global(out[t] + (size_t)(taken[t] + k) * X, rows[k]);
-            taken[t] = have;
-            if (taken[t] >= total[t]) --open;
-        }
-        if (!any) __builtin_amdgcn_s_sleep(1);
-    }
-}
+// (Round 4 tried two workgroup forms of the tile kernel above — tile waves + a LOADER wave that brings their record windows into LDS,
+// commit ee3facd; RESOLVER waves that put finished rows into an LDS ring + a STORER wave that does nothing but issue row stores, commit
+// 6651615 — both bit-exact, both slower in every configuration measured (505 - 553 us and 554 - 601 us against 450 - 474 us per 256 frames):
+// profiles/r04_sp_tile_loader_ab.txt, r04_sp_tile_storer_ab.txt.  One wave per tile stays.)
 
 constexpr int PWG = 256;  // 16 rows x 16 chunks of 4 pixels = 4 blocks side by side
 
@@ -1329,29 +1091,6 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     if (nframes <= 0) return;
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
-    static const int storer_tw = [] { const char* e = std::getenv("JSP_SP_TILE_STORER"); return e ? std::atoi(e) : 4; }();   // lab: 0 = one wave per tile, no storer wave
-    static const int ring_rows = [] { const char* e = std::getenv("JSP_SP_TILE_RING"); const int v = e ? std::atoi(e) : 4; return v == 2 || v == 4 || v == 8 ? v : 4; }();
-    if ((storer_tw == 4 || storer_tw == 7) && nframes <= 65535) {
-        // TW resolver waves + a storer wave per workgroup; a resolver's LDS: head row, row index, left column, a record window, a ring of K rows
-        const int TW = storer_tw, K = ring_rows;
-        const int idx_words = (t.rows + 1 + 3) & ~3, left_words = (t.rows + 3) & ~3;
-        int cap = 256;                                                   // records per window (2 KB)
-        const int tile_words = SPAN_WORDS + idx_words + left_words + 2 * cap + K * SPAN_WORDS;
-        const int ntiles = bands * t.nspans;
-        const dim3 grid(nframes, (ntiles + TW - 1) / TW);
-        const size_t lds = ((size_t)TW * tile_words + 2 * TW + 4) * 4;
-        static std::once_flag attr_once;
-        std::call_once(attr_once, [] {
-#define JSP_ATTR(TW_, K_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_storer_kernel<TW_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
-            JSP_ATTR(4, 2); JSP_ATTR(4, 4); JSP_ATTR(4, 8); JSP_ATTR(7, 2); JSP_ATTR(7, 4); JSP_ATTR(7, 8);
-#undef JSP_ATTR
-        });
-#define JSP_GO(TW_, K_) hipLaunchKernelGGL((sp_iframe_tile_storer_kernel<TW_, K_>), grid, dim3((TW_ + 1) * 64), lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, ntiles, cap, tile_words)
-        if (TW == 4) { if (K == 2) JSP_GO(4, 2); else if (K == 4) JSP_GO(4, 4); else JSP_GO(4, 8); }
-        else { if (K == 2) JSP_GO(7, 2); else if (K == 4) JSP_GO(7, 4); else JSP_GO(7, 8); }
-#undef JSP_GO
-        return;
-    }
     const char* e = std::getenv("JSP_SP_TILE_FASTEST");                 // lab: which index runs fastest in the launch order (read at every launch)
     const int tile_fastest = e && std::atoi(e) != 0 && nframes <= 65535;   // (frames fastest: 0.616 of 8 TB/s, tiles fastest 0.573, same buffers; rotating the bands per frame: no change)
     const dim3 grid = tile_fastest ? dim3(bands * t.nspans, nframes) : dim3(nframes, bands * t.nspans);
