@@ -1069,7 +1069,6 @@ bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; 
 // each with a longer serial row step)
 int iframe_tile_span(const Geometry&) { return 256; }   // (8 pixels per lane, 512-column spans: 0.71 vs 0.54 ms, profiles/r03_fused_notes.txt)
 namespace {
-constexpr int SPAN_WORDS = 256;
 struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {
     TilePlan t;
