@@ -239,9 +239,17 @@ struct Msv1Codec : jsp_codec {
     }
     bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
     bool counted_async = false;   // this instance is in g_async_streams
-    hipStream_t up_stream = nullptr;
+    // The copy engine takes a frame's bytes up on a stream of its own, next to the previous frame's kernel.  One such stream is enough: a
+    // megabyte per copy goes at ~30 GB/s on one stream where the bus takes 57 (bench.py: e2e.h2d_ceiling_GBs), but taking consecutive frames up
+    // on 2 - 4 streams in turn (JSP_MSV1_UP_STREAMS, lab) changes nothing for one player stream (55.5 Gpixels/s with 1, 2, 3 or 4: the frames'
+    // kernels follow each other on one HIP stream, 37 us apiece, and that chain is the bound) and costs 3 - 40 % with two (profiles/
+    // r04_msv1_up_streams.txt).
+    static constexpr int kUpStreamsMax = 4;
+    hipStream_t up_streams[kUpStreamsMax] = {nullptr, nullptr, nullptr, nullptr};
+    int up_count = [] { const char* e = std::getenv("JSP_MSV1_UP_STREAMS"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : (v > kUpStreamsMax ? kUpStreamsMax : v); }();
+    unsigned up_next = 0;
     ~Msv1Codec() override {
-        if (up_stream) (void)hipStreamDestroy(up_stream);
+        for (hipStream_t s : up_streams) if (s) (void)hipStreamDestroy(s);
         if (counted_async) g_async_streams.fetch_sub(1);
     }
     // block_changes is only maintained by the host parser; after frames parsed on the GPU it is
@@ -472,6 +480,7 @@ struct Msv1Codec : jsp_codec {
             // GPU: 57 against 68 Gpixels/s), the kernels then fetch the bytes themselves
             st->dma = opt_async_auto ? g_async_streams.load() <= kDmaStreams : opt_async_dma;
             if (st->dma) {   // the copy engine brings the bytes up on a stream of its own, next to the previous frame's kernel
+                hipStream_t& up_stream = up_streams[up_next++ % (unsigned)up_count];
                 if (!up_stream) JSP_HIP(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
                 if (!st->uploaded) JSP_HIP(hipEventCreateWithFlags(&st->uploaded, hipEventDisableTiming));
                 JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, up_stream));

@@ -27,7 +27,7 @@ for step in "$@"; do
       for w in msvideo1_16_1080p_keyframes_m1_hostdesc msvideo1_8_1080p_keyframes_m1 msvideo1_16_1080p_keyframes_solid \
                msvideo1_16_1080p_keyframes_eight msvideo1_16_1080p_inter70 screenpressor_v4_1080p_iframes \
                screenpressor_v2_1080p_iframes screenpressor_v4_1080p_pclip300; do
-        timeout -k 10 600 python bench.py --workload $w --steps 20 --warmup 3 >> "$O/${T}_bench_all.jsonl" 2>> "$O/${T}_bench_all.err" || { tail -20 "$O/${T}_bench_all.err"; exit 1; }
+        timeout -k 10 600 python bench.py --workload $w --steps 20 --warmup 5 >> "$O/${T}_bench_all.jsonl" 2>> "$O/${T}_bench_all.err" || { tail -20 "$O/${T}_bench_all.err"; exit 1; }
         echo "done $w"
       done ;;
     profile:*)
