@@ -158,7 +158,7 @@ private:
     int cx_ = 0, cx1_ = 0, cxshift_;
     int version_ = 0;               // which entropy coder ec_ is (2, 3, 4); pinned by the first coded key frame
     std::unique_ptr<EntropyDecoder> ec_;
-    std::vector<int32_t> shadow_[2];  // [cur_] is being written, [1-cur_] is the previous frame
+    BigVector<int32_t> shadow_[2];    // [cur_] is being written, [1-cur_] is the previous frame (huge-page candidates: sp_models.h)
     int cur_ = 0;
     bool has_prev_ = false;     // prevFrame != null
     bool decoded_i_ = false;
