@@ -49,6 +49,15 @@ class NativeCodec implements IVideoCodec {
     // ---- IVideoCodec (IVideoCodec.hx:16-29) ---------------------------------------------------------------------------
     public function Preinit(insignificant_lines:Int):Void {
         JspNative.preinit(h, insignificant_lines);
+        JspNative.setOption(h, "key_frame_compare", Std.string(insignificant_lines));   // key frames compared while they decode (KeyFrameDiffers)
+    }
+
+    /** Manager.frames_differ_significantly's pixel loop (Manager.hx:413-419) comes with the decode: after Preinit every key frame is
+        compared with the frame before it from `insignificant_lines` on (option "key_frame_compare"); null = nothing to compare with
+        (the Manager's `prev == null` / first-frame cases). */
+    public function KeyFrameDiffers():Null<Bool> {
+        var v = JspNative.keyFrameDiffers(h);
+        return v < 0 ? null : v != 0;
     }
 
     public function PreviousFrame():FrameBuffer {
