@@ -48,32 +48,6 @@ struct Msv1Staged : jsp_staged {
     bool needs_desc = false;   // some launch reads the descriptor table the parse kernels build
     std::vector<uint32_t> scrub;   // (tests: option "msv1_scrub_tables") frames whose table a replay rewrites: poisoned before it does
     bool any_fused = false;
-    // A replay's table-writing parse in PIECES, next to the launches that read the tables: the parse of piece i + 1 runs on a stream of
-    // its own while the temporal launch of piece i (the group cut at the piece's frames) runs on the caller's — the parse is a chain of
-    // short dependent steps per tile, the temporal launch a stream of stores, and the two overlap almost completely (17 % of the step
-    // was the parse: profiles/r03_msvideo1_16_1080p_inter70_kernel_stats.csv).  A piece = frames [f0, f1) = tile records [t0, t1) of
-    // d_recs_emit (tile-major within the piece).
-    struct Piece { int f0, f1; uint32_t t0, t1; };
-    std::vector<Piece> pieces;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr;
-    std::vector<hipEvent_t> ev_piece;
-    ~Msv1Staged() override {
-        for (hipEvent_t e : ev_piece) if (e) (void)hipEventDestroy(e);
-        if (ev_main) (void)hipEventDestroy(ev_main);
-        if (side) (void)hipStreamDestroy(side);
-    }
-    bool piecewise_ready() {
-        if (pieces.size() < 2) return false;
-        if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side = nullptr; return false; }
-        if (!ev_main && hipEventCreateWithFlags(&ev_main, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_main = nullptr; return false; }
-        while (ev_piece.size() < pieces.size()) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
-            ev_piece.push_back(e);
-        }
-        return true;
-    }
 
     void launch_parse(hipStream_t stream) {
         msv1_launch_parse(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
@@ -89,39 +63,15 @@ struct Msv1Staged : jsp_staged {
         // A replay re-executes the whole device pipeline: with the on-GPU parse that includes the
         // parse kernels, so a staged batch can be timed from raw stream bytes.  (The first decode
         // uses the tables the staging pass left behind.)
-        bool piecewise = false;
-        if (gpu_parse && decoded && needs_desc)   // the fused kernel's parse, writing block tables instead of pixels
+        if (gpu_parse && decoded && needs_desc)   // one launch: the fused kernel's parse, writing block tables instead of pixels
         {
-            piecewise = piecewise_ready();
-            hipStream_t ps = piecewise ? side : stream;
-            if (piecewise) {   // the tables are rewritten: whatever the caller's stream still has queued may be reading them
-                JSP_HIP(hipEventRecord(ev_main, stream));
-                JSP_HIP(hipStreamWaitEvent(side, ev_main, 0));
-            }
             for (uint32_t i : scrub)
                 JSP_HIP(hipMemsetAsync(static_cast<uint32_t*>(d_desc.p) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE,
-                                       sizeof(uint32_t) * (size_t)geo.nblocks, ps));
-            if (piecewise) {
-                for (size_t i = 0; i < pieces.size(); ++i) {
-                    msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                                      static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), pieces[i].t0, (int)(pieces[i].t1 - pieces[i].t0),
-                                      static_cast<uint32_t*>(d_sync.p), side, nullptr, 0, 4);
-                    JSP_HIP(hipEventRecord(ev_piece[i], side));
-                }
-            } else {
-                msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                                  static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
-                                  nullptr, 0, 4);
-            }
+                                       sizeof(uint32_t) * (size_t)geo.nblocks, stream));
+            msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
+                              static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
+                              nullptr, 0, 4);
         }
-        // (piecewise) the caller's stream waits for the tables of frames [.., upto) before a launch that reads them
-        size_t waited = 0;
-        auto need_tables = [&](int upto) {
-            while (piecewise && waited < pieces.size() && pieces[waited].f0 < upto) {
-                JSP_HIP(hipStreamWaitEvent(stream, ev_piece[waited], 0));
-                ++waited;
-            }
-        };
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
         for (const Group& g : groups) {
@@ -132,30 +82,16 @@ struct Msv1Staged : jsp_staged {
                 msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs.p), d_palette,
                                   static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), tile0, (int)(last.first_tile + last.ntiles - tile0),
                                   static_cast<uint32_t*>(d_sync.p), stream, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);
-            } else if (g.temporal) {
-                // cut at the piece boundaries: a part starts as soon as its own tables are there (its first written frame takes the
-                // pixels of the frame before it from HBM, where the part before has just left them)
-                int lo = g.first;
-                const int end = g.first + g.count;
-                while (lo < end) {
-                    int hi = end;
-                    if (piecewise)
-                        for (const Piece& p : pieces)
-                            if (p.f1 > lo && p.f1 < hi) { hi = p.f1; break; }
-                    need_tables(hi);
-                    msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const uint32_t*>(d_desc.p), frames + lo, hi - lo,
-                                                d_palette, stream);
-                    lo = hi;
-                }
-            } else {
-                need_tables(g.first + g.count);
+            } else if (g.temporal)
+                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
+                                            static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette,
+                                            stream);
+            else
                 msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p),
                                    static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count,
                                    d_palette, vec_ok, stream);
-            }
             if (g.edge_compare) msv1_launch_edge_compare(geo, frames + g.first, g.count, stream);
         }
-        need_tables(nframes);                     // (every piece's parse is joined: the fault word below is final, nothing of this decode is left on the side stream)
         JSP_HIP(hipGetLastError());
         if (need_signif)
             JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
@@ -916,7 +852,6 @@ struct Msv1Codec : jsp_codec {
         {
             st->needs_desc = false;
             st->any_fused = false;
-            st->pieces.clear();
             st->kernels.clear();
             uint64_t moved = 0;
             for (const auto& g : st->groups) {
@@ -1032,29 +967,7 @@ struct Msv1Codec : jsp_codec {
                             r.cmp_row_lo = 0xFFFFFFFFu;
                             r.flags = (h_pf[i].host_parsed || in_fused[i]) ? MSV1_TILE_SKIP : 0u;
                         }
-                    // replays write the tables in pieces next to the launches that read them (Msv1Staged::pieces): tile-major inside a piece
-                    st->pieces.clear();
-                    {
-                        static const int want = [] { const char* e = std::getenv("JSP_MSV1_PARSE_PIECES"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();   // lab: 1 = one parse launch in front
-                        const int np = nf >= 32 * want ? want : 1;
-                        for (int i = 0; i < np; ++i) {
-                            const int f0 = (int)((long)nf * i / np), f1 = (int)((long)nf * (i + 1) / np);
-                            if (f1 <= f0) continue;
-                            tile_major(er, f0, f1);
-                            st->pieces.push_back({f0, f1, h_pf[f0].first_tile, h_pf[f1 - 1].first_tile + h_pf[f1 - 1].ntiles});
-                        }
-                        // what the cut costs: a launch per piece, and a temporal group cut at a piece's end reads the frame before the cut once more
-                        if (st->pieces.size() > 1) {
-                            st->info.kernel_launches += st->pieces.size() - 1;
-                            for (const auto& g : st->groups)
-                                if (g.temporal)
-                                    for (const auto& p : st->pieces)
-                                        if (p.f1 > g.first && p.f1 < g.first + g.count) {
-                                            ++st->info.kernel_launches;
-                                            st->info.moved_bytes += 64 * (uint64_t)geo.nblocks;
-                                        }
-                        }
-                    }
+                    tile_major(er, 0, nf);
                     JSP_HIP(hipMemcpyAsync(st->d_recs_emit.p, er, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
                     st->scrub.clear();
                     if (opt_scrub_tables)
