@@ -106,3 +106,37 @@ def test_measure_fill_reports_a_store_rate_and_refuses_bad_arguments():
     assert "bad argument" in N.last_error()
     assert lib.jsp_measure_fill(C.c_void_p(buf.data_ptr()), C.c_size_t(64), 1, C.byref(rate), None) != 0
     assert lib.jsp_measure_fill(None, C.c_size_t(1 << 20), 1, C.byref(rate), None) != 0
+
+
+def test_measure_h2d_and_the_bounded_pool_probe(monkeypatch):
+    """jsp_measure_h2d (bench.py: e2e.h2d_ceiling_GBs): a plausible rate for pinned host-to-device copies, bad arguments refused.
+    jsp_pool_create's placement probe is bounded: JSP_POOL_PROBE_MAX candidates at most, never more held than its limit, and
+    jsp_pool_probe_info says what it cost; a small pool is not probed at all."""
+    import ctypes as C
+    from jsplayer_amd import _native as N
+    from jsplayer_amd.codec import FramePool
+    lib = N.lib()
+    rate = C.c_double(0.0)
+    assert lib.jsp_measure_h2d(0, 4 << 20, 2, 4, C.byref(rate)) == 0
+    assert 1.0 < rate.value < 200.0, rate.value                 # GB/s: PCIe 5 x16 is 64 GB/s; anything sane passes
+    assert lib.jsp_measure_h2d(0, 0, 1, 1, C.byref(rate)) != 0 and lib.jsp_measure_h2d(0, 1 << 20, 0, 1, C.byref(rate)) != 0
+    assert lib.jsp_measure_h2d(0, 1 << 20, 17, 1, C.byref(rate)) != 0 and lib.jsp_measure_h2d(0, 1 << 20, 1, 1, None) != 0
+    assert lib.jsp_measure_h2d(99, 1 << 20, 1, 1, C.byref(rate)) != 0
+    monkeypatch.setenv("JSP_POOL_PROBE_MAX", "2")
+    pool = FramePool(1920, 1080, 32)
+    try:
+        assert 1 <= pool.attempts <= 2 and pool.store_rate > 100.0
+        assert pool.probe_ms > 0 and 32 * 1920 * 1080 * 4 <= pool.held_bytes <= 2 * 32 * 1920 * 1080 * 4 and pool.held_bytes <= pool.hold_limit
+    finally:
+        pool.close()
+    monkeypatch.setenv("JSP_POOL_PROBE_HOLD_GB", "0.1")          # less than one candidate: the pool itself is still allowed, nothing beside it
+    pool = FramePool(1920, 1080, 32)
+    try:
+        assert pool.attempts == 1 and pool.held_bytes == 32 * 1920 * 1080 * 4 == pool.hold_limit
+    finally:
+        pool.close()
+    small = FramePool(320, 240, 9)
+    try:
+        assert small.attempts == 0 and small.store_rate == 0 and small.probe_ms == 0 and small.held_bytes == 0
+    finally:
+        small.close()
