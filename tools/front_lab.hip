@@ -66,6 +66,36 @@ __global__ __launch_bounds__(64) void band_kernel(uint32_t* __restrict__ pool, i
     }
 }
 
+// the ScreenPressor inter-frame group kernel's store shape: workgroups that own a piece of the picture and write it into `nframes` consecutive frames
+//   wide = 0: 256 lanes = 8 blocks x 16 rows, a wave's store = two 512-byte row segments (rows r and r + 8), 2 stores per lane and frame (sp_pframe_group_kernel)
+//   wide = 1: 256 lanes = 16 blocks x 16 rows, a wave's store = ONE 1 KB row segment, 4 stores per lane and frame (rows 4w .. 4w + 3 of wave w)
+__global__ __launch_bounds__(256) void group_kernel(uint32_t* __restrict__ pool, int nframes, int wide) {
+    const int tid = threadIdx.x;
+    uint32_t a = (uint32_t)(blockIdx.x * 131 + blockIdx.y * 7 + tid);
+    if (!wide) {
+        const int r = tid >> 5, ch = tid & 31;
+        const int x0 = (int)blockIdx.x * 128 + ch * 4, ya = (int)blockIdx.y * 16 + r, yb = ya + 8;
+        if (x0 >= X) return;
+        for (int f = 0; f < nframes; ++f) {
+            uint32_t* dst = pool + (size_t)f * X * Y;
+            a = a * 1664525u + 1013904223u;
+            if (ya < Y) *(gu32x4*)(dst + (size_t)ya * X + x0) = u32x4{a, a + 1, a + 2, a + 3};
+            if (yb < Y) *(gu32x4*)(dst + (size_t)yb * X + x0) = u32x4{a, a + 1, a + 2, a + 4};
+        }
+    } else {
+        const int w = tid >> 6, lane = tid & 63;
+        const int x0 = (int)blockIdx.x * 256 + lane * 4, y0 = (int)blockIdx.y * 16 + w * 4;
+        if (x0 >= X) return;
+        for (int f = 0; f < nframes; ++f) {
+            uint32_t* dst = pool + (size_t)f * X * Y;
+            a = a * 1664525u + 1013904223u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (y0 + k < Y) *(gu32x4*)(dst + (size_t)(y0 + k) * X + x0) = u32x4{a, a + 1, a + 2, a + (uint32_t)k};
+        }
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -157,6 +187,20 @@ int main(int argc, char** argv) {
                     CK(hipEventSynchronize(e1));
                     CK(hipEventElapsedTime(&band_ms, e0, e1));
                 }
+                float group_ms[2] = {0, 0};
+                for (int wide = 0; wide < 2; ++wide) {
+                    const int GF = F < 299 ? F : 299;
+                    auto go = [&] { hipLaunchKernelGGL(group_kernel, dim3(wide ? 8 : 15, 68), dim3(256), 0, 0, pools[k], GF, wide); };
+                    go();
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 3; ++i) go();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&group_ms[wide], e0, e1));
+                    group_ms[wide] = (float)((double)GF * FRAME_BYTES * 3 / group_ms[wide] / 1e6);
+                }
+                printf("pool %d: group shape (299 frames per workgroup): 8 blocks x 16 rows, 2 x 512 B per wave %5.0f | 16 blocks x 16 rows, 1 KB per wave %5.0f GB/s\n", k, group_ms[0], group_ms[1]);
                 printf("pool %d: plain fill %5.0f | band-walking waves %5.0f | ", k, (double)F * FRAME_BYTES * 3 / fill_ms / 1e6, (double)F * FRAME_BYTES * 3 / band_ms / 1e6);
                 printf("tile-major %5.0f | frame-major %5.0f | staggered %5.0f | scattered %5.0f GB/s\n", (double)F * FRAME_BYTES * 3 / by_order[1] / 1e6,
                        (double)F * FRAME_BYTES * 3 / by_order[0] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[2] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[3] / 1e6);
