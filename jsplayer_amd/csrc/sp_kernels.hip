@@ -197,6 +197,11 @@ __device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFF
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
+#if defined(JSP_SP_LAB_CACHED_RECORDS)
+#define JSP_TILE_OFF(x) ((x) & 1020u)
+#else
+#define JSP_TILE_OFF(x) (x)
+#endif
 __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
                                                             int band_rows, int nspans, int win_cap, int tile_fastest) {
     constexpr int PPL = 4, SPAN = 64 * PPL;
@@ -254,6 +259,10 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     // re-read its last record) and every row issues exactly one row store, so after R rows `s_waitcnt vmcnt(R)` says precisely
     // "the window's records have landed" while the R stores behind them stay in flight.
     unsigned long long wva[WMAX];
+    // (Tried and not kept, round 4: touching the window AFTER the next as well — one LDS-DMA load per window into a sink, so that the
+    // records are in the caches when the real request comes.  With every window read out of the same 8 KB the launch takes 0.39 - 0.42 ms
+    // instead of 0.47 (profiles/r04_sp_tile_parts.txt), but the touch itself made it 0.49 - 0.51 at 7 and at 8 waves per SIMD alike
+    // (profiles/r04_sp_tile_touch_ab.txt): what the cached build saves is the requests, not the wait for them.)
     struct Window { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
     auto plan_and_fetch = [&](int from) {
         Window w;
@@ -271,7 +280,11 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
             const int kq = lane + 64 * q, kk = kq < w.wn ? kq : (w.wn > 0 ? w.wn - 1 : 0);
+#if defined(JSP_SP_LAB_CACHED_RECORDS)   // lab: every window comes out of the same 8 KB of the frame's records (cache hits: the kernel's reads never reach DRAM); pixels are garbage
+            const uint2* src = gruns + ((w.w0 + kk) & 1023u);
+#else
             const uint2* src = gruns + w.w0 + kk;              // (always a record of this tile)
+#endif
 #if defined(JSP_SP_LAB_NOFETCH)   // lab (with JSP_SP_LAB_STOREONLY): the row loop without its record fetches — no load at all behind the row stores
             wva[q] = (unsigned long long)(uintptr_t)src;
 #else
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             if (cw.direct) {
                 for (int r = lane; r < nfirst; r += 64) {
                     const uint2 q = load2_global(gruns + cw.w0 + r);
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(q.x)) = q.y;
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);            // (its scatter read straight from memory)
             }
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             if (!cw.direct)
                 for (int r = lane; r < nfirst; r += 64) {
                     const uint2 q = win[r];
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q.x) = q.y;
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(q.x)) = q.y;
                 }
         }
 #if defined(JSP_SP_LAB_STOREONLY)   // lab: the row stores and nothing else
@@ -388,10 +401,10 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 #pragma unroll
             for (int j = 0; j < PPL; ++j) p[j] = q[j];
             ++rows_since_fetch;                                // (one row store per row, issued by every wave with an active lane)
-            if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + nrec.x) = nrec.y;
+            if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(nrec.x)) = nrec.y;
             for (int k = lane + 64; k < n_next; k += 64) {     // rows with more records than lanes
                 const uint2 q2 = win[next_at + k];
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + q2.x) = q2.y;
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(q2.x)) = q2.y;
             }
             __builtin_amdgcn_wave_barrier();
             e0 = e1;

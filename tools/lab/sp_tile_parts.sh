@@ -10,16 +10,12 @@ build() {  # $1 = dir, $2 = extra flags
 build /tmp/alt_nostore "-DJSP_SP_LAB_NOSTORE"
 build /tmp/alt_storeonly "-DJSP_SP_LAB_STOREONLY"
 build /tmp/alt_nofetch "-DJSP_SP_LAB_STOREONLY -DJSP_SP_LAB_NOFETCH"
-build /tmp/alt_sleep1 "-DJSP_SP_LAB_STOREONLY -DJSP_SP_LAB_NOFETCH -DJSP_SP_LAB_SLEEP=1"
-build /tmp/alt_sleep2 "-DJSP_SP_LAB_STOREONLY -DJSP_SP_LAB_NOFETCH -DJSP_SP_LAB_SLEEP=2"
-build /tmp/alt_sleep4 "-DJSP_SP_LAB_STOREONLY -DJSP_SP_LAB_NOFETCH -DJSP_SP_LAB_SLEEP=4"
+build /tmp/alt_cached "-DJSP_SP_LAB_CACHED_RECORDS"
 one() { (cd $1 && python bench.py --workload screenpressor_v4_1080p_iframes --steps 30 --warmup 5 --no-e2e --no-cpu-baseline --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['frac'], d['config']['destination_frames']['probe_GBs'])"); }
 for i in 1 2; do
   echo -n "whole      "; one $R
   echo -n "no stores  "; one /tmp/alt_nostore
   echo -n "stores only"; one /tmp/alt_storeonly
   echo -n "stores only, no record fetches in the loop"; one /tmp/alt_nofetch
-  echo -n "... a sleep of 1 x 1024 cycles before every row store"; one /tmp/alt_sleep1
-  echo -n "... 2 x 1024 cycles"; one /tmp/alt_sleep2
-  echo -n "... 4 x 1024 cycles"; one /tmp/alt_sleep4
+  echo -n "whole, every record window read out of the same 8 KB (cache hits; pixels garbage)"; one /tmp/alt_cached
 done
