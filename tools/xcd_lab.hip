@@ -9,6 +9,9 @@
 //   mode 4  N looping workgroups, runs of 16 pieces (64 KB) handed out by an atomic counter   (dynamic split, coarse: one atomic per 64 KB)
 //   mode 5  one run of 16 pieces per workgroup, address order                   (fresh workgroups, 64 KB each)
 //   mode 6  as 4, the next ticket asked for before the current run is written   (the ticket's round trip hidden)
+//   mode 7  one piece per workgroup, but the eight dispatch classes (workgroup id mod 8 = the XCD the hardware deals it to) own
+//           UNEQUAL contiguous shares of the buffer, sized from the classes' end times in the pass before (three rounds): the XCDs
+//           that get less from memory get fewer pieces, surplus workgroups of a class leave at once
 // and has every workgroup note its XCC id, CU id and the clock when it began and ended; the summary is per XCD.
 //   hipcc -O3 --offload-arch=gfx950 tools/xcd_lab.hip -o tools/xcd_lab.bin && tools/xcd_lab.bin [MB] [N]
 #include <hip/hip_runtime.h>
@@ -26,7 +29,8 @@ struct Note { unsigned long long t0, t1; uint32_t xcc, cu, pieces, pad; };
 __device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xF; }
 __device__ __forceinline__ uint32_t hw_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
 
-__global__ __launch_bounds__(256) void lab_kernel(u32x4* __restrict__ dst, size_t npieces, int mode, unsigned long long* __restrict__ counter, Note* __restrict__ notes) {
+struct Shares { uint32_t first[8], count[8]; };
+__global__ __launch_bounds__(256) void lab_kernel(u32x4* __restrict__ dst, size_t npieces, int mode, unsigned long long* __restrict__ counter, Note* __restrict__ notes, Shares sh) {
     __shared__ unsigned long long s_next;
     const unsigned long long t0 = (unsigned long long)wall_clock64();
     uint32_t done = 0;
@@ -42,6 +46,9 @@ __global__ __launch_bounds__(256) void lab_kernel(u32x4* __restrict__ dst, size_
     } else if (mode == 3) {
         const size_t per = (npieces + N - 1) / N, lo = blockIdx.x * per, hi = lo + per < npieces ? lo + per : npieces;
         for (size_t p = lo; p < hi; ++p) piece(p);
+    } else if (mode == 7) {
+        const uint32_t c = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        if (j < sh.count[c]) piece((size_t)sh.first[c] + j);
     } else if (mode == 5) {
         for (size_t p = (size_t)blockIdx.x * 16; p < (size_t)blockIdx.x * 16 + 16 && p < npieces; ++p) piece(p);
     } else if (mode == 4 || mode == 6) {
@@ -84,7 +91,7 @@ int main(int argc, char** argv) {
     unsigned long long* counter;
     CK(hipMalloc(&counter, 8));
     Note* d_notes;
-    const size_t maxwg = std::max<size_t>(npieces, (size_t)N);
+    const size_t maxwg = 2 * std::max<size_t>(npieces, (size_t)N);
     CK(hipMalloc(&d_notes, sizeof(Note) * maxwg));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -92,16 +99,34 @@ int main(int argc, char** argv) {
     int clk_khz = 0;
     CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, 0));
     printf("%zu MB in 4 KB pieces, %d looping workgroups, wall clock %d kHz\n", mb, N, clk_khz);
-    const char* names[7] = {"one piece per workgroup", "looping, grid-stride", "looping, atomic queue", "looping, contiguous runs", "looping, queue of 64 KB runs",
-                            "one 64 KB run per workgroup", "looping, 64 KB runs, ticket ahead"};
+    const char* names[8] = {"one piece per workgroup", "looping, grid-stride", "looping, atomic queue", "looping, contiguous runs", "looping, queue of 64 KB runs",
+                            "one 64 KB run per workgroup", "looping, 64 KB runs, ticket ahead", "one piece per workgroup, XCD shares"};
+    double share[8], class_end[8];
+    Shares sh{};
+    for (int c = 0; c < 8; ++c) { share[c] = 0.125; class_end[c] = 1; }
     for (int pass = 0; pass < 2; ++pass)
-        for (int mode : {0, 1, 3, 4, 5, 6}) {
-            const unsigned grid = mode == 0 ? (unsigned)npieces : mode == 5 ? (unsigned)((npieces + 15) / 16) : (unsigned)N;
+        for (int mode : {0, 1, 3, 7, 7, 7, 7, 0}) {
+            if (mode == 0) for (int c = 0; c < 8; ++c) share[c] = 1.0 / 8;
+            if (mode == 7) {   // new shares from the end times of the launch before: a class that ended late gets less
+                double sum = 0;
+                for (int c = 0; c < 8; ++c) { share[c] = share[c] / class_end[c]; sum += share[c]; }
+                uint32_t at = 0;
+                for (int c = 0; c < 8; ++c) {
+                    sh.first[c] = at;
+                    sh.count[c] = c == 7 ? (uint32_t)npieces - at : (uint32_t)(share[c] / sum * npieces);
+                    share[c] = (double)sh.count[c] / npieces;
+                    at += sh.count[c];
+                }
+            }
+            uint32_t most = 0;
+            for (int c = 0; c < 8; ++c) most = std::max(most, sh.count[c]);
+            const unsigned grid = mode == 0 ? (unsigned)npieces : mode == 7 ? most * 8u : mode == 5 ? (unsigned)((npieces + 15) / 16) : (unsigned)N;
+            if (grid > maxwg) { printf("shares too far apart\n"); return 1; }
             float best = 1e9f;
             for (int rep = 0; rep < 4; ++rep) {
                 CK(hipMemset(counter, 0, 8));
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(lab_kernel, dim3(grid), dim3(256), 0, 0, buf, npieces, mode, counter, d_notes);
+                hipLaunchKernelGGL(lab_kernel, dim3(grid), dim3(256), 0, 0, buf, npieces, mode, counter, d_notes, sh);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms;
@@ -122,7 +147,23 @@ int main(int argc, char** argv) {
                     if ((int)n.xcc == x) { ++wgs; pieces += n.pieces; last = std::max(last, n.t1); first_end = std::min(first_end, n.t1); }
                 if (wgs) printf(" [%d %llu %.0f]", wgs, pieces, (double)(last - start) * 1e3 / clk_khz);
             }
-            if (mode != 0 && mode != 5) {   // how far apart do the looping workgroups finish?
+            if (mode == 0 || mode == 7) {   // per dispatch class (workgroup id mod 8): is it one XCD, when did it end, what share did it have
+                printf(" | per class (xcc, share %%, last end us):");
+                for (int c = 0; c < 8; ++c) {
+                    unsigned long long last = 0;
+                    int xcc = -1;
+                    bool one = true;
+                    for (size_t g = c; g < notes.size(); g += 8) {
+                        if (notes[g].pieces == 0) continue;
+                        if (xcc < 0) xcc = (int)notes[g].xcc;
+                        one = one && xcc == (int)notes[g].xcc;
+                        last = std::max(last, notes[g].t1);
+                    }
+                    class_end[c] = (double)(last - start) * 1e3 / clk_khz;
+                    printf(" [%d%s %.2f %.0f]", xcc, one ? "" : "!", 100.0 * (mode == 7 ? share[c] : 0.125), class_end[c]);
+                }
+            }
+            if (mode != 0 && mode != 5 && mode != 7) {   // how far apart do the looping workgroups finish?
                 std::vector<double> ends;
                 for (const Note& n : notes) ends.push_back((double)(n.t1 - start) * 1e3 / clk_khz);
                 std::sort(ends.begin(), ends.end());
