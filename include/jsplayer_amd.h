@@ -140,7 +140,11 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       group (the loader-wave kernel).  n: the launch is split along the time axis too — a workgroup emits n frames and exits, and
  *       finds the pixels it starts from by a last-writer look-back over the block records (every frame of the group then needs a
  *       buffer of its own).  Measured slower on MI355X; kept as a launch plan that needs no long-lived workgroups.
- *       Results do not depend on it. */
+ *       Results do not depend on it.
+ *   "msv1_parse_pieces" = "1" (default) .. "16" : MSVideo1 with "msv1_parse" = "gpu", staged batches with inter frames.  A replay of
+ *       such a batch writes its block tables with one launch and paints from them with the next; n > 1: the tables are written in
+ *       n pieces of frames on a second stream, and the inter-frame launches — cut at the same frames — paint piece p while piece
+ *       p + 1 is parsed.  Measured slower on MI355X.  Results do not depend on it. */
 /*   "msv1_async" = "auto" (default) | "one_launch_dma" | "one_launch" | "two_launches" : MSVideo1 with "msv1_parse" = "gpu",
  *       asynchronous calls only; frames of up to 128 parse tiles (2 MiB).  auto: one_launch_dma while at most 3 codec instances
  *       of the process use this path, one_launch beyond (many streams: the copy queues are the bottleneck).  one_launch_dma: the copy engine brings the frame's bytes up on a

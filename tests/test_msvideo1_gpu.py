@@ -242,6 +242,54 @@ def test_batch_with_inter_frames_matches_oracle():
 
 
 @pytest.mark.parametrize("bits", [16, 8])
+@pytest.mark.parametrize("pieces", [2, 3, 5])
+def test_replay_parses_in_pieces_beside_the_inter_frame_launches(bits, pieces):
+    """Option msv1_parse_pieces: a replay of a staged batch writes its block tables piece by piece on a second stream while the
+    temporal launches — cut at the same frames — paint the piece before.  Same frames, flags and adoption as the oracle after the
+    first decode and after two replays, with the tables poisoned before each replay (whatever comes out right was rebuilt)."""
+    if PARSE_MODE != "gpu":
+        pytest.skip("on-GPU parse only")
+    w, h, n = 132, 76, 97 + 32 * pieces
+    frames, keys, pal = sg.msv1_clip(11 + pieces, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 25.0), key_every=n + 1)
+    gpu = make_gpu(bits, w, h, pal)
+    gpu.Preinit(36)
+    gpu.set_option("msv1_parse_pieces", str(pieces))
+    gpu.set_option("msv1_scrub_tables", "1")
+    nbuf = 5                                                   # (buffers repeat inside the group)
+    dsts = [dev_buf(w * h, 3) for _ in range(nbuf)]
+    st = gpu.stage_batch(frames, [dsts[i % nbuf] for i in range(n)], is_key=keys)
+    assert "msv1_blocks_temporal_kernel" in st.kernels()
+    orc = OracleMSVideo1(bits, w, h, pal)
+    orc.Preinit(36)
+    obufs = [np.full(w * h, 3, dtype=np.int32) for _ in range(nbuf)]
+    want_sig, want_adopted = [], []
+    for i in range(n):
+        if keys[i]:
+            orc.DecompressI(frames[i], obufs[i % nbuf])
+            want_sig.append(None)
+            want_adopted.append(None)
+        else:
+            data, sig = orc.DecompressP(frames[i], obufs[i % nbuf])
+            want_sig.append(sig)
+            want_adopted.append(data is obufs[i % nbuf])
+    for run in range(3):
+        for d in dsts:
+            d.fill_(3)
+        st.decode()
+        gpu.sync()
+        status, adopted, signif = st.results()
+        assert status == [0] * n
+        for i in range(n):
+            if want_sig[i] is not None:
+                assert bool(signif[i]) == want_sig[i], (run, i)
+                assert bool(adopted[i]) == want_adopted[i], (run, i)
+        for k in range(nbuf):
+            assert np.array_equal(obufs[k], to_np(dsts[k])), (run, k)
+    assert gpu.counter("lookback_fallbacks") == 0
+    st.close()
+
+
+@pytest.mark.parametrize("bits", [16, 8])
 def test_look_back_fault_falls_back_to_the_descriptor_kernels(bits):
     """A tile that gives up waiting for its predecessor (GPU shared with other work, profiler serialisation) is a matter of
     timing, not of the stream: the batch must then come out right through the three-kernel parse + block kernels, not as an
