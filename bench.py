@@ -288,6 +288,7 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
     # the same bytes
     nshort = max(8, ncap // 8) if not inter else ncap
     secs = seconds if seconds else (1.5 if spec["codec"] == "msv1" else 3.0)
+    prefetch_mb = float(os.environ.get("JSP_BENCH_PREFETCH_MB", "32"))    # jsp_play --prefetch (MSVideo1: the file goes up in ranges of this size, jsp_prefetch; 0: a copy / a bus read per frame)
 
     def avi_of(frames, keys, palette):
         return avi.write_avi(W, H, frames, fourcc=b"SCPR" if spec["codec"] == "sp" else b"CRAM",
@@ -307,7 +308,7 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
         def run(streams):
             names = ",".join(f.name for f in files[:streams])
             res = subprocess.run([exe, names, "--pipelined", "--quiet", "--depth", "8", "--streams", str(streams), "--seconds", str(secs),
-                                  "--device", str(job.local_rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                                  "--device", str(job.local_rank), "--prefetch", str(prefetch_mb)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             if res.returncode != 0:
                 raise SystemExit("examples/jsp_play failed: " + res.stderr.decode()[-500:])
             return json.loads(res.stdout.decode().strip().splitlines()[-1])
@@ -381,7 +382,11 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
            "includes": "AVI bytes in pinned host memory -> chunk walk + host stage + H2D + kernels, one frame per call "
                        "(jsp_decompress_*_async / jsp_wait, 8 frames in flight per stream), examples/jsp_play over the C ABI; "
                        "one untimed pass over the file first (codec and buffers set up), all streams start the timed passes together; "
-                       "uploaded_bytes_per_s = compressed bytes handed to the decoders per second (what crosses the bus)"}
+                       "uploaded_bytes_per_s = compressed bytes handed to the decoders per second (what crosses the bus)"
+                       + ("; MSVideo1: the file's bytes go up in ranges of %g MB ahead of the frames (jsp_prefetch, every pass over the file anew) "
+                          "instead of a copy per frame" % prefetch_mb if spec["codec"] == "msv1" and prefetch_mb > 0 else "")}
+    if spec["codec"] == "msv1":
+        e2e["prefetch_MB"] = prefetch_mb
     if batch_api:
         e2e["batch_api"] = batch_api
     if h2d:

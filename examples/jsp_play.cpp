@@ -9,6 +9,9 @@
 //                                end-to-end rate: T independent streams (threads, a codec instance each) play the clip R
 //                                times (or over and over for S seconds, all streams for the same interval) from the file's
 //                                bytes in pinned memory; prints one JSON line
+//   ... --pipelined [--prefetch MB]  MSVideo1: the file's bytes go to the device in ranges of about MB megabytes (default 32), one range
+//                                ahead of the one being decoded and every pass over the file anew (jsp_prefetch): the frames then queue
+//                                no upload of their own.  --prefetch 0: a copy, or a read over the bus inside the kernel, per frame
 //   jsp_play a.avi,b.avi --pipelined --devices 0,1,... [--streams T] [--quiet ...]
 //                                streams sharded one per GPU inside this process: stream s plays file s (mod their number) on
 //                                device devices[s mod G], a host thread, a codec instance and a frame pool each; the per-device
@@ -142,6 +145,9 @@ using Clock = std::chrono::steady_clock;
 // `seconds` > 0: the timed passes start the file over until that much time has passed since the gate opened and stop where they are (frames
 // in flight are collected) — streams with files of different lengths then all run for the same interval.
 // `sink`: the per-frame lines go there instead of stdout (several streams printing side by side).
+// --prefetch MB (g_prefetch_bytes): the file's bytes go to the device in ranges of about that size, the range after the current one ahead of the frames being
+// submitted (jsp_prefetch), every pass over the file anew; the frames' own uploads then fall away (MSVideo1; other codecs ignore it).
+size_t g_prefetch_bytes = 32u << 20;                     // (--prefetch 0: every frame finds its own way up)
 long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int warmup = 0, Gate* gate = nullptr, Clock::time_point* t0 = nullptr,
                     Clock::time_point* t1 = nullptr, int device = 0, double seconds = 0, std::string* sink = nullptr) {
     auto say = [&](const char* fmt, auto... a) {
@@ -208,6 +214,18 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
     Clock::time_point deadline{};
     bool timed_out = false;
     if (seconds > 0) repeat = 1 << 30;
+    struct Ahead { int pass; size_t begin, end; };          // frames [begin, end) of a pass whose bytes were handed to jsp_prefetch
+    std::deque<Ahead> ahead;
+    auto fetch = [&](int pass, size_t i0) {
+        const size_t lo = clip.frames[i0].first;
+        size_t j = i0, hi = lo;
+        while (j < clip.frames.size() && (j == i0 || clip.frames[j].first + clip.frames[j].second - lo <= g_prefetch_bytes)) {
+            hi = clip.frames[j].first + clip.frames[j].second;
+            ++j;
+        }
+        if (jsp_prefetch(dec, clip.bytes.data() + lo, hi - lo) != 0) std::fprintf(stderr, "jsp_prefetch: %s\n", jsp_last_error());
+        ahead.push_back({pass, i0, j});
+    };
     for (int rep = -warmup; rep < repeat && !failed && !timed_out; ++rep) {
         if (rep == 0) {
             if (gate) { gate->waiting.fetch_add(1); while (gate->waiting.load() < gate->parties) std::this_thread::yield(); }
@@ -220,6 +238,15 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
         for (size_t i = 0; i < clip.frames.size(); ++i) {
             if (seconds > 0 && rep >= 0 && Clock::now() >= deadline) { timed_out = true; break; }
             if ((int)flying.size() == depth) collect();
+            if (g_prefetch_bytes && clip.kind != JSP_CODEC_SCREENPRESSOR) {
+                while (!ahead.empty() && (ahead.front().pass != rep || i < ahead.front().begin || i >= ahead.front().end)) ahead.pop_front();
+                if (ahead.empty()) fetch(rep, i);
+                if (ahead.size() < 2) {                       // the range after this one travels while this one is decoded
+                    const Ahead& b = ahead.back();
+                    if (b.end < clip.frames.size()) fetch(b.pass, b.end);
+                    else if (rep + 1 < repeat) fetch(b.pass + 1, 0);
+                }
+            }
             const uint8_t* src = clip.bytes.data() + clip.frames[i].first;
             const size_t len = clip.frames[i].second;
             const bool key = frame_is_key(clip, dec, i);
@@ -348,6 +375,7 @@ int main(int argc, char** argv) {
         if (o == "--pipelined") pipelined = true;
         else if (o == "--quiet") quiet = true;
         else if (o == "--depth" && a + 1 < argc) depth = std::atoi(argv[++a]);
+        else if (o == "--prefetch" && a + 1 < argc) g_prefetch_bytes = (size_t)(std::atof(argv[++a]) * 1048576.0);
         else if (o == "--streams" && a + 1 < argc) streams = std::atoi(argv[++a]);
         else if (o == "--repeat" && a + 1 < argc) repeat = std::atoi(argv[++a]);
         else if (o == "--seconds" && a + 1 < argc) seconds = std::atof(argv[++a]);

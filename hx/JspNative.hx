@@ -37,6 +37,7 @@ extern class JspNative {
     // the asynchronous form of DecompressI / DecompressP (optional: a Manager that decodes ahead of display)
     @:native("jsp_decompress_i_async") static function decompressIAsync(c:RawPointer<JspCodec>, src:RawConstPointer<UInt8>, n:SizeT, dst:RawPointer<cpp.Int32>, ticket:RawPointer<UInt64>):Int;
     @:native("jsp_decompress_p_async") static function decompressPAsync(c:RawPointer<JspCodec>, src:RawConstPointer<UInt8>, n:SizeT, dst:RawPointer<cpp.Int32>, ticket:RawPointer<UInt64>):Int;
+    @:native("jsp_prefetch")           static function prefetch(c:RawPointer<JspCodec>, host:RawConstPointer<UInt8>, bytes:SizeT):Int;   // a stretch of the file ahead of the frames submitted next: one copy instead of one per frame
     @:native("jsp_wait")               static function wait(c:RawPointer<JspCodec>, ticket:UInt64, dataPnt:RawPointer<RawPointer<cpp.Int32>>, significant:RawPointer<Int>):Int;
     // frame pool in HBM (Manager.hx:114-118) and the two Manager passes that follow the codec
     @:native("jsp_key_frame_differs")  static function keyFrameDiffers(c:RawPointer<JspCodec>):Int;

@@ -204,6 +204,16 @@ int jsp_wait(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* significant
 /* Pinned host memory for compressed frames (what an AVI reader fills): uploads from it need no staging copy. */
 void* jsp_host_alloc(size_t bytes);
 void jsp_host_free(void* p);
+/* The next frames' bytes lie in [host, host + bytes) (a stretch of the file the reader holds, chunk headers and all): the codec may
+ * take the whole range to the device in ONE copy on a stream of its own, and asynchronous frames submitted afterwards whose `src`
+ * lies inside it then queue no upload of their own (MSVideo1 with "msv1_parse" = "gpu", frames of up to 2 MiB; everything else
+ * accepts the call and does nothing).  No counterpart in the reference: its Manager hands the decoder slices of the one ArrayBuffer
+ * the loader filled (DataLoader.hx), and this is that buffer crossing the bus in pieces sized for the bus instead of frame by frame
+ * (a megabyte per copy goes at 24 - 39 GB/s here, 64 MB at 57).  Returns at once.  The codec keeps the 4 most recent ranges; a
+ * range must stay unchanged in host memory while it is kept (frames are pre-scanned on the host from `src` itself); host == NULL,
+ * bytes == 0 gives every range up (do so before the memory is reused for other bytes).  Results never depend on it.
+ * jsp_counter(c, "prefetched_frames") counts the frames that found their bytes on the device. */
+int jsp_prefetch(jsp_codec* c, const void* host, size_t bytes);
 
 /* Equivalent to calling DecompressI on frames 0..n-1 in order (Manager.hx:507 in a loop); device
  * `dsts` only.  Key-frame-only MSVideo1 batches decode in ONE launch (grid.y = frame). */

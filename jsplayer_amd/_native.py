@@ -67,6 +67,7 @@ SIGNATURES = {
     "jsp_sync": (C.c_int, [C.c_void_p]),
     "jsp_counter": (C.c_longlong, [C.c_void_p, C.c_char_p]),
     "jsp_key_frame_differs": (C.c_int, [C.c_void_p]),
+    "jsp_prefetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "jsp_measure_h2d": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "jsp_device_count": (C.c_int, []),
     "jsp_assign_stream": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),

@@ -207,6 +207,20 @@ class _NativeCodec:
         v = int(self._lib.jsp_key_frame_differs(self._h))
         return None if v < 0 else bool(v)
 
+    def prefetch(self, host) -> None:
+        """jsp_prefetch: the next frames' bytes lie in `host` (a numpy uint8 array / memoryview over a stretch of the file, ideally
+        in pinned memory: PinnedBytes.array slices) — the codec may take the whole range to the device in one copy; asynchronous
+        frames whose `src` is a slice of it then queue no upload of their own.  `None` gives every range up.  The range must stay
+        alive and unchanged while the codec keeps it (the 4 most recent ranges): the object is held here."""
+        if host is None:
+            self._lib.jsp_prefetch(self._h, None, 0)
+            self._ranges = []
+            return
+        keep, p, n = _src_arg(host)
+        if self._lib.jsp_prefetch(self._h, p, n) != 0:
+            raise CodecError(N.last_error())
+        self._ranges = (getattr(self, "_ranges", []) + [keep])[-4:]
+
     def counter(self, name: str) -> int:
         """How often this instance took one of its slow paths ("async_reruns", "lookback_fallbacks"): jsp_counter."""
         v = int(self._lib.jsp_counter(self._h, name.encode()))

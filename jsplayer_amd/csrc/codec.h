@@ -105,6 +105,8 @@ struct jsp_codec {
     // has to be uploaded first to keep them as the caller had them).
     virtual bool may_leave_pixels(const jsp_frame_in& f) = 0;
     virtual int set_option(const char*, const char*) { return -1; }
+    // jsp_prefetch: a range of host memory the next frames' bytes lie in may be taken to the device in one copy (0: accepted or nothing to do)
+    virtual int prefetch(const void*, size_t) { return 0; }
     long long async_reruns = 0;            // jsp_counter("async_reruns")
     virtual long long counter(const char*) { return -1; }   // the codec's own counters (jsp_counter)
     // Host stage of ONE frame for the asynchronous path: like stage(), but it must not wait for the GPU (uploads come

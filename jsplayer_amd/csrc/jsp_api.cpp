@@ -410,6 +410,14 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream) {
     return 0;
 }
 
+int jsp_prefetch(jsp_codec* c, const void* host, size_t bytes) {
+    if (!c || (!host && bytes)) return JSP_ERROR_OCCURED;
+    return guarded([&] {
+        c->activate();
+        return c->prefetch(host, bytes) == 0 ? JSP_ZERO_STATE : JSP_ERROR_OCCURED;
+    });
+}
+
 int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
     if (!c || !key || !value) return -1;
     if (std::strcmp(key, "key_frame_compare") == 0) {

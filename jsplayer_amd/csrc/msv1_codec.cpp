@@ -237,6 +237,7 @@ struct Msv1AsyncStaged : jsp_staged {
     uint32_t want = 0;                        // ... to this value once every launch so far is through
     const uint8_t* src_dev = nullptr;         // device-side address of the frame's bytes in pinned host memory
     hipEvent_t uploaded = nullptr;            // (copy-engine form) the frame's bytes are in d_stream
+    hipEvent_t range_up = nullptr;            // (jsp_prefetch) the range the frame's bytes lie in is on the device: waited for once per range
     bool dma = false;
     ~Msv1AsyncStaged() override { if (uploaded) (void)hipEventDestroy(uploaded); }
 
@@ -250,6 +251,7 @@ struct Msv1AsyncStaged : jsp_staged {
         if (merged) {
             want += (uint32_t)ntiles;
             if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
+            if (range_up) { JSP_HIP(hipStreamWaitEvent(stream, range_up, 0)); range_up = nullptr; }   // (the first frame out of a prefetched range: later ones are behind it)
             msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
                               next_epoch(epoch), 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad, d_poison, &rec,
                               static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles);
@@ -288,6 +290,7 @@ struct Msv1Codec : jsp_codec {
     bool opt_inject_deaf = false;        // tests ("msv1_inject_fault" = "2"): the next one-launch asynchronous frame never sees all its tiles report
     std::shared_ptr<std::atomic<long long>> lookback_fallbacks = std::make_shared<std::atomic<long long>>(0);
     long long counter(const char* name) override {
+        if (std::strcmp(name, "prefetched_frames") == 0) return prefetched_frames;
         return std::strcmp(name, "lookback_fallbacks") == 0 ? lookback_fallbacks->load() : -1;
     }
     bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
@@ -301,7 +304,67 @@ struct Msv1Codec : jsp_codec {
     hipStream_t up_streams[kUpStreamsMax] = {nullptr, nullptr, nullptr, nullptr};
     int up_count = [] { const char* e = std::getenv("JSP_MSV1_UP_STREAMS"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : (v > kUpStreamsMax ? kUpStreamsMax : v); }();
     unsigned up_next = 0;
+    // jsp_prefetch: ranges of the caller's host memory that are (being) copied to the device in ONE piece each, on a stream of their own.
+    // An asynchronous frame whose bytes lie inside such a range takes them from the device copy: no copy of its own is queued and
+    // nothing crosses the bus inside its kernel.  A megabyte per copy goes at 24 - 39 GB/s, 64 MB at 57 (bench.py: e2e.h2d_ceiling_GBs),
+    // and sixteen player streams that each queue a copy, an event and a wait per frame are bound by those queues, not by the bus.
+    // A ring: the range prefetched kRanges calls ago is given up (after the kernels that read it: `last_use`).
+    struct UpRange {
+        const uint8_t* host = nullptr;
+        size_t bytes = 0, skew = 0;           // the device copy starts at dev.p + skew: same offset inside a 64-byte line as `host`
+        DeviceBuffer dev;
+        hipEvent_t up = nullptr, last_use = nullptr;
+        bool waited = false;                  // the codec's stream (`waited_on`) already waits for `up`
+        hipStream_t waited_on = nullptr;
+        bool used = false;                    // some kernel read it since it was uploaded
+    };
+    static constexpr int kRanges = 4;
+    UpRange ranges[kRanges];
+    unsigned range_next = 0;
+    hipStream_t prefetch_stream = nullptr;
+    long long prefetched_frames = 0;          // jsp_counter("prefetched_frames"): asynchronous frames that found their bytes on the device
+    int prefetch(const void* host, size_t n) override {
+        if (!host || n == 0) {                // give every range up (the caller's memory changes or goes away)
+            for (UpRange& r : ranges) { r.host = nullptr; r.bytes = 0; }
+            return 0;
+        }
+        if (!opt_gpu_parse) return 0;         // (the host parser reads the caller's bytes: nothing to take up)
+        UpRange& r = ranges[range_next++ % kRanges];
+        r.host = nullptr;                     // (not to be found while it is being replaced)
+        r.bytes = 0;
+        if (!prefetch_stream) JSP_HIP(hipStreamCreateWithFlags(&prefetch_stream, hipStreamNonBlocking));
+        if (!r.up) {
+            JSP_HIP(hipEventCreateWithFlags(&r.up, hipEventDisableTiming));
+            JSP_HIP(hipEventCreateWithFlags(&r.last_use, hipEventDisableTiming));
+        }
+        if (r.used) {                         // kernels queued so far may still read what the range held: the copy goes behind them
+            JSP_HIP(hipEventRecord(r.last_use, stream));
+            JSP_HIP(hipStreamWaitEvent(prefetch_stream, r.last_use, 0));
+        }
+        r.dev.reserve(n + 128);               // (growing frees the old copy: hipFree waits for the device)
+        r.skew = (size_t)(reinterpret_cast<uintptr_t>(host) & 63u);
+        JSP_HIP(hipMemcpyAsync(static_cast<uint8_t*>(r.dev.p) + r.skew, host, n, hipMemcpyHostToDevice, prefetch_stream));
+        JSP_HIP(hipEventRecord(r.up, prefetch_stream));
+        r.host = static_cast<const uint8_t*>(host);
+        r.bytes = n;
+        r.waited = false;
+        r.used = false;
+        return 0;
+    }
+    UpRange* range_of(const uint8_t* src, size_t n) {
+        for (int k = 0; k < kRanges; ++k) {   // oldest first: of two copies of the same bytes the earlier one has arrived
+            UpRange& r = ranges[(range_next + (unsigned)k) % kRanges];
+            if (r.host && src >= r.host && n <= r.bytes && (size_t)(src - r.host) <= r.bytes - n) return &r;
+        }
+        return nullptr;
+    }
     ~Msv1Codec() override {
+        if (prefetch_stream) (void)hipStreamSynchronize(prefetch_stream);
+        for (UpRange& r : ranges) {
+            if (r.up) (void)hipEventDestroy(r.up);
+            if (r.last_use) (void)hipEventDestroy(r.last_use);
+        }
+        if (prefetch_stream) (void)hipStreamDestroy(prefetch_stream);
         for (hipStream_t s : up_streams) if (s) (void)hipStreamDestroy(s);
         if (counted_async) g_async_streams.fetch_sub(1);
     }
@@ -518,11 +581,19 @@ struct Msv1Codec : jsp_codec {
             r.signif = &info_dev->signif;
             r.pad = 0;
         };
-        // the frame's bytes: from where they are when the caller keeps them in pinned memory, else through our own
+        // the frame's bytes: on the device already when the caller had the range prefetched (jsp_prefetch); else from where they are
+        // when the caller keeps them in pinned memory, else through our own
         const void* up = f.src;
         const uint8_t* up_dev = nullptr;
         hipPointerAttribute_t attr{};
-        if (hipPointerGetAttributes(&attr, f.src) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        UpRange* range = st->merged ? range_of(f.src, f.n) : nullptr;
+        st->range_up = nullptr;
+        if (range) {
+            up_dev = static_cast<const uint8_t*>(range->dev.p) + range->skew + (f.src - range->host);
+            if (!range->waited || range->waited_on != stream) { st->range_up = range->up; range->waited = true; range->waited_on = stream; }
+            range->used = true;
+            ++prefetched_frames;
+        } else if (hipPointerGetAttributes(&attr, f.src) == hipSuccess && attr.type == hipMemoryTypeHost) {
             up_dev = static_cast<const uint8_t*>(attr.devicePointer ? attr.devicePointer : f.src);
         } else {
             (void)hipGetLastError();
@@ -538,6 +609,7 @@ struct Msv1Codec : jsp_codec {
             // a few streams: the copy engine works next to the kernels; many: its queues become the bottleneck (16 streams on one
             // GPU: 57 against 68 Gpixels/s), the kernels then fetch the bytes themselves
             st->dma = opt_async_auto ? g_async_streams.load() <= kDmaStreams : opt_async_dma;
+            if (range) st->dma = false;      // (the kernel reads the device copy of the range and leaves the frame's own copy in d_stream, as when it reads pinned memory)
             if (st->dma) {   // the copy engine brings the bytes up on a stream of its own, next to the previous frame's kernel
                 hipStream_t& up_stream = up_streams[up_next++ % (unsigned)up_count];
                 if (!up_stream) JSP_HIP(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));

@@ -148,7 +148,13 @@ struct SpCodec : jsp_codec, DstColumns {
     int stream_version = 0;                       // entropy coder the stream is pinned to (0: none yet), as far as submission has got
     bool seen_key = false;                        // (prediction) a key frame has been decoded
     int32_t* pred_prev_dev = nullptr;             // (prediction) device pointer of the previous frame after the last submitted frame
-    struct JobExtra { bool done = false; };
+    struct JobExtra {
+        bool done = false;
+        uint64_t seq = 0;                         // submission order (0: the slot was never used)
+    };
+    uint64_t submit_seq = 0;
+    static constexpr size_t kAfterRing = 64;      // (more than frames can be in flight)
+    std::pair<uint64_t, int32_t*> after_ring[kAfterRing] = {};   // [seq mod 64] = {seq, the previous frame once that frame was through}: what the next frame really follows
     std::vector<JobExtra> extra;                  // per ring slot: the worker is through with the slot's job
 
     // auto: the host's threads are shared by the ScreenPressor streams of the process that use the asynchronous calls — one
@@ -214,6 +220,7 @@ struct SpCodec : jsp_codec, DstColumns {
         SpStaged* st = dynamic_cast<SpStaged*>(j.st.get());
         std::string failed;
         try {
+            const bool opens_here = !g.have_prev;      // the group's first frame: what it follows was left by ANOTHER worker
             int32_t* prev = g.have_prev ? g.prev : j.prev_dev_before;
             const int32_t* prev_in = prev;             // what a key frame is compared with (option "key_frame_compare")
             jsp_staged* got = stage_impl(std::vector<jsp_frame_in>{j.frame}, st, g.dec, &prev, &outs_local);
@@ -241,9 +248,27 @@ struct SpCodec : jsp_codec, DstColumns {
             g.have_prev = true;
             j.st->device = device;
             j.st->decode(stream);
-            if (j.frame.key && key_compare_row >= 0 && j.st->status[0] == JSP_ZERO_STATE && j.st->adopted[0] && prev_in) {
-                queue_key_compare(j.frame.dst, prev_in, (int)(&j - jobs.data()));
-                j.key_compare_queued = true;
+            if (j.frame.key && key_compare_row >= 0 && j.st->status[0] == JSP_ZERO_STATE && j.st->adopted[0]) {
+                if (opens_here) {
+                    // The picture before this one belongs to the group in front, whose worker queues its kernels when ITS host stage is
+                    // through — possibly after this point.  The compare must come behind them on the stream, and against the picture that
+                    // group really left (the submission-time guess may be off by a frame that adopted nothing): wait until every frame
+                    // submitted earlier has queued its work.  (Earlier frames only: groups are handed to workers in order, so whoever is
+                    // waited for here has a worker and waits, if at all, for still earlier ones.)
+                    const size_t me = (size_t)(&j - jobs.data());
+                    std::unique_lock<std::mutex> lk(mu);
+                    const uint64_t my = extra[me].seq;
+                    cv_done.wait(lk, [&] {
+                        for (size_t k = 0; k < extra.size(); ++k)
+                            if (k != me && extra[k].seq != 0 && extra[k].seq < my && !extra[k].done) return false;
+                        return true;
+                    });
+                    if (my > 1 && after_ring[(my - 1) % kAfterRing].first == my - 1) prev_in = after_ring[(my - 1) % kAfterRing].second;
+                }
+                if (prev_in) {
+                    queue_key_compare(j.frame.dst, prev_in, (int)(&j - jobs.data()));
+                    j.key_compare_queued = true;
+                }
             }
             JSP_HIP(hipEventRecord(j.done, stream));
         } catch (const std::exception& e) {
@@ -260,6 +285,8 @@ struct SpCodec : jsp_codec, DstColumns {
         }
         {
             std::lock_guard<std::mutex> lk(mu);
+            const uint64_t seq = extra[&j - jobs.data()].seq;
+            after_ring[seq % kAfterRing] = {seq, g.have_prev ? g.prev : j.prev_dev_before};
             extra[&j - jobs.data()].done = true;
         }
         cv_done.notify_all();
@@ -331,6 +358,7 @@ struct SpCodec : jsp_codec, DstColumns {
         {
             std::lock_guard<std::mutex> lk(mu);
             extra[&j - jobs.data()].done = false;
+            extra[&j - jobs.data()].seq = ++submit_seq;
             cur->tasks.push_back(&j);
         }
         cv_work.notify_all();

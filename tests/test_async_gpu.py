@@ -13,7 +13,7 @@ from oracle_binding import OracleAbort, OracleMSVideo1, OracleScreenPressor
 pytestmark = pytest.mark.gpu
 
 
-def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36, before_close=None):
+def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36, before_close=None, prefetch=0, drop_ranges_at=None):
     import torch
     gpu.Preinit(lines)
     orc.Preinit(lines)
@@ -23,15 +23,30 @@ def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36, before_
     obufs = [np.full(w * h, 0x00A5A5A5, dtype=np.int32) for _ in range(nbuf)]
     torch.cuda.synchronize()
     arena = None
+    spans = []
     if pinned:   # the compressed frames live in pinned memory: uploaded from where they are
-        arena = HostBuffer(sum(len(c) for c in chunks) + 64)
-        pos, srcs = 0, []
+        gap = 8 if prefetch else 0                            # (as in a file: a chunk header in front of every frame, frames at even offsets only)
+        arena = HostBuffer(sum(len(c) + gap + 1 for c in chunks) + 64)
+        pos, srcs = 2 if prefetch else 0, []
         for c in chunks:
+            pos += gap
             arena.array[pos:pos + len(c)] = np.frombuffer(c, dtype=np.uint8)
             srcs.append(arena.array[pos:pos + len(c)])
-            pos += len(c)
+            spans.append((pos, pos + len(c)))
+            pos += len(c) + (len(c) & 1 if prefetch else 0)
     else:
         srcs = list(chunks)
+    # prefetch = R: the arena goes up in ranges of R frames (jsp_prefetch), the range after the current one ahead of it; every third
+    # range stops 5 bytes short of its last frame, which then has to find its own way up
+    fetched = set()
+
+    def fetch_range(r):
+        if r in fetched or r * prefetch >= len(chunks):
+            return
+        fetched.add(r)
+        lo = spans[r * prefetch][0] - 8
+        hi = spans[min((r + 1) * prefetch, len(chunks)) - 1][1] - (5 if r % 3 == 2 else 0)
+        gpu.prefetch(arena.array[lo:hi])
     inflight = []   # (ticket, frame index, buffer index, oracle result, oracle picture)
 
     def collect():
@@ -54,6 +69,11 @@ def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36, before_
     for i, (src, key) in enumerate(zip(srcs, keys)):
         if len(inflight) == depth:
             collect()
+        if prefetch:
+            if drop_ranges_at == i:
+                gpu.prefetch(None)
+            fetch_range(i // prefetch)
+            fetch_range(i // prefetch + 1)
         busy = {k for _, _, k, _, _ in inflight} | {p[0] for _, _, _, _, p in inflight if p is not None}
         oprev = orc.PreviousFrame()
         k = next(j for j in range(nbuf) if obufs[j] is not oprev and j not in busy)
@@ -95,6 +115,46 @@ def test_msvideo1_async_matches_oracle(bits, size, pinned):
     gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
     gpu.set_option("msv1_parse", "gpu")
     drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, pinned=pinned)
+
+
+@pytest.mark.parametrize("bits,size,per_range", [(16, (320, 240), 3), (8, (320, 240), 2), (16, (1920, 1080), 4), (16, (66, 50), 5)],
+                         ids=["16-320x240", "8-320x240", "16-1080p", "16-66x50"])
+def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size, per_range):
+    """jsp_prefetch: the pinned arena the frames lie in (chunk headers between them, as in a file) goes to the device in ranges of a few
+    frames, ahead of the frames; frames inside a range queue no upload of their own, a frame a range stops short of takes the ordinary
+    way, the ring of four ranges is recycled several times, and halfway every range is given up once.  Same frames, flags and buffer
+    identities as the oracle; frames the GPU cannot settle alone (a truncated one, noise) go to the synchronous path as ever."""
+    w, h = size
+    n = 14 if w * h > 500000 else 32
+    frames, keys, pal = sg.msv1_clip(77, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=9)
+    frames = list(frames)
+    frames[5] = frames[5][:len(frames[5]) // 2 + 1]              # ends early, at an odd length
+    frames[11] = np.random.default_rng(3).integers(0, 256, 2001, dtype=np.uint8).tobytes()
+    gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
+    gpu.set_option("msv1_parse", "gpu")
+    seen = {}
+
+    def before_close(g):
+        seen["prefetched"] = g.counter("prefetched_frames")
+    drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, pinned=True, prefetch=per_range, drop_ranges_at=n // 2, before_close=before_close)
+    # most frames found their bytes on the device: not the ones a range stopped short of, the ones staged synchronously, and the
+    # rest of the range that was current when every range was given up
+    if w % 4 == 0 and h % 4 == 0:
+        assert seen["prefetched"] >= n // 2, seen
+    else:
+        assert seen["prefetched"] == 0, seen                    # (odd geometry: every frame is staged synchronously, from the caller's bytes)
+
+
+def test_prefetch_is_accepted_and_ignored_where_it_does_not_apply():
+    w, h = 64, 48
+    frames, keys, _ = sg.msv1_clip(78, w, h, 6, p_mix=sg.msv1_p_mix(0.5, 10.0), key_every=4)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "host")
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, pinned=True, prefetch=2)
+    sp = ScreenPressor(64, 48, 24)
+    sp.prefetch(np.zeros(100, dtype=np.uint8))
+    sp.prefetch(None)
+    sp.StopAndClean()
 
 
 @pytest.mark.parametrize("form", ["auto", "one_launch_dma", "one_launch", "two_launches"])
