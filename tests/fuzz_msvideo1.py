@@ -59,7 +59,11 @@ def main():
                 gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
                 gpu.set_option("msv1_parse", "gpu")
                 gpu.set_option("msv1_async", form)
-                A.drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=bool(rng.random() < 0.5), lines=lines)
+                # (a third of the asynchronous clips: the arena goes up in ranges of a few frames ahead of them, jsp_prefetch — some ranges
+                # stop short of their last frame, and halfway every range is given up once)
+                ranges = int(rng.integers(1, 5)) if rng.random() < 0.33 else 0
+                A.drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=bool(ranges) or bool(rng.random() < 0.5), lines=lines,
+                        prefetch=ranges, drop_ranges_at=(n // 2 if ranges and rng.random() < 0.5 else None))
             else:
                 drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
         except AssertionError as e:
