@@ -26,7 +26,16 @@ def drive(gpu, orc, w, h, chunks, keys, depth=4, pinned=False, lines=36, before_
     spans = []
     if pinned:   # the compressed frames live in pinned memory: uploaded from where they are
         gap = 8 if prefetch else 0                            # (as in a file: a chunk header in front of every frame, frames at even offsets only)
-        arena = HostBuffer(sum(len(c) + gap + 1 for c in chunks) + 64)
+        if pinned == "pageable-arena":                        # one ordinary allocation holding the file (jsp_prefetch takes ranges of it up all the same)
+            class _Plain:
+                def __init__(self, n):
+                    self.array = np.zeros(n, dtype=np.uint8)
+
+                def close(self):
+                    pass
+            arena = _Plain(sum(len(c) + gap + 1 for c in chunks) + 64)
+        else:
+            arena = HostBuffer(sum(len(c) + gap + 1 for c in chunks) + 64)
         pos, srcs = 2 if prefetch else 0, []
         for c in chunks:
             pos += gap
@@ -143,6 +152,19 @@ def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size,
         assert seen["prefetched"] >= n // 2, seen
     else:
         assert seen["prefetched"] == 0, seen                    # (odd geometry: every frame is staged synchronously, from the caller's bytes)
+
+
+def test_prefetched_ranges_of_pageable_memory():
+    """The file need not be in pinned memory: ranges of an ordinary allocation go up through the runtime's staging, frames out of them
+    are decoded from the device copy all the same."""
+    w, h, n = 320, 240, 12
+    frames, keys, _ = sg.msv1_clip(79, w, h, n, p_mix=sg.msv1_p_mix(0.6, 15.0), key_every=5)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    seen = {}
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, pinned="pageable-arena", prefetch=4,
+          before_close=lambda g: seen.update(n=g.counter("prefetched_frames")))
+    assert seen["n"] >= n - 2, seen                            # (all but the frame a range stopped short of)
 
 
 def test_prefetch_is_accepted_and_ignored_where_it_does_not_apply():
