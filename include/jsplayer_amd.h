@@ -206,7 +206,7 @@ void* jsp_host_alloc(size_t bytes);
 void jsp_host_free(void* p);
 /* The next frames' bytes lie in [host, host + bytes) (a stretch of the file the reader holds, chunk headers and all): the codec may
  * take the whole range to the device in ONE copy on a stream of its own, and asynchronous frames submitted afterwards whose `src`
- * lies inside it then queue no upload of their own (MSVideo1 with "msv1_parse" = "gpu", frames of up to 2 MiB; everything else
+ * lies inside it then queue no upload of their own (MSVideo1 with "msv1_parse" = "gpu"; everything else
  * accepts the call and does nothing).  No counterpart in the reference: its Manager hands the decoder slices of the one ArrayBuffer
  * the loader filled (DataLoader.hx), and this is that buffer crossing the bus in pieces sized for the bus instead of frame by frame
  * (a megabyte per copy goes at 24 - 39 GB/s here, 64 MB at 57).  Returns at once.  The codec keeps the 4 most recent ranges; a

@@ -237,7 +237,6 @@ struct Msv1AsyncStaged : jsp_staged {
     uint32_t want = 0;                        // ... to this value once every launch so far is through
     const uint8_t* src_dev = nullptr;         // device-side address of the frame's bytes in pinned host memory
     hipEvent_t uploaded = nullptr;            // (copy-engine form) the frame's bytes are in d_stream
-    hipEvent_t range_up = nullptr;            // (jsp_prefetch) the range the frame's bytes lie in is on the device: waited for once per range
     bool dma = false;
     ~Msv1AsyncStaged() override { if (uploaded) (void)hipEventDestroy(uploaded); }
 
@@ -251,7 +250,6 @@ struct Msv1AsyncStaged : jsp_staged {
         if (merged) {
             want += (uint32_t)ntiles;
             if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
-            if (range_up) { JSP_HIP(hipStreamWaitEvent(stream, range_up, 0)); range_up = nullptr; }   // (the first frame out of a prefetched range: later ones are behind it)
             msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
                               next_epoch(epoch), 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad, d_poison, &rec,
                               static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles);
@@ -586,11 +584,14 @@ struct Msv1Codec : jsp_codec {
         const void* up = f.src;
         const uint8_t* up_dev = nullptr;
         hipPointerAttribute_t attr{};
-        UpRange* range = st->merged ? range_of(f.src, f.n) : nullptr;
-        st->range_up = nullptr;
+        UpRange* range = range_of(f.src, f.n);
         if (range) {
             up_dev = static_cast<const uint8_t*>(range->dev.p) + range->skew + (f.src - range->host);
-            if (!range->waited || range->waited_on != stream) { st->range_up = range->up; range->waited = true; range->waited_on = stream; }
+            if (!range->waited || range->waited_on != stream) {   // the first frame out of the range: the frames' stream waits for the range's copy once
+                JSP_HIP(hipStreamWaitEvent(stream, range->up, 0));
+                range->waited = true;
+                range->waited_on = stream;
+            }
             range->used = true;
             ++prefetched_frames;
         } else if (hipPointerGetAttributes(&attr, f.src) == hipSuccess && attr.type == hipMemoryTypeHost) {
@@ -622,7 +623,8 @@ struct Msv1Codec : jsp_codec {
             auto* recs = static_cast<Msv1TileRec*>(st->h_meta.p);
             for (int k = 0; k < nt; ++k) fill(recs[k], k);
             std::memset(recs + nt, 0, sizeof(Msv1AsyncInfo));
-            JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, stream));
+            if (range) JSP_HIP(hipMemcpyAsync(st->d_stream.p, up_dev, f.n, hipMemcpyDeviceToDevice, stream));   // (larger frames: from the range's copy to the frame's own)
+            else JSP_HIP(hipMemcpyAsync(st->d_stream.p, up, f.n, hipMemcpyHostToDevice, stream));
             JSP_HIP(hipMemcpyAsync(st->d_meta.p, recs, meta_bytes, hipMemcpyHostToDevice, stream));
         }
         // codec state, as the synchronous path leaves it

@@ -126,8 +126,8 @@ def test_msvideo1_async_matches_oracle(bits, size, pinned):
     drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, pinned=pinned)
 
 
-@pytest.mark.parametrize("bits,size,per_range", [(16, (320, 240), 3), (8, (320, 240), 2), (16, (1920, 1080), 4), (16, (66, 50), 5)],
-                         ids=["16-320x240", "8-320x240", "16-1080p", "16-66x50"])
+@pytest.mark.parametrize("bits,size,per_range", [(16, (320, 240), 3), (8, (320, 240), 2), (16, (1920, 1080), 4), (16, (66, 50), 5), (16, (1920, 1088), 3)],
+                         ids=["16-320x240", "8-320x240", "16-1080p", "16-66x50", "16-1088p-eight-colour-two-launches"])
 def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size, per_range):
     """jsp_prefetch: the pinned arena the frames lie in (chunk headers between them, as in a file) goes to the device in ranges of a few
     frames, ahead of the frames; frames inside a range queue no upload of their own, a frame a range stops short of takes the ordinary
@@ -135,7 +135,11 @@ def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size,
     identities as the oracle; frames the GPU cannot settle alone (a truncated one, noise) go to the synchronous path as ever."""
     w, h = size
     n = 14 if w * h > 500000 else 32
-    frames, keys, pal = sg.msv1_clip(77, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=9)
+    big = h == 1088                                              # all-eight-colour key frames of 2.35 MB: past the one-launch form's 2 MiB, scout + decode launches
+    frames, keys, pal = sg.msv1_clip(77, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=2 if big else 9,
+                                     key_mix=sg.MIX_ALL_EIGHT if big else sg.MIX_M1)
+    if big:
+        assert max(len(f) for f in frames) > (2 << 20)
     frames = list(frames)
     frames[5] = frames[5][:len(frames[5]) // 2 + 1]              # ends early, at an odd length
     frames[11] = np.random.default_rng(3).integers(0, 256, 2001, dtype=np.uint8).tobytes()
