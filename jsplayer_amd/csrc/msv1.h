@@ -133,7 +133,8 @@ constexpr int MSV1_MERGED_MAX_TILES = 128;
 // One-frame launches of a small frame (an inter frame, an 8-bit frame: a few hundred KB) use 8 KiB tiles — `small_tiles` —: twice the
 // workgroups, half the serial work in each; the kernel's time is a chain of dependent steps per tile, and such a launch has the
 // GPU to itself.  (1080p inter frames with 70 % skipped blocks: 28.8 -> 37.9 Gpixels/s on one stream, 8-bit key frames 42.4 -> 52.8;
-// frames of a megabyte gain nothing on one stream and lose a fifth on sixteen: they keep 16 KiB tiles.)
+// frames of a megabyte gain nothing on one stream and lose a fifth on sixteen: they keep 16 KiB tiles — with their uploads gone, jsp_prefetch,
+// they lose an eighth on one stream as well: profiles/r04_msv1_small_tiles_e2e.txt.)
 constexpr size_t MSV1_SMALL_TILE_FRAME_BYTES = 640 * 1024;
 void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const Msv1TileRec* d_recs, const int32_t* d_palette,
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,

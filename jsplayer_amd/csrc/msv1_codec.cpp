@@ -503,7 +503,8 @@ struct Msv1Codec : jsp_codec {
 
     jsp_staged* stage_async(const jsp_frame_in& f, jsp_staged* reuse) override {
         activate();
-        const bool small_tiles = f.n <= MSV1_SMALL_TILE_FRAME_BYTES;
+        static const size_t small_limit = [] { const char* e = std::getenv("JSP_MSV1_SMALL_TILE_BYTES"); return e ? (size_t)std::atoll(e) : MSV1_SMALL_TILE_FRAME_BYTES; }();   // (lab)
+        const bool small_tiles = f.n <= small_limit;
         const size_t tile_bytes = small_tiles ? msv1_small_tile_bytes() : msv1_parse_tile_bytes();
         const Prescan ps = prescan(f.src, f.n);
         if (sync_staging(f, ps)) {
