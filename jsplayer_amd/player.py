@@ -143,7 +143,7 @@ class Manager:
 
     def play_pipelined(self, frames: Sequence[bytes], depth: int = 4,
                        on_frame: Optional[Callable[[DecodedFrame, object], None]] = None,
-                       key_flags: Optional[Sequence[bool]] = None):
+                       key_flags: Optional[Sequence[bool]] = None, prefetch_bytes: int = 0):
         """play() through the asynchronous calls (DecompressI_async / DecompressP_async / wait): up to `depth` frames are in
         flight, the host stage of frame n+1 runs while the uploads and kernels of frame n do.  The log is the one play()
         writes.  HIP codecs only; the pool must hold `depth` more buffers than play() needs (Manager(..., num_buffers =
@@ -152,6 +152,29 @@ class Manager:
         from .codec import CodecError
         dec = self.decoder
         dec.set_option("async_depth", str(depth))
+        # prefetch_bytes > 0 (MSVideo1): the frames are laid out in ONE pinned arena, as the file holds them (a chunk header in front of
+        # each), and the arena goes to the device in ranges of about that size — the range after the current one ahead of the frames
+        # being submitted (decoder.prefetch / jsp_prefetch); the frames then queue no upload of their own.  examples/jsp_play --prefetch.
+        arena, spans, ahead = None, [], deque()
+        if prefetch_bytes > 0 and hasattr(dec, "prefetch") and len(frames):
+            from .codec import HostBuffer
+            import numpy as np
+            arena = HostBuffer(sum(len(f) + 8 + (len(f) & 1) for f in frames) + 16)
+            pos = 0
+            for f in frames:
+                pos += 8
+                arena.array[pos:pos + len(f)] = np.frombuffer(bytes(f), dtype=np.uint8)
+                spans.append((pos, pos + len(f)))
+                pos += len(f) + (len(f) & 1)
+            frames = [arena.array[a:b] for a, b in spans]
+
+        def fetch(i0):
+            lo, j, hi = spans[i0][0] - 8, i0, spans[i0][1]
+            while j < len(spans) and (j == i0 or spans[j][1] - lo <= prefetch_bytes):
+                hi = spans[j][1]
+                j += 1
+            dec.prefetch(arena.array[lo:hi])
+            ahead.append((i0, j))
         flying: deque = deque()      # (ticket, index, key, slot, prev_slot, prev buffer, compare bytes?, frame bytes)
 
         def collect():
@@ -163,7 +186,7 @@ class Manager:
                     if index == 0:
                         sig = True
                     elif cmp_bytes:
-                        sig = prev_blob != blob
+                        sig = not (len(prev_blob) == len(blob) and bytes(prev_blob) == bytes(blob))
                     elif prev is None:
                         sig = True
                     elif self._fused_compare:
@@ -185,6 +208,13 @@ class Manager:
         for i, f in enumerate(frames):
             if len(flying) == depth:
                 collect()
+            if arena is not None:
+                while ahead and not (ahead[0][0] <= i < ahead[0][1]):
+                    ahead.popleft()
+                if not ahead:
+                    fetch(i)
+                if len(ahead) < 2 and ahead[-1][1] < len(spans):
+                    fetch(ahead[-1][1])
             key = bool(key_flags[i]) if key_flags is not None else (i == 0 or dec.IsKeyFrame(f))
             prev = dec.PreviousFrame()                      # as of the last SUBMITTED frame
             prev_slot = self._slot_of(prev) if prev is not None else -1
@@ -220,4 +250,7 @@ class Manager:
             self.next_frame_to_decode = i + 1
         while flying:
             collect()
+        if arena is not None:
+            dec.prefetch(None)                              # (the arena goes away: the codec must not find frames in it any more)
+            arena.close()
         return self.log

@@ -103,11 +103,11 @@ def test_avi_clip_gpu_matches_cpu_reference_path(bits):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("what", ["msvc16", "msvc8", "screenpressor"])
-@pytest.mark.parametrize("depth", [1, 3])
-def test_python_player_pipelined_shows_the_same_pictures(what, depth):
+@pytest.mark.parametrize("depth,prefetch", [(1, 0), (3, 0), (3, 20000)], ids=["1", "3", "3-prefetched"])
+def test_python_player_pipelined_shows_the_same_pictures(what, depth, prefetch):
     """Manager.play_pipelined (DecompressI_async / DecompressP_async / wait, `depth` frames in flight) writes the log
     Manager.play writes through the oracle — key flags, significance, states — and every frame shows the same picture
-    (the pool is larger, so slot numbers may differ)."""
+    (the pool is larger, so slot numbers may differ); also with the frames taken to the device in ranges ahead of them."""
     import torch
     from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit, ScreenPressor
     if what == "screenpressor":
@@ -125,7 +125,10 @@ def test_python_player_pipelined_shows_the_same_pictures(what, depth):
     if what != "screenpressor":
         dec.set_option("msv1_parse", "gpu")
     gpu = player.Manager(vi, dec, lambda n: torch.zeros(n, dtype=torch.int32, device="cuda"), num_buffers=player.NUM_BUFFERS + depth)
-    gpu.play_pipelined(got, depth=depth, on_frame=lambda d, buf: shown_gpu.append(buf.cpu().numpy()))
+    # (prefetch: the frames in one pinned arena that goes to the device in ranges of ~20 KB — a few frames each — ahead of them)
+    gpu.play_pipelined(got, depth=depth, on_frame=lambda d, buf: shown_gpu.append(buf.cpu().numpy()), prefetch_bytes=prefetch)
+    if prefetch and what != "screenpressor":
+        assert dec.counter("prefetched_frames") >= len(got) // 2
     assert len(cpu.log) == len(gpu.log) == len(got)
     for a, b, pa, pb in zip(cpu.log, gpu.log, shown_cpu, shown_gpu):
         assert (a.index, a.key, a.significant_changes, a.state) == (b.index, b.key, b.significant_changes, b.state)
