@@ -674,6 +674,9 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 5) s_ready[tid] = 0u;
     __syncthreads();
+#if defined(JSP_SP_LAB_STAGGER)   // lab: workgroups start in eight classes, JSP_SP_LAB_STAGGER x ~0.5 us apart, so that the launch's write fronts stand in different frames
+    for (int i = 0; i < (int)((blockIdx.x + blockIdx.y) & 7u) * JSP_SP_LAB_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     const int by = blockIdx.y;
     const int nb_here = nbx - (int)blockIdx.x * G2_BLOCKS < G2_BLOCKS ? nbx - (int)blockIdx.x * G2_BLOCKS : G2_BLOCKS;
 
