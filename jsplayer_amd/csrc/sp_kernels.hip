@@ -202,7 +202,12 @@ __device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFF
 #else
 #define JSP_TILE_OFF(x) (x)
 #endif
-__global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
+#if defined(JSP_SP_LAB_TOUCH)
+#define JSP_TILE_BOUNDS __launch_bounds__(64, 8)   // (the touch's address would cost the kernel its eighth wave per SIMD)
+#else
+#define JSP_TILE_BOUNDS __launch_bounds__(64)
+#endif
+__global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
                                                             int band_rows, int nspans, int win_cap, int tile_fastest) {
     constexpr int PPL = 4, SPAN = 64 * PPL;
     extern __shared__ __align__(16) uint32_t lds[];
@@ -226,6 +231,9 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     uint32_t* idx = lds + SPAN;                       // band_rows + 1 offsets (relative to fa.runs)
     uint32_t* left = idx + ((band_rows + 1 + 3) & ~3);   // band_rows words
     uint2* win = reinterpret_cast<uint2*>(left + ((band_rows + 3) & ~3));   // win_cap records
+#if defined(JSP_SP_LAB_TOUCH)
+    const uint32_t touch_sink_off = (uint32_t)((reinterpret_cast<char*>(win + win_cap)) - reinterpret_cast<char*>(lds));   // 64 words nobody reads, behind the window
+#endif
     const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
     const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
     for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
@@ -261,8 +269,12 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     unsigned long long wva[WMAX];
     // (Tried and not kept, round 4: touching the window AFTER the next as well — one LDS-DMA load per window into a sink, so that the
     // records are in the caches when the real request comes.  With every window read out of the same 8 KB the launch takes 0.39 - 0.42 ms
-    // instead of 0.47 (profiles/r04_sp_tile_parts.txt), but the touch itself made it 0.49 - 0.51 at 7 and at 8 waves per SIMD alike
-    // (profiles/r04_sp_tile_touch_ab.txt): what the cached build saves is the requests, not the wait for them.)
+    // instead of 0.47 (profiles/r04_sp_tile_parts.txt), but the touch made it 0.49 - 0.51 through the builtin (the compiler then waits for
+    // vmcnt(0) at the next LDS access) and still 0.47 - 0.49 issued as asm behind the window's loads (-DJSP_SP_LAB_TOUCH, profiles/
+    // r04_sp_tile_touch_ab.txt): what the cached build saves is the requests, not the wait for them.)
+#if defined(JSP_SP_LAB_TOUCH)
+    const uint32_t tile_rec_last = ((uint32_t)__builtin_amdgcn_readfirstlane((int)idx[ye - yb]) & OFF) - 1u;   // the tile's last record (scalar)
+#endif
     struct Window { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
     auto plan_and_fetch = [&](int from) {
         Window w;
@@ -291,12 +303,27 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wva[q]) : "v"(src) : "memory");
 #endif
         }
+#if defined(JSP_SP_LAB_TOUCH)
+        // lab: the window AFTER this one is touched as well — one LDS-DMA load (no register: a sink in LDS), lane i asking for a word of the
+        // i-th 64-byte line behind this window's records — so that its records are in the caches when they are asked for in earnest.  As asm,
+        // like the window's loads: a load the compiler knows of makes it wait for vmcnt(0) — every row store in flight — at the next LDS access.
+        // One more operation between the window's loads and the row stores: settle_window counts it.
+        {
+            uint32_t rr = ((uint32_t)__builtin_amdgcn_readfirstlane((int)(w.w0 + (uint32_t)w.wn))) + (uint32_t)lane * JSP_SP_LAB_TOUCH;
+            rr = rr < tile_rec_last ? rr : tile_rec_last;
+            const uint2* tp = gruns + rr;
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(tp), "s"(touch_sink_off) : "memory");
+        }
+#endif
         return w;
     };
     // wait until at most `stores_behind` vector-memory operations of this wave are outstanding (the newest ones)
     auto settle_window = [&](int stores_behind) {
 #if defined(JSP_SP_LAB_NOFETCH)
         return;
+#endif
+#if defined(JSP_SP_LAB_TOUCH)
+        stores_behind += 1;                                    // (the touch behind the window's loads)
 #endif
         switch (stores_behind < 16 ? stores_behind : 16) {     // (more than 16 rows per window: waiting down to 16 is just as exact)
 #define JSP_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -1099,6 +1126,9 @@ TilePlan tile_plan(const Geometry& g, int band_rows) {
     if (cap > 384) cap = 384;                                  // the kernel fetches a window with at most six loads per lane
     t.win_cap = (int)cap;
     t.lds = 4 * (fixed + 2 * cap);
+#if defined(JSP_SP_LAB_TOUCH)
+    t.lds += 4 * 64;                                           // (the sink of the lab build's look-ahead touches)
+#endif
     return t;
 }
 }  // namespace
