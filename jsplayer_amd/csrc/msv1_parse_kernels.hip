@@ -534,6 +534,21 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
             if (o < (uint32_t)BYTES_W * 4u && at < data_end && !(MODE == 3 && data_end - at < 16u))
                 v[q] = *reinterpret_cast<const uint4*>(stream + at);   // buffers are padded
         }
+#if defined(JSP_FUSED_LAB_TOUCH)
+        // lab: the tile JSP_FUSED_LAB_TOUCH launches ahead (a multiple of 8: the same XCD, the same L2) is touched — one LDS-DMA load per thread, a word of
+        // each of its 256 64-byte lines, into a sink — so that its own loads, a few microseconds from now, come out of the L2.  Behind this tile's loads
+        // (loads return in order) and as asm (no register, and the compiler's vmcnt bookkeeping does not see it).
+        if (MODE == 0 && blockIdx.x + (uint32_t)JSP_FUSED_LAB_TOUCH < gridDim.x) {
+            const Msv1TileRec& ra = recs[tile0 + blockIdx.x + (uint32_t)JSP_FUSED_LAB_TOUCH];
+            const uint32_t ta = ra.byte0 + (uint32_t)tid * 64u;
+            if (!(ra.flags & MSV1_TILE_SKIP) && ta < ra.data_end) {
+                __shared__ uint32_t s_touch_sink[64];
+                const uint32_t sink_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)s_touch_sink);
+                const uint8_t* tp = stream + ta;
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(tp), "s"(sink_off) : "memory");
+            }
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < NLOAD; ++q) {
             const uint32_t o = tid * 16u + (uint32_t)q * (PWG * 16u), at = tile_byte0 + o;
