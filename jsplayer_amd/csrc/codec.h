@@ -116,6 +116,11 @@ struct jsp_codec {
         return stage(std::vector<jsp_frame_in>{f}, reuse);
     }
     virtual bool async_finish(jsp_staged*) { return true; }
+    // The frame of job `j` is staged (j.st): the codec may take its launch in hand — queue its kernels and record j.done now, or HOLD it
+    // until the next frame is submitted and launch the two together (async_flush(&j) or async_flush(nullptr) launches what is held; async_reset
+    // drops it: the frame is about to be re-run synchronously).  false: the caller queues st->decode() and records the event itself.
+    virtual bool async_launch(jsp_async_job&) { return false; }
+    virtual void async_flush(const jsp_async_job* /*only_if_held*/) {}
     // True when stage_async() would stage this frame with kernels that cannot be vetoed afterwards (the synchronous
     // staging): every earlier frame still in flight is then settled first — re-run, if the GPU could not settle it —
     // because the caller may already have handed this frame a buffer an earlier frame's re-run still reads.

@@ -406,8 +406,12 @@ int jsp_upload(int32_t* device_frame, const int32_t* host, size_t npixels) {
 
 int jsp_set_stream(jsp_codec* c, void* hip_stream) {
     if (!c) return JSP_ERROR_OCCURED;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
-    return 0;
+    return guarded([&] {
+        c->activate();
+        c->async_flush(nullptr);                         // (a frame held for its successor belongs on the stream it was staged for)
+        c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+        return 0;
+    });
 }
 
 int jsp_prefetch(jsp_codec* c, const void* host, size_t bytes) {
@@ -445,7 +449,10 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
         c->async_depth = (int)v;
         return 0;
     }
-    return c->set_option(key, value);
+    return guarded([&] {
+        c->activate();
+        return c->set_option(key, value);
+    }, -1);
 }
 
 int jsp_key_frame_differs(jsp_codec* c) { return c ? c->last_key_differs : -1; }
@@ -504,6 +511,7 @@ void settle(jsp_codec* c, uint64_t t) {
         j.settled = true;
         return;
     }
+    c->async_flush(&j);                                  // (held for a frame that has not come: launched alone)
     JSP_HIP(hipEventSynchronize(j.done));
     j.st->finish_results();
     if (!c->async_finish(j.st.get())) { redo_from(c, t); return; }
@@ -557,13 +565,18 @@ int submit_async(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, bool 
     jsp_staged* st = c->stage_async(j.frame, j.st.get());
     st->device = c->device;
     if (st != j.st.get()) j.st.reset(st);
-    st->decode(c->stream);
-    if (key && c->key_compare_row >= 0 && st->status[0] == JSP_ZERO_STATE && st->adopted[0] && j.prev_dev_before) {
+    const bool wants_compare = key && c->key_compare_row >= 0 && st->status[0] == JSP_ZERO_STATE && st->adopted[0] && j.prev_dev_before;
+    if (wants_compare) j.key_differs = st->key_differs.empty() ? -2 : st->key_differs[0];   // (-3: the frame's own kernels compare; async_finish() knows)
+    // (a compare pass of the codec's own must follow the frame's kernels at once: such a frame is not handed to async_launch, which may hold it)
+    if (j.key_differs == -2 && wants_compare) c->async_flush(nullptr);
+    if (!(wants_compare && j.key_differs == -2) && c->async_launch(j)) {
+        // the codec launches the frame — now, or together with the next one — and records j.done behind it
+    } else {
+        st->decode(c->stream);
         // (a frame the GPU may still veto leaves `dst` untouched and is re-run through the synchronous path, which compares again)
-        j.key_differs = st->key_differs.empty() ? -2 : st->key_differs[0];   // (-3: the frame's own kernels compare; async_finish() knows)
-        if (j.key_differs == -2) { c->queue_key_compare(dst, j.prev_dev_before, (int)(c->next_ticket % c->async_depth)); j.key_compare_queued = true; }
+        if (wants_compare && j.key_differs == -2) { c->queue_key_compare(dst, j.prev_dev_before, (int)(c->next_ticket % c->async_depth)); j.key_compare_queued = true; }
+        JSP_HIP(hipEventRecord(j.done, c->stream));
     }
-    JSP_HIP(hipEventRecord(j.done, c->stream));
     if (!st->cleared.empty() && st->cleared[0]) c->prev_caller = nullptr;
     if (st->adopted[0]) c->prev_caller = dst;
     j.prev_caller_after = c->prev_caller;

@@ -244,9 +244,36 @@ struct Msv1AsyncStaged : jsp_staged {
         if (merged) return static_cast<Msv1AsyncInfo*>(d_report.p);
         return reinterpret_cast<Msv1AsyncInfo*>(static_cast<uint8_t*>(d_meta.p) + sizeof(Msv1TileRec) * (size_t)ntiles);
     }
+    uint32_t bad_mask() const { return MSV1_ASYNC_SHORT | MSV1_ASYNC_END | MSV1_ASYNC_STUCK | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE) | (deaf ? MSV1_LAB_DEAF : 0u); }
+    // This frame and the one submitted right behind it in ONE launch (both one-launch frames with the same tile size; msv1.h, Msv1SecondFrame).
+    void decode_with(Msv1AsyncStaged& next, hipStream_t stream) {
+        want += (uint32_t)ntiles;
+        next.want += (uint32_t)next.ntiles;
+        if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
+        if (next.dma) JSP_HIP(hipStreamWaitEvent(stream, next.uploaded, 0));
+        Msv1SecondFrame two;
+        two.stream = next.src_dev;
+        two.agg = static_cast<unsigned long long*>(next.d_agg.p);
+        two.info = next.d_info();
+        two.host_info = static_cast<Msv1AsyncInfo*>(next.h_info.p);
+        two.keep = next.dma ? nullptr : static_cast<uint8_t*>(next.d_stream.p);
+        two.info_before = d_info();
+        two.rec = next.rec;
+        two.epoch = next_epoch(next.epoch);
+        two.bad_mask = next.bad_mask();
+        two.want = next.want;
+        two.want_before = want;
+        auto* info_dev = d_info();
+        msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
+                          next_epoch(epoch), 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad_mask(), d_poison, &rec,
+                          static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles, &two);
+        JSP_HIP(hipGetLastError());
+        decoded = true;
+        next.decoded = true;
+    }
     void decode(hipStream_t stream) override {
         auto* info_dev = d_info();
-        const uint32_t bad = MSV1_ASYNC_SHORT | MSV1_ASYNC_END | MSV1_ASYNC_STUCK | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE) | (deaf ? MSV1_LAB_DEAF : 0u);
+        const uint32_t bad = bad_mask();
         if (merged) {
             want += (uint32_t)ntiles;
             if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
@@ -289,6 +316,7 @@ struct Msv1Codec : jsp_codec {
     std::shared_ptr<std::atomic<long long>> lookback_fallbacks = std::make_shared<std::atomic<long long>>(0);
     long long counter(const char* name) override {
         if (std::strcmp(name, "prefetched_frames") == 0) return prefetched_frames;
+        if (std::strcmp(name, "paired_frames") == 0) return paired_frames;
         return std::strcmp(name, "lookback_fallbacks") == 0 ? lookback_fallbacks->load() : -1;
     }
     bool opt_async_merged = true, opt_async_dma = true, opt_async_auto = true;
@@ -375,8 +403,44 @@ struct Msv1Codec : jsp_codec {
     size_t last_full_dev_bytes = 0;
     DeviceBuffer d_poison;   // asynchronous path: set by a vetoed decode pass, cleared by async_reset()
     void async_reset() override {
+        held = nullptr;          // (a frame held for its successor is among those about to be re-run: it is never launched)
         if (d_poison.p) JSP_HIP(hipMemsetAsync(d_poison.p, 0, sizeof(uint32_t), stream));
     }
+    // Two frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until the next frame is submitted and the
+    // two go out together (Msv1AsyncStaged::decode_with) — or alone, as soon as anybody waits for it or anything else needs the stream.
+    bool opt_async_pairs = [] { const char* e = std::getenv("JSP_MSV1_ASYNC_PAIRS"); return !(e && e[0] == '0'); }();
+    jsp_async_job* held = nullptr;
+    long long paired_frames = 0;      // jsp_counter("paired_frames"): frames that went out two to a launch
+    void launch_held() {
+        if (!held) return;
+        jsp_async_job* h = held;
+        held = nullptr;
+        h->st->decode(stream);
+        JSP_HIP(hipEventRecord(h->done, stream));
+    }
+    bool async_launch(jsp_async_job& j) override {
+        auto* st = dynamic_cast<Msv1AsyncStaged*>(j.st.get());
+        if (!st || !st->merged || !opt_async_pairs) { launch_held(); return false; }
+        if (held) {
+            auto* first = dynamic_cast<Msv1AsyncStaged*>(held->st.get());
+            if (first && first->small_tiles == st->small_tiles) {
+                jsp_async_job* h = held;
+                held = nullptr;
+                first->decode_with(*st, stream);
+                JSP_HIP(hipEventRecord(h->done, stream));
+                JSP_HIP(hipEventRecord(j.done, stream));
+                paired_frames += 2;
+                return true;
+            }
+            launch_held();
+        }
+        held = &j;
+        return true;
+    }
+    void async_flush(const jsp_async_job* only_if_held) override {
+        if (held && (!only_if_held || only_if_held == held)) launch_held();
+    }
+    void worker_drain() override { launch_held(); }   // (every call that needs the stream's work queued, or waits for it, comes through here)
 
     Msv1Codec(int bits, int w, int h, const uint8_t* pal, int pal_bytes) {
         kind = bits == 16 ? JSP_CODEC_MSVIDEO1_16 : JSP_CODEC_MSVIDEO1_8;
@@ -434,6 +498,12 @@ struct Msv1Codec : jsp_codec {
         if (std::strcmp(key, "msv1_inject_fault") == 0) {   // tests: the next staged batch behaves as if a tile's look-back had timed out
             opt_inject_fault = std::strcmp(value, "1") == 0;
             opt_inject_deaf = std::strcmp(value, "2") == 0;   // ... or the next one-launch asynchronous frame as if its verdict wait had
+            return 0;
+        }
+        if (std::strcmp(key, "msv1_async_pairs") == 0) {    // one-launch asynchronous frames two to a launch (on) or one by one (off)
+            if (std::strcmp(value, "on") != 0 && std::strcmp(value, "off") != 0) return JSP_ERROR_OCCURED;
+            launch_held();
+            opt_async_pairs = std::strcmp(value, "on") == 0;
             return 0;
         }
         if (std::strcmp(key, "msv1_parse_pieces") == 0) {   // a replay's table-writing parse in this many pieces, beside the launches that read them (1: one launch first)

@@ -416,16 +416,30 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // LS = slots (2 bytes) per lane: 32 (16 KiB tiles) for the batch forms, 16 (8 KiB tiles) for the one-frame-per-launch forms,
 // whose few dozen workgroups have the GPU to themselves: half the serial work per tile, twice the tiles.
 template <int BITS, int MODE, int LS>
-__global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream,
+__global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream_p,
                                                             const Msv1TileRec* __restrict__ recs,
                                                             const int32_t* __restrict__ palette,
-                                                            unsigned long long* __restrict__ agg, uint32_t epoch,
-                                                            uint32_t tile0, uint32_t* __restrict__ fault,
+                                                            unsigned long long* __restrict__ agg_p, uint32_t epoch_p,
+                                                            uint32_t tile0, uint32_t* __restrict__ fault_p,
                                                             uint32_t nblocks, int nbx, int X,
-                                                            Msv1AsyncInfo* __restrict__ info, uint32_t s1_first_block,
-                                                            uint32_t bad_mask, uint32_t* __restrict__ poison,
-                                                            Msv1TileRec one_rec, Msv1AsyncInfo* __restrict__ host_info, uint32_t want,
-                                                            uint8_t* __restrict__ keep) {
+                                                            Msv1AsyncInfo* __restrict__ info_p, uint32_t s1_first_block,
+                                                            uint32_t bad_mask_p, uint32_t* __restrict__ poison,
+                                                            Msv1TileRec one_rec_p, Msv1AsyncInfo* __restrict__ host_info_p, uint32_t want_p,
+                                                            uint8_t* __restrict__ keep_p, Msv1SecondFrame second) {
+    // MODE 3 may carry TWO frames in one launch (msv1.h, Msv1SecondFrame): workgroups [0, tiles_before) are the first frame's tiles, the
+    // rest the second's, with everything a frame calls its own — bytes, tables, report, record — taken from `second`.  Both frames parse
+    // side by side; the second paints when the first is through (it may read its pixels).  Every other mode: the parameters as they are.
+    const bool second_frame = MODE == 3 && second.tiles_before != 0u && blockIdx.x >= second.tiles_before;
+    const uint32_t bid = second_frame ? blockIdx.x - second.tiles_before : blockIdx.x;
+    const uint8_t* __restrict__ stream = second_frame ? second.stream : stream_p;
+    unsigned long long* __restrict__ agg = second_frame ? second.agg : agg_p;
+    const uint32_t epoch = second_frame ? second.epoch : epoch_p;
+    Msv1AsyncInfo* __restrict__ info = second_frame ? second.info : info_p;
+    uint32_t* __restrict__ fault = second_frame ? &second.info->fault : fault_p;
+    const uint32_t bad_mask = second_frame ? second.bad_mask : bad_mask_p;
+    Msv1AsyncInfo* __restrict__ host_info = second_frame ? second.host_info : host_info_p;
+    const uint32_t want = second_frame ? second.want : want_p;
+    uint8_t* __restrict__ keep = second_frame ? second.keep : keep_p;
     constexpr bool INFO = MODE == 1 || MODE == 3;
     constexpr bool USES_PREV = MODE != 0;                      // copies of skipped blocks, stage-2 compare (see above)
     constexpr int TSLOTS = PWG * LS;                           // (shadow the file's 32-slot constants)
@@ -461,9 +475,9 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
 #ifdef JSP_FUSED_CLOCKS
     unsigned long long clk_ = __builtin_readcyclecounter();
 #endif
-    Msv1TileRec r = MODE == 3 ? one_rec : recs[tile0 + blockIdx.x];   // MODE 3: one frame per launch, the record is a kernel argument
-    if (MODE == 3) r.k = blockIdx.x;
-    const uint32_t t = PREFIX ? r.first_tile + r.k : tile0 + blockIdx.x;   // the tile's number in stream order (its slot in `agg`)
+    Msv1TileRec r = MODE == 3 ? (second_frame ? second.rec : one_rec_p) : recs[tile0 + blockIdx.x];   // MODE 3: the record is a kernel argument
+    if (MODE == 3) r.k = bid;
+    const uint32_t t = PREFIX ? r.first_tile + r.k : tile0 + bid;   // the tile's number in stream order (its slot in `agg`)
     if (MODE != 3 && (r.flags & MSV1_TILE_SKIP)) return;
     // MODE 3 bookkeeping (thread 0): `arrived` counts the workgroups whose findings are in info->flags, `finished` those
     // that have written their last pixel; both run on from launch to launch (`want` = their value once this launch is
@@ -832,6 +846,23 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
                 }
                 s_entry = verdict == MSV1_VERDICT_VETO ? 1u : 0u;
                 if (s_entry) atomicOr(poison, 1u);             // ... and every later frame in flight with it
+                if (!s_entry && second_frame) {
+                    // The frame in front, in this very launch: every tile of it must be through — painted, or vetoed — before a pixel of
+                    // this one is written (it may copy from that frame, and be compared with it).  If that frame was vetoed the veto word
+                    // is set by now (its tiles set it before they finish): this frame then goes to the host with it, unpainted.
+                    for (int spin = 0;; ++spin) {
+                        if ((int32_t)(__hip_atomic_load(&second.info_before->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - second.want_before) >= 0) break;
+                        if (spin >= VERDICT_SPIN_LIMIT) {
+                            atomicOr(&info->flags, MSV1_ASYNC_STUCK);
+                            atomicOr(poison, 1u);
+                            s_entry = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    __threadfence();                           // (what the frame in front wrote is what this one reads)
+                    if (!s_entry && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_entry = 1u;
+                }
             }
             arrived = true;
             __syncthreads();
@@ -981,14 +1012,16 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
                        hipStream_t stream, Msv1AsyncInfo* d_info, int insignificant_blocks, int mode, uint32_t bad_mask,
                        uint32_t* d_poison, const Msv1TileRec* one_rec, Msv1AsyncInfo* h_info, uint32_t want, uint8_t* d_keep,
-                       bool small_tiles) {
+                       bool small_tiles, const Msv1SecondFrame* second) {
     if (ntiles <= 0) return;
+    Msv1SecondFrame two{};
+    if (second && mode == 3) { two = *second; two.tiles_before = (uint32_t)ntiles; ntiles += (int)two.rec.ntiles; }
     const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
     const Msv1TileRec rec = one_rec ? *one_rec : Msv1TileRec{};
     if (mode == 0 || mode == 4) small_tiles = false;           // the batch forms lay frames out on 16 KiB boundaries
 #define JSP_FUSED(BITS, MODE, LS)                                                                                            \
     hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE, LS>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
-                       d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep)
+                       d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep, two)
 #define JSP_FUSED_LS(BITS, MODE) do { if (small_tiles) JSP_FUSED(BITS, MODE, 16); else JSP_FUSED(BITS, MODE, JSP_BATCH_LS); } while (0)
 #define JSP_FUSED_MODES(BITS)                                                                                                \
     switch (mode) { case 1: JSP_FUSED_LS(BITS, 1); break; case 2: JSP_FUSED_LS(BITS, 2); break; case 3: JSP_FUSED_LS(BITS, 3); break; \

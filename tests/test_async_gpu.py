@@ -158,6 +158,33 @@ def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size,
         assert seen["prefetched"] == 0, seen                    # (odd geometry: every frame is staged synchronously, from the caller's bytes)
 
 
+@pytest.mark.parametrize("bits,size", [(16, (320, 240)), (8, (320, 240)), (16, (1920, 1080))], ids=["16-320x240", "8-320x240", "16-1080p"])
+@pytest.mark.parametrize("pairs", ["on", "off"])
+def test_msvideo1_async_two_frames_per_launch(bits, size, pairs):
+    """Option msv1_async_pairs (default on): a one-launch frame is held until the next one is submitted and the two go out in ONE launch — both
+    parse side by side, the second paints when the first is through (it copies from its pixels and is compared with them), and is left
+    unpainted when the first was vetoed.  Key and inter frames, a frame that ends early and a frame of noise in the middle (vetoed: re-run by
+    the host together with whatever rode along), depths 2 and 5 (odd: a frame is left over and goes out alone when it is waited for).
+    Same results as the oracle either way; the counter says whether pairs were formed."""
+    w, h = size
+    n = 12 if w * h > 500000 else 30
+    frames, keys, pal = sg.msv1_clip(81, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=7)
+    frames = list(frames)
+    frames[4] = frames[4][:len(frames[4]) // 3]
+    frames[9] = np.random.default_rng(9).integers(0, 256, 1501, dtype=np.uint8).tobytes()
+    for depth in (2, 5):
+        gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
+        gpu.set_option("msv1_parse", "gpu")
+        gpu.set_option("msv1_async_pairs", pairs)
+        seen = {}
+        drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=True,
+              before_close=lambda g: seen.update(n=g.counter("paired_frames")))
+        if pairs == "on":
+            assert seen["n"] >= n // 3 and seen["n"] % 2 == 0, seen
+        else:
+            assert seen["n"] == 0, seen
+
+
 def test_prefetched_ranges_of_pageable_memory():
     """The file need not be in pinned memory: ranges of an ordinary allocation go up through the runtime's staging, frames out of them
     are decoded from the device copy all the same."""
