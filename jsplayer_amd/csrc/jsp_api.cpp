@@ -470,6 +470,7 @@ namespace {
 // The frame of job `from` could not be settled by the GPU alone: everything from it on is re-run, in order, through
 // the synchronous path (the codec's state is put back to what it was before that frame).
 void redo_from(jsp_codec* c, uint64_t from) {
+    c->async_flush(nullptr);                             // (frames held for their successors go out as submitted: they find the veto word set and leave their frames alone)
     JSP_HIP(hipStreamSynchronize(c->stream));
     c->async_reset();
     jsp_async_job& first = c->jobs[from % c->async_depth];

@@ -130,21 +130,26 @@ constexpr uint32_t MSV1_LAB_DEAF = 0x80000000u;   // in `bad_mask` (tests): mode
 // (any alignment, nothing read past the frame's last byte): each tile reads its bytes once, over the bus, and leaves a copy
 // in `d_keep` (HBM, the frame's size rounded up to 16 bytes).
 constexpr int MSV1_MERGED_MAX_TILES = 128;
-// mode 3 with TWO frames in one launch: the frame submitted right behind the first one rides along — workgroups [0, tiles_before) are the
-// first frame's tiles, [tiles_before, tiles_before + rec.ntiles) this one's.  Both frames load, parse and reach their verdicts side by side
-// (none of that touches a pixel); this frame's tiles then wait until every tile of the first has finished (`info_before->finished` has
-// reached `want_before`) before they write — the frame may copy from the first one's pixels and be compared with them — and leave it
-// unwritten when the first was vetoed.  One launch and one kernel-to-kernel gap per two frames, and the second frame's parse hidden behind
-// the first one's painting: what bounds ONE player stream is the chain of its frames' kernels.  tiles_before = 0: no second frame.
-struct Msv1SecondFrame {
+// mode 3 with SEVERAL frames in one launch: the frames submitted right behind the first one (up to 3) ride along — workgroups
+// [0, f[0].first_wg) are the first frame's tiles, [f[i].first_wg, f[i].first_wg + f[i].rec.ntiles) those of rider i.  All frames load, parse
+// and reach their verdicts side by side (none of that touches a pixel); a rider's tiles then wait until every tile of the frame in front
+// has finished (that frame's `finished` has reached its `want`) before they write — a frame may copy from the pixels of the one before it
+// and be compared with them — and leave their frame unwritten when the one in front was vetoed.  One launch and one kernel-to-kernel gap
+// per group, and every frame's parse hidden behind the painting of the frames before it: what bounds ONE player stream is the chain of
+// its frames' kernels.  count = 0: one frame, as ever.
+struct Msv1Rider {
     const uint8_t* stream = nullptr;
     unsigned long long* agg = nullptr;
     Msv1AsyncInfo* info = nullptr;
     Msv1AsyncInfo* host_info = nullptr;
     uint8_t* keep = nullptr;
-    const Msv1AsyncInfo* info_before = nullptr;
     Msv1TileRec rec{};
-    uint32_t epoch = 0, bad_mask = 0, want = 0, want_before = 0, tiles_before = 0, pad = 0;
+    uint32_t epoch = 0, bad_mask = 0, want = 0, first_wg = 0;
+};
+constexpr int MSV1_MAX_RIDERS = 3;
+struct Msv1Riders {
+    uint32_t count = 0, pad = 0;
+    Msv1Rider f[MSV1_MAX_RIDERS];
 };
 // One-frame launches of a small frame (an inter frame, an 8-bit frame: a few hundred KB) use 8 KiB tiles — `small_tiles` —: twice the
 // workgroups, half the serial work in each; the kernel's time is a chain of dependent steps per tile, and such a launch has the
@@ -157,7 +162,7 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
                        hipStream_t stream, Msv1AsyncInfo* d_info = nullptr, int insignificant_blocks = 0, int mode = 0,
                        uint32_t bad_mask = 0, uint32_t* d_poison = nullptr, const Msv1TileRec* one_rec = nullptr,
                        Msv1AsyncInfo* h_info = nullptr, uint32_t want = 0, uint8_t* d_keep = nullptr, bool small_tiles = false,
-                       const Msv1SecondFrame* second = nullptr);   // (mode 3 only: a second frame in the same launch)
+                       const Msv1Riders* riders = nullptr);   // (mode 3 only: more frames in the same launch; first_wg is filled in here)
 
 // Kernel launchers (msv1_kernels.hip).  All asynchronous on `stream`.
 void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,

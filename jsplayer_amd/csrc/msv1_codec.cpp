@@ -245,31 +245,33 @@ struct Msv1AsyncStaged : jsp_staged {
         return reinterpret_cast<Msv1AsyncInfo*>(static_cast<uint8_t*>(d_meta.p) + sizeof(Msv1TileRec) * (size_t)ntiles);
     }
     uint32_t bad_mask() const { return MSV1_ASYNC_SHORT | MSV1_ASYNC_END | MSV1_ASYNC_STUCK | (have_prev ? 0u : MSV1_ASYNC_SKIPCODE) | (deaf ? MSV1_LAB_DEAF : 0u); }
-    // This frame and the one submitted right behind it in ONE launch (both one-launch frames with the same tile size; msv1.h, Msv1SecondFrame).
-    void decode_with(Msv1AsyncStaged& next, hipStream_t stream) {
+    // This frame and the ones submitted right behind it (at most MSV1_MAX_RIDERS) in ONE launch: all one-launch frames with the same tile
+    // size (msv1.h, Msv1Riders).
+    void decode_with(const std::vector<Msv1AsyncStaged*>& behind, hipStream_t stream) {
         want += (uint32_t)ntiles;
-        next.want += (uint32_t)next.ntiles;
         if (dma) JSP_HIP(hipStreamWaitEvent(stream, uploaded, 0));
-        if (next.dma) JSP_HIP(hipStreamWaitEvent(stream, next.uploaded, 0));
-        Msv1SecondFrame two;
-        two.stream = next.src_dev;
-        two.agg = static_cast<unsigned long long*>(next.d_agg.p);
-        two.info = next.d_info();
-        two.host_info = static_cast<Msv1AsyncInfo*>(next.h_info.p);
-        two.keep = next.dma ? nullptr : static_cast<uint8_t*>(next.d_stream.p);
-        two.info_before = d_info();
-        two.rec = next.rec;
-        two.epoch = next_epoch(next.epoch);
-        two.bad_mask = next.bad_mask();
-        two.want = next.want;
-        two.want_before = want;
+        Msv1Riders riders;
+        for (Msv1AsyncStaged* next : behind) {
+            next->want += (uint32_t)next->ntiles;
+            if (next->dma) JSP_HIP(hipStreamWaitEvent(stream, next->uploaded, 0));
+            Msv1Rider& r = riders.f[riders.count++];
+            r.stream = next->src_dev;
+            r.agg = static_cast<unsigned long long*>(next->d_agg.p);
+            r.info = next->d_info();
+            r.host_info = static_cast<Msv1AsyncInfo*>(next->h_info.p);
+            r.keep = next->dma ? nullptr : static_cast<uint8_t*>(next->d_stream.p);
+            r.rec = next->rec;
+            r.epoch = next_epoch(next->epoch);
+            r.bad_mask = next->bad_mask();
+            r.want = next->want;
+        }
         auto* info_dev = d_info();
         msv1_launch_fused(geo, src_dev, nullptr, d_palette, static_cast<unsigned long long*>(d_agg.p),
                           next_epoch(epoch), 0, ntiles, &info_dev->fault, stream, info_dev, insignificant_blocks, 3, bad_mask(), d_poison, &rec,
-                          static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles, &two);
+                          static_cast<Msv1AsyncInfo*>(h_info.p), want, dma ? nullptr : static_cast<uint8_t*>(d_stream.p), small_tiles, &riders);
         JSP_HIP(hipGetLastError());
         decoded = true;
-        next.decoded = true;
+        for (Msv1AsyncStaged* next : behind) next->decoded = true;
     }
     void decode(hipStream_t stream) override {
         auto* info_dev = d_info();
@@ -355,6 +357,7 @@ struct Msv1Codec : jsp_codec {
             return 0;
         }
         if (!opt_gpu_parse) return 0;         // (the host parser reads the caller's bytes: nothing to take up)
+        launch_held();                        // (frames held for their successors may read the range that is about to be given up: their kernels go out first)
         UpRange& r = ranges[range_next++ % kRanges];
         r.host = nullptr;                     // (not to be found while it is being replaced)
         r.bytes = 0;
@@ -403,42 +406,47 @@ struct Msv1Codec : jsp_codec {
     size_t last_full_dev_bytes = 0;
     DeviceBuffer d_poison;   // asynchronous path: set by a vetoed decode pass, cleared by async_reset()
     void async_reset() override {
-        held = nullptr;          // (a frame held for its successor is among those about to be re-run: it is never launched)
+        held.clear();            // (frames held for their successors are among those about to be re-run: they are never launched)
         if (d_poison.p) JSP_HIP(hipMemsetAsync(d_poison.p, 0, sizeof(uint32_t), stream));
     }
-    // Two frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until the next frame is submitted and the
-    // two go out together (Msv1AsyncStaged::decode_with) — or alone, as soon as anybody waits for it or anything else needs the stream.
+    // Several frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until enough frames are submitted behind it
+    // — half of what may be in flight ("async_depth"), at most 1 + MSV1_MAX_RIDERS — and they go out together (Msv1AsyncStaged::decode_with);
+    // or with whatever is held, as soon as anybody waits for one of them or anything else needs the stream.
     bool opt_async_pairs = [] { const char* e = std::getenv("JSP_MSV1_ASYNC_PAIRS"); return !(e && e[0] == '0'); }();
-    jsp_async_job* held = nullptr;
-    long long paired_frames = 0;      // jsp_counter("paired_frames"): frames that went out two to a launch
+    std::vector<jsp_async_job*> held;
+    long long paired_frames = 0;      // jsp_counter("paired_frames"): frames that shared a launch with others
+    int frames_per_launch() const {
+        static const int lab = [] { const char* e = std::getenv("JSP_MSV1_FRAMES_PER_LAUNCH"); return e ? std::atoi(e) : 0; }();
+        const int k = lab > 0 ? lab : async_depth / 2;
+        return k < 1 ? 1 : (k > 1 + MSV1_MAX_RIDERS ? 1 + MSV1_MAX_RIDERS : k);
+    }
     void launch_held() {
-        if (!held) return;
-        jsp_async_job* h = held;
-        held = nullptr;
-        h->st->decode(stream);
-        JSP_HIP(hipEventRecord(h->done, stream));
+        if (held.empty()) return;
+        std::vector<jsp_async_job*> group;
+        group.swap(held);
+        auto* first = static_cast<Msv1AsyncStaged*>(group[0]->st.get());
+        if (group.size() == 1) {
+            first->decode(stream);
+        } else {
+            std::vector<Msv1AsyncStaged*> behind;
+            for (size_t i = 1; i < group.size(); ++i) behind.push_back(static_cast<Msv1AsyncStaged*>(group[i]->st.get()));
+            first->decode_with(behind, stream);
+            paired_frames += (long long)group.size();
+        }
+        for (jsp_async_job* j : group) JSP_HIP(hipEventRecord(j->done, stream));
     }
     bool async_launch(jsp_async_job& j) override {
         auto* st = dynamic_cast<Msv1AsyncStaged*>(j.st.get());
-        if (!st || !st->merged || !opt_async_pairs) { launch_held(); return false; }
-        if (held) {
-            auto* first = dynamic_cast<Msv1AsyncStaged*>(held->st.get());
-            if (first && first->small_tiles == st->small_tiles) {
-                jsp_async_job* h = held;
-                held = nullptr;
-                first->decode_with(*st, stream);
-                JSP_HIP(hipEventRecord(h->done, stream));
-                JSP_HIP(hipEventRecord(j.done, stream));
-                paired_frames += 2;
-                return true;
-            }
-            launch_held();
-        }
-        held = &j;
+        const int k = frames_per_launch();
+        if (!st || !st->merged || !opt_async_pairs || k < 2) { launch_held(); return false; }
+        if (!held.empty() && static_cast<Msv1AsyncStaged*>(held[0]->st.get())->small_tiles != st->small_tiles) launch_held();
+        held.push_back(&j);
+        if ((int)held.size() >= k) launch_held();
         return true;
     }
     void async_flush(const jsp_async_job* only_if_held) override {
-        if (held && (!only_if_held || only_if_held == held)) launch_held();
+        if (held.empty()) return;
+        if (!only_if_held || std::find(held.begin(), held.end(), only_if_held) != held.end()) launch_held();
     }
     void worker_drain() override { launch_held(); }   // (every call that needs the stream's work queued, or waits for it, comes through here)
 

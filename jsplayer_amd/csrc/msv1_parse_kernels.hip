@@ -425,21 +425,29 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
                                                             Msv1AsyncInfo* __restrict__ info_p, uint32_t s1_first_block,
                                                             uint32_t bad_mask_p, uint32_t* __restrict__ poison,
                                                             Msv1TileRec one_rec_p, Msv1AsyncInfo* __restrict__ host_info_p, uint32_t want_p,
-                                                            uint8_t* __restrict__ keep_p, Msv1SecondFrame second) {
-    // MODE 3 may carry TWO frames in one launch (msv1.h, Msv1SecondFrame): workgroups [0, tiles_before) are the first frame's tiles, the
-    // rest the second's, with everything a frame calls its own — bytes, tables, report, record — taken from `second`.  Both frames parse
-    // side by side; the second paints when the first is through (it may read its pixels).  Every other mode: the parameters as they are.
-    const bool second_frame = MODE == 3 && second.tiles_before != 0u && blockIdx.x >= second.tiles_before;
-    const uint32_t bid = second_frame ? blockIdx.x - second.tiles_before : blockIdx.x;
-    const uint8_t* __restrict__ stream = second_frame ? second.stream : stream_p;
-    unsigned long long* __restrict__ agg = second_frame ? second.agg : agg_p;
-    const uint32_t epoch = second_frame ? second.epoch : epoch_p;
-    Msv1AsyncInfo* __restrict__ info = second_frame ? second.info : info_p;
-    uint32_t* __restrict__ fault = second_frame ? &second.info->fault : fault_p;
-    const uint32_t bad_mask = second_frame ? second.bad_mask : bad_mask_p;
-    Msv1AsyncInfo* __restrict__ host_info = second_frame ? second.host_info : host_info_p;
-    const uint32_t want = second_frame ? second.want : want_p;
-    uint8_t* __restrict__ keep = second_frame ? second.keep : keep_p;
+                                                            uint8_t* __restrict__ keep_p, Msv1Riders riders) {
+    // MODE 3 may carry SEVERAL frames in one launch (msv1.h, Msv1Riders): the first workgroups are the first frame's tiles, the rest belong to
+    // the riders, with everything a frame calls its own — bytes, tables, report, record — taken from the rider's entry.  All frames parse
+    // side by side; a rider paints when the frame in front is through (it may read its pixels).  Every other mode: the parameters as they are.
+    uint32_t ride = 0;                                         // 0: the launch's first frame; i: rider i - 1
+    if (MODE == 3)
+        for (uint32_t q = 0; q < riders.count; ++q) ride = blockIdx.x >= riders.f[q].first_wg ? q + 1u : ride;
+    const bool rider = MODE == 3 && ride != 0u;
+    const Msv1Rider& rd = riders.f[rider ? ride - 1u : 0u];
+    const uint32_t bid = rider ? blockIdx.x - rd.first_wg : blockIdx.x;
+    const uint8_t* __restrict__ stream = rider ? rd.stream : stream_p;
+    unsigned long long* __restrict__ agg = rider ? rd.agg : agg_p;
+    const uint32_t epoch = rider ? rd.epoch : epoch_p;
+    Msv1AsyncInfo* __restrict__ info = rider ? rd.info : info_p;
+    uint32_t* __restrict__ fault = rider ? &rd.info->fault : fault_p;
+    const uint32_t bad_mask = rider ? rd.bad_mask : bad_mask_p;
+    Msv1AsyncInfo* __restrict__ host_info = rider ? rd.host_info : host_info_p;
+    const uint32_t want = rider ? rd.want : want_p;
+    uint8_t* __restrict__ keep = rider ? rd.keep : keep_p;
+    // the frame in front of a rider: its report and the value its `finished` counter reaches when all its tiles are through
+    const Msv1AsyncInfo* info_before = ride >= 2u ? riders.f[ride - 2u].info : info_p;
+    const uint32_t want_before = ride >= 2u ? riders.f[ride - 2u].want : want_p;
+    const uint32_t epoch_before = ride >= 2u ? riders.f[ride - 2u].epoch : epoch_p;
     constexpr bool INFO = MODE == 1 || MODE == 3;
     constexpr bool USES_PREV = MODE != 0;                      // copies of skipped blocks, stage-2 compare (see above)
     constexpr int TSLOTS = PWG * LS;                           // (shadow the file's 32-slot constants)
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
 #ifdef JSP_FUSED_CLOCKS
     unsigned long long clk_ = __builtin_readcyclecounter();
 #endif
-    Msv1TileRec r = MODE == 3 ? (second_frame ? second.rec : one_rec_p) : recs[tile0 + blockIdx.x];   // MODE 3: the record is a kernel argument
+    Msv1TileRec r = MODE == 3 ? (rider ? rd.rec : one_rec_p) : recs[tile0 + blockIdx.x];   // MODE 3: the record is a kernel argument
     if (MODE == 3) r.k = bid;
     const uint32_t t = PREFIX ? r.first_tile + r.k : tile0 + bid;   // the tile's number in stream order (its slot in `agg`)
     if (MODE != 3 && (r.flags & MSV1_TILE_SKIP)) return;
@@ -845,23 +853,28 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
                     else __builtin_amdgcn_s_sleep(8);
                 }
                 s_entry = verdict == MSV1_VERDICT_VETO ? 1u : 0u;
-                if (s_entry) atomicOr(poison, 1u);             // ... and every later frame in flight with it
-                if (!s_entry && second_frame) {
-                    // The frame in front, in this very launch: every tile of it must be through — painted, or vetoed — before a pixel of
-                    // this one is written (it may copy from that frame, and be compared with it).  If that frame was vetoed the veto word
-                    // is set by now (its tiles set it before they finish): this frame then goes to the host with it, unpainted.
+                if (rider) {
+                    // The frame in front, in this very launch: every tile of it must be through — painted, or left unpainted — before a
+                    // pixel of this one is written (it may copy from that frame, and be compared with it) AND before this frame may set the
+                    // veto word: all frames of a launch reach their verdicts side by side, and a word set now could still meet a tile of a
+                    // frame in front at its first instruction.  If the frame in front was left unpainted (vetoed, or behind a vetoed one
+                    // itself: its tiles say so in its report, tagged with its launch epoch, before they finish) this frame goes to the host
+                    // with it, unpainted too.
                     for (int spin = 0;; ++spin) {
-                        if ((int32_t)(__hip_atomic_load(&second.info_before->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - second.want_before) >= 0) break;
+                        if ((int32_t)(__hip_atomic_load(&info_before->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want_before) >= 0) break;
                         if (spin >= VERDICT_SPIN_LIMIT) {
                             atomicOr(&info->flags, MSV1_ASYNC_STUCK);
-                            atomicOr(poison, 1u);
                             s_entry = 1u;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(8);
                     }
                     __threadfence();                           // (what the frame in front wrote is what this one reads)
-                    if (!s_entry && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_entry = 1u;
+                    if (!s_entry && __hip_atomic_load(&info_before->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch_before) s_entry = 1u;
+                }
+                if (s_entry) {
+                    atomicOr(poison, 1u);                      // ... and every later frame in flight with it
+                    __hip_atomic_store(&info->pad[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "launch `epoch` leaves this frame unpainted"
                 }
             }
             arrived = true;
@@ -1012,10 +1025,13 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
                        unsigned long long* d_agg, uint32_t epoch, uint32_t tile0, int ntiles, uint32_t* d_fault,
                        hipStream_t stream, Msv1AsyncInfo* d_info, int insignificant_blocks, int mode, uint32_t bad_mask,
                        uint32_t* d_poison, const Msv1TileRec* one_rec, Msv1AsyncInfo* h_info, uint32_t want, uint8_t* d_keep,
-                       bool small_tiles, const Msv1SecondFrame* second) {
+                       bool small_tiles, const Msv1Riders* riders) {
     if (ntiles <= 0) return;
-    Msv1SecondFrame two{};
-    if (second && mode == 3) { two = *second; two.tiles_before = (uint32_t)ntiles; ntiles += (int)two.rec.ntiles; }
+    Msv1Riders two{};
+    if (riders && mode == 3) {
+        two = *riders;
+        for (uint32_t q = 0; q < two.count; ++q) { two.f[q].first_wg = (uint32_t)ntiles; ntiles += (int)two.f[q].rec.ntiles; }
+    }
     const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
     const Msv1TileRec rec = one_rec ? *one_rec : Msv1TileRec{};
     if (mode == 0 || mode == 4) small_tiles = false;           // the batch forms lay frames out on 16 KiB boundaries

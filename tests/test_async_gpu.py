@@ -161,18 +161,18 @@ def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size,
 @pytest.mark.parametrize("bits,size", [(16, (320, 240)), (8, (320, 240)), (16, (1920, 1080))], ids=["16-320x240", "8-320x240", "16-1080p"])
 @pytest.mark.parametrize("pairs", ["on", "off"])
 def test_msvideo1_async_two_frames_per_launch(bits, size, pairs):
-    """Option msv1_async_pairs (default on): a one-launch frame is held until the next one is submitted and the two go out in ONE launch — both
-    parse side by side, the second paints when the first is through (it copies from its pixels and is compared with them), and is left
-    unpainted when the first was vetoed.  Key and inter frames, a frame that ends early and a frame of noise in the middle (vetoed: re-run by
-    the host together with whatever rode along), depths 2 and 5 (odd: a frame is left over and goes out alone when it is waited for).
-    Same results as the oracle either way; the counter says whether pairs were formed."""
+    """Option msv1_async_pairs (default on): a one-launch frame is held until half of what may be in flight is submitted (at most four frames)
+    and they go out in ONE launch — all parse side by side, each paints when the one in front is through (it copies from its pixels and is
+    compared with them), and is left unpainted when that one was vetoed.  Key and inter frames, a frame that ends early and a frame of noise
+    in the middle (vetoed: re-run by the host together with whatever rode along), depths 4, 5 (two per launch, a frame left over goes out
+    alone when it is waited for) and 8 (four per launch).  Same results as the oracle either way; the counter says whether groups were formed."""
     w, h = size
     n = 12 if w * h > 500000 else 30
     frames, keys, pal = sg.msv1_clip(81, w, h, n, bits=bits, p_mix=sg.msv1_p_mix(0.7, 20.0), key_every=7)
     frames = list(frames)
     frames[4] = frames[4][:len(frames[4]) // 3]
     frames[9] = np.random.default_rng(9).integers(0, 256, 1501, dtype=np.uint8).tobytes()
-    for depth in (2, 5):
+    for depth in (4, 5, 8):
         gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
         gpu.set_option("msv1_parse", "gpu")
         gpu.set_option("msv1_async_pairs", pairs)
@@ -180,9 +180,25 @@ def test_msvideo1_async_two_frames_per_launch(bits, size, pairs):
         drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=True,
               before_close=lambda g: seen.update(n=g.counter("paired_frames")))
         if pairs == "on":
-            assert seen["n"] >= n // 3 and seen["n"] % 2 == 0, seen
+            assert seen["n"] >= n // 3, seen
         else:
             assert seen["n"] == 0, seen
+
+
+def test_prefetched_ranges_recycled_under_frames_held_for_a_group_launch():
+    """Eight frames in flight (four to a launch) out of ranges of ONE frame each: the codec keeps four ranges, so the range a held frame reads is
+    due to be given up by the prefetch two frames later — the held frames' kernels must go out before it is (the fuzz campaign found this one:
+    wrong pixels, then a fault on a freed range)."""
+    w, h, n = 320, 240, 40
+    rng = np.random.default_rng(12)
+    frames, keys, _ = sg.msv1_clip(83, w, h, n, p_mix=sg.msv1_p_mix(0.6, 15.0), key_every=4)
+    frames = [f + bytes(int(rng.integers(0, 4000)) * 2) if k else f for f, k in zip(frames, keys)]   # (sizes vary: the ranges' device copies are reallocated now and then)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    seen = {}
+    drive(gpu, OracleMSVideo1(16, w, h), w, h, frames, keys, depth=8, pinned=True, prefetch=1,
+          before_close=lambda g: seen.update(p=g.counter("prefetched_frames"), g=g.counter("paired_frames")))
+    assert seen["p"] >= n // 2 and seen["g"] >= n // 4, seen
 
 
 def test_prefetched_ranges_of_pageable_memory():
