@@ -141,6 +141,14 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       finds the pixels it starts from by a last-writer look-back over the block records (every frame of the group then needs a
  *       buffer of its own).  Measured slower on MI355X; kept as a launch plan that needs no long-lived workgroups.
  *       Results do not depend on it.
+ *   "msv1_async_pairs" = "on" (default) | "off" : MSVideo1 with "msv1_parse" = "gpu", asynchronous calls, frames of up to 128 parse tiles.
+ *       on: such a frame is not launched at once but HELD until half of "async_depth" frames (at most 4) have been submitted, and they go
+ *       out in ONE launch: all of them load, parse and reach their verdicts side by side, each paints when the frame in front is through
+ *       (it may copy from its pixels and be compared with them) and is left unpainted — for the host's re-run — when the frame in front
+ *       was.  Whatever is held goes out at once when one of the held frames is waited for, or when anything else needs the stream
+ *       (jsp_sync, a synchronous call, jsp_prefetch, jsp_set_stream).  One player stream is bound by the chain of its frames' kernels:
+ *       64 -> 94 Gpixels/s at 1080p with 8 frames in flight.  jsp_counter(c, "paired_frames") counts the frames that shared a launch.
+ *       Results do not depend on it.
  *   "msv1_parse_pieces" = "1" (default) .. "16" : MSVideo1 with "msv1_parse" = "gpu", staged batches with inter frames.  A replay of
  *       such a batch writes its block tables with one launch and paints from them with the next; n > 1: the tables are written in
  *       n pieces of frames on a second stream, and the inter-frame launches — cut at the same frames — paint piece p while piece
