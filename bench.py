@@ -355,6 +355,11 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
                    "seconds": round(many["seconds"], 3), "uploaded_bytes_per_s": round(float(tot[3])),
                    "note": f"{threads} independent streams per GPU (host threads, a codec instance and a FILE OF ITS OWN each: stream 0 the "
                            f"{ncap}-frame sample, the others {nshort}-frame clips of other seeds), every stream playing its file over and over for the same {secs} s"}
+    # what the streams' decoders counted on this rank (jsp_counter, since their creation: the untimed pass included): frames the GPU could not settle
+    # alone and the host re-ran (a time-out among them would show here), frames that shared a launch, frames found in a prefetched range
+    for k in ("async_reruns", "paired_frames", "prefetched_frames"):
+        if k in many:
+            all_threads[k] = many[k]
     if not one:
         return {"all_threads": all_threads}
     # what the bus itself delivers on this box: pinned host-to-device copies, nothing else queued (jsp_measure_h2d)
@@ -387,6 +392,9 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
                           "instead of a copy per frame" % prefetch_mb if spec["codec"] == "msv1" and prefetch_mb > 0 else "")}
     if spec["codec"] == "msv1":
         e2e["prefetch_MB"] = prefetch_mb
+    for k in ("async_reruns", "paired_frames", "prefetched_frames"):
+        if k in one:
+            e2e[k] = one[k]
     if batch_api:
         e2e["batch_api"] = batch_api
     if h2d:

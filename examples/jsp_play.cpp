@@ -147,6 +147,9 @@ using Clock = std::chrono::steady_clock;
 // `sink`: the per-frame lines go there instead of stdout (several streams printing side by side).
 // --prefetch MB (g_prefetch_bytes): the file's bytes go to the device in ranges of about that size, the range after the current one ahead of the frames being
 // submitted (jsp_prefetch), every pass over the file anew; the frames' own uploads then fall away (MSVideo1; other codecs ignore it).
+// what the streams' decoders counted (jsp_counter), summed when they are destroyed: frames re-run through the synchronous path, frames that shared a
+// launch, frames that found their bytes in a prefetched range
+std::atomic<long long> g_async_reruns{0}, g_paired_frames{0}, g_prefetched_frames{0};
 size_t g_prefetch_bytes = 32u << 20;                     // (--prefetch 0: every frame finds its own way up)
 long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int warmup = 0, Gate* gate = nullptr, Clock::time_point* t0 = nullptr,
                     Clock::time_point* t1 = nullptr, int device = 0, double seconds = 0, std::string* sink = nullptr) {
@@ -282,6 +285,11 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
         while (!flying.empty()) collect();
     }
     if (t1) *t1 = Clock::now();
+    for (auto [name, sum] : {std::pair<const char*, std::atomic<long long>*>{"async_reruns", &g_async_reruns}, {"paired_frames", &g_paired_frames},
+                             {"prefetched_frames", &g_prefetched_frames}}) {
+        const long long v = jsp_counter(dec, name);
+        if (v > 0) sum->fetch_add(v);
+    }
     jsp_pool_destroy(pool);
     jsp_codec_destroy(dec);
     return failed ? -1 : done;
@@ -486,8 +494,9 @@ int main(int argc, char** argv) {
             shard += "], \"total_pixels\": " + std::to_string(total[1]) + ", \"counter_reduce\": \"" + (via ? "rccl" : "host") + "\"";
         }
         std::printf("{\"streams\": %d, \"files\": %zu, \"depth\": %d, \"frames\": %ld, \"warmup_passes\": %d, \"seconds\": %.6f, \"mpixels_per_s\": %.1f, "
-                    "\"compressed_bytes\": %.0f, \"uploaded_bytes_per_s\": %.0f%s}\n", streams, clips.size(), depth, frames,
-                    warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6, compressed, compressed / sec, shard.c_str());
+                    "\"compressed_bytes\": %.0f, \"uploaded_bytes_per_s\": %.0f, \"async_reruns\": %lld, \"paired_frames\": %lld, \"prefetched_frames\": %lld%s}\n",
+                    streams, clips.size(), depth, frames, warmup, sec, frames * (double)clip.X * clip.Y / sec / 1e6, compressed, compressed / sec,
+                    g_async_reruns.load(), g_paired_frames.load(), g_prefetched_frames.load(), shard.c_str());
         return 0;
     }
     jsp_codec* dec = jsp_codec_create(clip.kind, clip.X, clip.Y, clip.bpp, clip.palette.empty() ? nullptr : clip.palette.data(),
