@@ -422,6 +422,7 @@ struct Msv1Codec : jsp_codec {
     }
     void launch_held() {
         if (held.empty()) return;
+        activate();
         std::vector<jsp_async_job*> group;
         group.swap(held);
         auto* first = static_cast<Msv1AsyncStaged*>(group[0]->st.get());
@@ -467,6 +468,7 @@ struct Msv1Codec : jsp_codec {
     }
 
     int preinit(int lines) override {
+        launch_held();                        // (frames held for a group launch were staged under the settings so far)
         insignificant_blocks = (lines + 3) >> 2;
         if (geo.bits == 16) {
             insign_lines = lines;
