@@ -123,8 +123,9 @@ def _spawn_ranks(n: int) -> int:
 class Job:
     """What every leg needs to know about the run: ranks, the stream everything is queued on, the bracket."""
 
-    def __init__(self, args, rank, local_rank, world, distributed, stream):
+    def __init__(self, args, rank, local_rank, world, distributed, stream, coll_device="cuda"):
         self.args, self.rank, self.local_rank, self.world, self.distributed, self.stream = args, rank, local_rank, world, distributed, stream
+        self.coll_device = coll_device        # "cuda": RCCL; "cpu": gloo (--ranks-share-device: RCCL does not take two ranks on one device)
 
     def barrier(self):
         import torch
@@ -168,17 +169,23 @@ def resident_leg(job: Job, name: str, nfr_override=None, nclips=None):
     elapsed = time.perf_counter() - t0
     job.barrier()                             # closing bracket; the job's time is the max over ranks (below)
     gpu_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream, whole timed region
-    # ---- what the timed kernels left in HBM against the oracle's digests ------------------------------------
+    # ---- what a launch of the timed kind writes, against the oracle's digests ---------------------------------
+    # Warm-up already left correct frames in HBM, so hashing them would pass even if the timed replays had done nothing.  Every
+    # destination frame is therefore overwritten with 0xEE bytes first, ONE more (untimed) step of exactly the launches that were
+    # timed runs, and what THAT leaves is hashed: a frame the replay does not fully write cannot match.
     verified, bad = False, []
     if not args.no_verify and nfr_override is None:
         gold = wl.golden_digests(name, rank)
         if gold is None:
             verified = "no golden digests recorded for this workload / rank"
         else:
+            work.scrub()
+            step()
+            work.sync()
             bad = work.mismatches(gold)
             verified = not bad
     # 2 = every frame matches, 1 = not checked, 0 = mismatch; the job's verdict is the minimum over ranks
-    ok = torch.tensor([0 if bad else (2 if verified is True else 1)], dtype=torch.int64, device="cuda")
+    ok = torch.tensor([0 if bad else (2 if verified is True else 1)], dtype=torch.int64, device=job.coll_device)
     if job.distributed:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok[0]) == 0:
@@ -190,15 +197,15 @@ def resident_leg(job: Job, name: str, nfr_override=None, nclips=None):
     # slow paths the timed launches may have taken instead of the kernels named below (results never depend on them; the
     # number would): the fused kernel's look-back time-out re-runs a batch through the descriptor kernels
     fallbacks = work.lookback_fallbacks()
-    fb = torch.tensor([fallbacks], dtype=torch.int64, device="cuda")
+    fb = torch.tensor([fallbacks], dtype=torch.int64, device=job.coll_device)
     if job.distributed:
         dist.all_reduce(fb, op=dist.ReduceOp.SUM)
     fallbacks = int(fb[0])
     if fallbacks:
         print(f"[bench] {name}: {fallbacks} look-back fall-backs inside the run: the step time includes descriptor-path re-runs", file=sys.stderr)
 
-    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * wl.W * wl.H, elapsed, device="cuda")
-    per_rank = gather_per_rank(nfr * args.steps, device="cuda")
+    total_frames, total_pixels, elapsed = reduce_counters(nfr * args.steps, nfr * args.steps * wl.W * wl.H, elapsed, device=job.coll_device)
+    per_rank = gather_per_rank(nfr * args.steps, device=job.coll_device)
 
     launches = sum(i["kernel_launches"] for i in infos)
     step_us = gpu_ms * 1e3 / args.steps                       # GPU time of one step, HIP events
@@ -287,7 +294,7 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
     # own (seeds of ranks 1000 + rank*16 + 1 ...: independent inputs), shorter ones — what matters is that no two streams read
     # the same bytes
     nshort = max(8, ncap // 8) if not inter else ncap
-    secs = seconds if seconds else (1.5 if spec["codec"] == "msv1" else 3.0)
+    secs = seconds if seconds else float(os.environ.get("JSP_BENCH_E2E_SECONDS", 0) or (1.5 if spec["codec"] == "msv1" else 3.0))
     prefetch_mb = float(os.environ.get("JSP_BENCH_PREFETCH_MB", "32"))    # jsp_play --prefetch (MSVideo1: the file goes up in ranges of this size, jsp_prefetch; 0: a copy / a bus read per frame)
 
     def avi_of(frames, keys, palette):
@@ -348,7 +355,7 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
         del dsts
     # job-wide: the ranks played at the same time, each on its own GPU; rates add up
     tot = torch.tensor([one["mpixels_per_s"] if one else 0.0, many["mpixels_per_s"], one["uploaded_bytes_per_s"] if one else 0.0, many["uploaded_bytes_per_s"]],
-                       dtype=torch.float64, device="cuda")
+                       dtype=torch.float64, device=job.coll_device)
     if job.distributed:
         dist.all_reduce(tot)
     all_threads = {"value": round(float(tot[1]), 1), "unit": "Mpixels/s", "streams": threads * args.gpus, "frames": many["frames"],
@@ -399,8 +406,9 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
         e2e["batch_api"] = batch_api
     if h2d:
         e2e["h2d_ceiling_GBs"] = h2d
-        e2e["uploaded_fraction_of_h2d_ceiling"] = round(float(tot[2]) / max(1, args.gpus) / 1e9 / h2d["value"], 3)
-        e2e["all_threads"]["uploaded_fraction_of_h2d_ceiling"] = round(float(tot[3]) / max(1, args.gpus) / 1e9 / h2d["value"], 3)
+        buses = 1 if args.ranks_share_device else max(1, args.gpus)     # (ranks that share a device share its bus)
+        e2e["uploaded_fraction_of_h2d_ceiling"] = round(float(tot[2]) / buses / 1e9 / h2d["value"], 3)
+        e2e["all_threads"]["uploaded_fraction_of_h2d_ceiling"] = round(float(tot[3]) / buses / 1e9 / h2d["value"], 3)
     return e2e
 
 
@@ -432,7 +440,9 @@ def measured_ceilings(job: Job):
 
 
 def _with_ceilings(roofline, write_share, live, recorded):
-    """measured_ceiling / frac_of_measured / recorded_ceiling for one workload's roofline object."""
+    """reference_fill / frac_of_reference_fill / recorded_fill for one workload's roofline object.  A yardstick, NOT a ceiling: a plain
+    one-store-per-lane fill of this box's memory, measured in this run — kernels whose stores come in friendlier bursts (all-solid
+    MSVideo1 frames) have been seen 3 % above it.  The roofline fraction proper is `frac`, of the 8 TB/s peak."""
     rec = None
     if recorded:
         try:
@@ -442,9 +452,9 @@ def _with_ceilings(roofline, write_share, live, recorded):
             rec = None
     ceiling = live or rec
     out = dict(roofline)
-    out["measured_ceiling"] = ceiling
-    out["frac_of_measured"] = round(roofline["achieved"] / ceiling["value"], 4) if ceiling else None
-    out["recorded_ceiling"] = rec
+    out["reference_fill"] = ceiling
+    out["frac_of_reference_fill"] = round(roofline["achieved"] / ceiling["value"], 4) if ceiling else None
+    out["recorded_fill"] = rec
     return out
 
 
@@ -461,6 +471,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="experiments only: the JSON line then says verified: false")
+    ap.add_argument("--ranks-share-device", action="store_true",
+                    help="rehearsal of an N-GPU run on ONE GPU: every rank decodes its own streams (seeds, digests, legs: all per rank, as "
+                         "on N GPUs) on device 0, the process group is gloo and the collectives run on host tensors (RCCL refuses two ranks "
+                         "on one device); the line says ranks_share_device and n_gpus 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the launcher, the process group (gloo) and the counter collectives only; value is null")
     args = ap.parse_args()
@@ -507,15 +521,21 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    share = args.ranks_share_device
+    if share:
+        local_rank = 0                        # every rank on the one device there is
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # a dedicated (non-null) stream: kernels and the timing events are queued on the same one
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    job = Job(args, rank, local_rank, world, distributed, stream)
+    job = Job(args, rank, local_rank, world, distributed, stream, coll_device="cpu" if share else "cuda")
     t_all = time.perf_counter()
 
     name = args.workload
@@ -532,7 +552,7 @@ def main():
             "metric": METRIC,
             "value": head["value"],
             "unit": "Mpixels/s",
-            "n_gpus": args.gpus,
+            "n_gpus": 1 if share else args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
@@ -542,6 +562,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "verified": head["verified"],
+            "verified_how": "after the timed region every destination frame is overwritten with 0xEE bytes, one more untimed step of the same "
+                            "launches runs, and every frame it leaves in HBM is hashed against the CPU oracle's digest (tests/golden/bench_digests.json)",
             "lookback_fallbacks": head["lookback_fallbacks"],
             "config": {
                 "workload": name,
@@ -551,7 +573,8 @@ def main():
                 "clips_per_step": head["clips_per_step"],
                 "destination_frames": head["destination_frames"],
                 "streams": args.gpus,
-                "sharding": "one independent AVI stream per GPU, no data-path collective",
+                "sharding": ("REHEARSAL: %d ranks, one independent stream each, all on GPU 0 (gloo, host-tensor collectives)" % args.gpus) if share else
+                            "one independent AVI stream per GPU, no data-path collective",
                 "inputs": head["inputs"],
                 "input_bytes_per_step": head["input_bytes_per_step"],
             },
@@ -587,8 +610,8 @@ def main():
                 "host_stage": {k: v for k, v in leg["host_stage"].items() if k != "note"},
                 "total_frames": leg["total_frames"], "per_rank_frames": leg["per_rank_frames"],
             }
-            ent["roofline"].pop("recorded_ceiling", None)
-            ent["roofline"]["measured_ceiling"] = ent["roofline"]["measured_ceiling"]["value"] if ent["roofline"]["measured_ceiling"] else None
+            ent["roofline"].pop("recorded_fill", None)
+            ent["roofline"]["reference_fill"] = ent["roofline"]["reference_fill"]["value"] if ent["roofline"]["reference_fill"] else None
             if many:
                 ent["e2e"] = many
             if args.gpus == 1 and not args.no_cpu_baseline:
@@ -600,6 +623,9 @@ def main():
             entries.append(ent)
         del wclips
     if rank == 0:
+        if share:
+            out["ranks_share_device"] = True
+            out["ranks"] = args.gpus
         if also:
             out["also"] = entries
         out["bench_wall_s"] = round(time.perf_counter() - t_all, 1)

@@ -136,11 +136,13 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       frames are rebuilt by ONE launch (pixels carried in registers from frame to frame; the host stage
  *       hands motion rectangles over as literal pixels; a frame that moves more than a quarter of its
  *       pixels keeps its motion blocks and a launch of its own).  "off": one launch per frame.
- *   "sp_group_chunk" = "0" (default) | "4" | "8" | "16" : ScreenPressor only.  "0": a workgroup of such a launch walks the whole
- *       group (the loader-wave kernel).  n: the launch is split along the time axis too — a workgroup emits n frames and exits, and
- *       finds the pixels it starts from by a last-writer look-back over the block records (every frame of the group then needs a
- *       buffer of its own).  Measured slower on MI355X; kept as a launch plan that needs no long-lived workgroups.
- *       Results do not depend on it.
+ *   "sp_forget_buffers" = "1" : ScreenPressor only; nothing may be in flight.  CONTRACT behind it: an inter frame may read ONE pixel per row of
+ *       its destination before writing it (ScreenPressor.hx:436-449: "left of column 0" is the last pixel of the row above, which this
+ *       frame has not reached), so the codec remembers the last column of every picture it decoded into a buffer and asks the device for the
+ *       column of a buffer it has never written — a synchronous copy, ordered after work on blocking streams only: the caller's own writes
+ *       to that buffer must be complete.  A caller that writes into frame buffers itself BETWEEN decodes (jsp_upload, a clear, another codec
+ *       sharing the pool, a buffer freed and allocated again at the same address) says so with this option and every buffer is asked for
+ *       again; without such writes nothing needs to be said.  Buffers of a frame that failed are forgotten by the codec itself.
  *   "msv1_async_pairs" = "on" (default) | "off" : MSVideo1 with "msv1_parse" = "gpu", asynchronous calls, frames of up to 128 parse tiles.
  *       on: such a frame is not launched at once but HELD until half of "async_depth" frames (at most 4) have been submitted, and they go
  *       out in ONE launch: all of them load, parse and reach their verdicts side by side, each paints when the frame in front is through
@@ -148,11 +150,7 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       was.  Whatever is held goes out at once when one of the held frames is waited for, or when anything else needs the stream
  *       (jsp_sync, a synchronous call, jsp_prefetch, jsp_set_stream).  One player stream is bound by the chain of its frames' kernels:
  *       64 -> 94 Gpixels/s at 1080p with 8 frames in flight.  jsp_counter(c, "paired_frames") counts the frames that shared a launch.
- *       Results do not depend on it.
- *   "msv1_parse_pieces" = "1" (default) .. "16" : MSVideo1 with "msv1_parse" = "gpu", staged batches with inter frames.  A replay of
- *       such a batch writes its block tables with one launch and paints from them with the next; n > 1: the tables are written in
- *       n pieces of frames on a second stream, and the inter-frame launches — cut at the same frames — paint piece p while piece
- *       p + 1 is parsed.  Measured slower on MI355X.  Results do not depend on it. */
+ *       Results do not depend on it. */
 /*   "msv1_async" = "auto" (default) | "one_launch_dma" | "one_launch" | "two_launches" : MSVideo1 with "msv1_parse" = "gpu",
  *       asynchronous calls only; frames of up to 128 parse tiles (2 MiB).  auto: one_launch_dma while at most 3 codec instances
  *       of the process use this path, one_launch beyond (many streams: the copy queues are the bottleneck).  one_launch_dma: the copy engine brings the frame's bytes up on a
@@ -167,7 +165,8 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       own: ScreenPressor's host stage holds both pictures and answers itself (synchronous calls), otherwise the compare is queued on
  *       the codec's stream right behind the frame's kernels (no extra wait; the frame is still in the Infinity Cache).  The answer:
  *       jsp_key_frame_differs() after a synchronous DecompressI; *significant_changes of jsp_wait for an asynchronous one (a key
- *       frame with no previous frame to be compared with counts as a change: Manager.hx:399-411).  Staged batches are not compared. */
+ *       frame that decoded and has no previous frame to be compared with counts as a change: Manager.hx:399-411; for a frame that FAILED
+ *       *significant_changes stays what the decode reported and jsp_key_frame_differs() says -1).  Staged batches are not compared. */
 /*   "async_depth" = "1".."16" (default "4") : any codec.  Frames that may be in flight between jsp_decompress_*_async and
  *       jsp_wait. */
 int jsp_set_option(jsp_codec* c, const char* key, const char* value);
@@ -309,16 +308,6 @@ int jsp_reduce_counters(const int* devices, int ndev, const uint64_t* per_device
 const char* jsp_shard_last_error(void);
 
 /* Library/build identification: "jsplayer_amd <version> gfx950". */
-/* Measurement helper (no reference counterpart): the store rate this GPU reaches when asked for nothing else — `reps` launches
- * that fill `nbytes` of `device` (16-byte aligned) with one 16-byte store per lane, workgroups in address order, timed with HIP
- * events on `hip_stream`; best of three passes, GB/s.  bench.py reports it next to the 8 TB/s the roofline is priced against
- * (the boxes of one pool differ by a fifth in what their memory delivers). */
-int jsp_measure_fill(int32_t* device, size_t nbytes, int reps, double* gbytes_per_s, void* hip_stream);
-/* ... and what the BUS delivers (no reference counterpart): `copies` pinned host-to-device copies of `bytes_per_copy` on each of `nstreams`
- * (1..16) HIP streams of the device side by side, wall clock, best of three passes, GB/s — the ceiling of every end-to-end rate, where
- * the compressed bytes are all that crosses (bench.py: e2e.h2d_ceiling_GBs). */
-int jsp_measure_h2d(int device_id, size_t bytes_per_copy, int nstreams, int copies, double* gbytes_per_s);
-
 const char* jsp_version(void);
 
 #ifdef __cplusplus

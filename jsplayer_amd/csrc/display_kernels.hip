@@ -8,6 +8,7 @@
 #include <cstdint>
 
 #include "../../include/jsplayer_amd.h"
+#include "../../include/jsplayer_amd_lab.h"
 #include "common.h"
 
 namespace {

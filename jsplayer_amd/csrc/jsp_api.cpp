@@ -616,8 +616,10 @@ int wait_ticket(jsp_codec* c, uint64_t ticket, int32_t** data_pnt, int* signific
     if (significant_changes) *significant_changes = j.significant;
     if (j.frame.key) {
         c->last_key_differs = c->key_compare_row >= 0 && j.status == JSP_ZERO_STATE ? j.key_differs : -1;
-        // a key frame with nothing to be compared with counts as a change (Manager.hx:399-411: the first frame, no previous frame)
-        if (c->key_compare_row >= 0 && significant_changes) *significant_changes = j.key_differs != 0 ? 1 : 0;
+        // ONE mapping, here: jsp_key_frame_differs() says 1 / 0 / -1 (nothing to compare with, or the frame failed); *significant_changes of a
+        // key frame THAT DECODED says "changed" for 1 and for -1 (Manager.hx:399-411: the first frame, no previous frame, counts as a
+        // change).  A frame that failed reports what the decode reported (0): its status is the news, not a change.
+        if (c->key_compare_row >= 0 && significant_changes && j.status == JSP_ZERO_STATE) *significant_changes = j.key_differs != 0 ? 1 : 0;
     }
     return j.status;
 }

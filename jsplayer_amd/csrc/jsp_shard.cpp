@@ -12,9 +12,15 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>   // types and enums only: every entry point is taken from dlsym
-
 #include "codec.h"
+#include "../../include/jsplayer_amd_lab.h"
+
+// The few RCCL types and constants the counter reduce needs, spelled out here (values as in rccl/rccl.h of ROCm 7: part of the NCCL
+// ABI): every entry point is taken from dlsym, and a ROCm install without the RCCL headers still builds the library.
+typedef struct ncclComm* ncclComm_t;
+enum ncclResult_t : int { ncclSuccess = 0 };
+enum ncclDataType_t : int { ncclUint64 = 5 };
+enum ncclRedOp_t : int { ncclSum = 0 };
 
 namespace {
 

@@ -13,6 +13,7 @@
 
 #include "codec.h"
 #include "msv1.h"
+#include <msv1_fused_hooks.h>   // (angle brackets: a lab build puts its own in front on the include path, see the Makefile)
 
 namespace jsp {
 namespace {
@@ -48,24 +49,8 @@ struct Msv1Staged : jsp_staged {
     bool needs_desc = false;   // some launch reads the descriptor table the parse kernels build
     std::vector<uint32_t> scrub;   // (tests: option "msv1_scrub_tables") frames whose table a replay rewrites: poisoned before it does
     bool any_fused = false;
-    // A replay's table-writing parse in PIECES of frames on a second stream (option "msv1_parse_pieces"): piece p + 1 is parsed while
-    // the launches that read piece p's tables store their pixels — the parse is bound by its serial walk, the block kernels by
-    // memory, and side by side each takes what the other leaves.  piece_first[p] = first frame of piece p (+ one past the last).
-    std::vector<int> piece_first;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr;
-    std::vector<hipEvent_t> ev_piece;
-    ~Msv1Staged() override {
-        if (side) (void)hipStreamSynchronize(side);
-        for (hipEvent_t e : ev_piece) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (side) (void)hipStreamDestroy(side);
-    }
-    int piece_of(int frame) const {
-        int p = 0;
-        while (p + 2 < (int)piece_first.size() && piece_first[p + 1] <= frame) ++p;
-        return p;
-    }
+    // (Round 4 also wrote the replay's tables in PIECES of frames on a second stream, beside the launches that read the piece before — option
+    // "msv1_parse_pieces": bit-exact and 12 - 50 % slower in every split, profiles/r04_msv1_parse_pieces.txt; removed in round 5, commit history has it.)
 
     void launch_parse(hipStream_t stream) {
         msv1_launch_parse(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
@@ -81,37 +66,14 @@ struct Msv1Staged : jsp_staged {
         // A replay re-executes the whole device pipeline: with the on-GPU parse that includes the
         // parse kernels, so a staged batch can be timed from raw stream bytes.  (The first decode
         // uses the tables the staging pass left behind.)
-        const int pieces = (int)piece_first.size() - 1;
-        bool piped = false;
-        int waited = -1;                                       // pieces [0, waited] are behind `stream` already
-        auto tables_of = [&](int last_frame) {                 // the launches queued next read the tables of frames up to last_frame
-            if (!piped) return;
-            const int p = piece_of(last_frame);
-            for (int q = waited + 1; q <= p; ++q) JSP_HIP(hipStreamWaitEvent(stream, ev_piece[q], 0));
-            if (p > waited) waited = p;
-        };
         if (gpu_parse && decoded && needs_desc)   // one launch: the fused kernel's parse, writing block tables instead of pixels
         {
             for (uint32_t i : scrub)
                 JSP_HIP(hipMemsetAsync(static_cast<uint32_t*>(d_desc.p) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE,
                                        sizeof(uint32_t) * (size_t)geo.nblocks, stream));
-            if (pieces > 1) {
-                JSP_HIP(hipEventRecord(ev_fork, stream));      // (the tables' readers of the replay before, the scrub)
-                JSP_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-                const auto* pf = static_cast<const Msv1ParseFrame*>(h_pframes.p);
-                for (int p = 0; p < pieces; ++p) {
-                    const uint32_t t0 = pf[piece_first[p]].first_tile;
-                    const Msv1ParseFrame& last = pf[piece_first[p + 1] - 1];
-                    msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                                      static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), t0, (int)(last.first_tile + last.ntiles - t0),
-                                      static_cast<uint32_t*>(d_sync.p), side, nullptr, 0, 4);
-                    JSP_HIP(hipEventRecord(ev_piece[p], side));
-                }
-                piped = true;
-            } else
-                msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                                  static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
-                                  nullptr, 0, 4);
+            msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
+                              static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
+                              nullptr, 0, 4);
         }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
@@ -124,43 +86,27 @@ struct Msv1Staged : jsp_staged {
                                   static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), tile0, (int)(last.first_tile + last.ntiles - tile0),
                                   static_cast<uint32_t*>(d_sync.p), stream, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);
             } else if (g.temporal) {
-                // (cut where the parse's pieces end: the frames of a piece are painted while the next piece is parsed.  A launch that
-                // starts inside the group finds its pixels where the launch before left them: in the frame its first frame follows.)
-                int a = g.first;
-                const int end = g.first + g.count;
-                while (a < end) {
-                    const int b = piped ? std::min(end, piece_first[piece_of(a) + 1]) : end;
-                    tables_of(b - 1);
-                    msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
-                                                static_cast<const uint32_t*>(d_desc.p), frames + a, b - a, d_palette, stream);
-                    a = b;
-                }
+                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
+                                            static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette, stream);
             } else {
-                tables_of(g.first + g.count - 1);
                 msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p),
                                    static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count,
                                    d_palette, vec_ok, stream);
             }
             if (g.edge_compare) msv1_launch_edge_compare(geo, frames + g.first, g.count, stream);
         }
-        if (piped) tables_of(nframes - 1);                     // (every piece joins `stream`: whoever waits for it waits for the side stream too)
         JSP_HIP(hipGetLastError());
         if (need_signif)
             JSP_HIP(hipMemcpyAsync(h_signif.p, d_signif.p, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost,
                                    stream));
         if (any_fused || needs_desc)
             JSP_HIP(hipMemcpyAsync(h_fault.p, d_sync.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-#ifdef JSP_FUSED_CLOCKS
         ++clock_launches;
-#endif
         decoded = true;
     }
-#ifdef JSP_FUSED_CLOCKS
-    int clock_launches = 0;
-#endif
+    int clock_launches = 0;                                    // (read by the lab build's phase clocks only: msv1_fused_hooks.h)
     void after_sync() override {
-#ifdef JSP_FUSED_CLOCKS
-        if (clock_launches) {   // lab build: per-phase cycle sums since the last sync (see JSP_CLOCK), printed and cleared
+        if (kFusedClocks && clock_launches) {   // lab build only: per-phase cycle sums since the last sync (see JSP_CLOCK), printed and cleared
             std::vector<unsigned long long> c((size_t)ntiles * 8);
             unsigned long long* dev = static_cast<unsigned long long*>(d_agg.p) + (size_t)ntiles * 9;
             JSP_HIP(hipMemcpy(c.data(), dev, c.size() * 8, hipMemcpyDeviceToHost));
@@ -170,9 +116,8 @@ struct Msv1Staged : jsp_staged {
             const unsigned long long n = (unsigned long long)ntiles * clock_launches;
             std::fprintf(stderr, "fused clocks per tile (cycles; %d tiles x %d launches): load %llu | tables+trees %llu | look-back %llu | down %llu | replay %llu | decode %llu\n",
                          ntiles, clock_launches, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
-            clock_launches = 0;
         }
-#endif
+        clock_launches = 0;
         if ((any_fused || needs_desc) && (*static_cast<const uint32_t*>(h_fault.p) || inject_fault)) {
             // A tile gave up waiting for the tile before it.  That says something about the GPU's timing (shared with other
             // work, serialised by a profiler), nothing about the stream: the batch is decoded again through the descriptor
@@ -312,7 +257,6 @@ struct Msv1Codec : jsp_codec {
     DeviceBuffer d_palette;
     bool opt_gpu_parse = true;    // "msv1_parse": frames are parsed on the GPU unless the caller asks for the host parser
     bool opt_scrub_tables = false;
-    int opt_parse_pieces = [] { const char* e = std::getenv("JSP_MSV1_PARSE_PIECES"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }();   // "msv1_parse_pieces"
     bool opt_inject_fault = false;
     bool opt_inject_deaf = false;        // tests ("msv1_inject_fault" = "2"): the next one-launch asynchronous frame never sees all its tiles report
     std::shared_ptr<std::atomic<long long>> lookback_fallbacks = std::make_shared<std::atomic<long long>>(0);
@@ -381,7 +325,10 @@ struct Msv1Codec : jsp_codec {
         return 0;
     }
     UpRange* range_of(const uint8_t* src, size_t n) {
-        for (int k = 0; k < kRanges; ++k) {   // oldest first: of two copies of the same bytes the earlier one has arrived
+        // NEWEST first: a caller that hands the same host address over again (a ring of file chunks, a file played again) means the bytes that
+        // are there NOW — an older copy of that address may hold what was there before.  (Oldest first, until round 4, decoded from a copy two
+        // passes old when a short file was played over and over.)
+        for (int k = kRanges - 1; k >= 0; --k) {
             UpRange& r = ranges[(range_next + (unsigned)k) % kRanges];
             if (r.host && src >= r.host && n <= r.bytes && (size_t)(src - r.host) <= r.bytes - n) return &r;
         }
@@ -514,12 +461,6 @@ struct Msv1Codec : jsp_codec {
             if (std::strcmp(value, "on") != 0 && std::strcmp(value, "off") != 0) return JSP_ERROR_OCCURED;
             launch_held();
             opt_async_pairs = std::strcmp(value, "on") == 0;
-            return 0;
-        }
-        if (std::strcmp(key, "msv1_parse_pieces") == 0) {   // a replay's table-writing parse in this many pieces, beside the launches that read them (1: one launch first)
-            const int v = std::atoi(value);
-            if (v < 1 || v > 16) return JSP_ERROR_OCCURED;
-            opt_parse_pieces = v;
             return 0;
         }
         if (std::strcmp(key, "msv1_scrub_tables") == 0) {   // tests: a replay must rebuild every block table it reads
@@ -1181,20 +1122,7 @@ struct Msv1Codec : jsp_codec {
                             r.cmp_row_lo = 0xFFFFFFFFu;
                             r.flags = (h_pf[i].host_parsed || in_fused[i]) ? MSV1_TILE_SKIP : 0u;
                         }
-                    // Pieces of the replay's parse (see Msv1Staged::piece_first): only when some launch that reads tables has many
-                    // frames to paint behind each piece; the records are in tile-major order inside a piece.
-                    st->piece_first.clear();
-                    int pieces = 1;
-                    for (const auto& g : st->groups)
-                        if (g.temporal && g.count >= 64) pieces = std::max(pieces, std::min(opt_parse_pieces, nf / 32));
-                    for (int q = 0; q <= pieces; ++q) st->piece_first.push_back((int)((long long)nf * q / pieces));
-                    if (pieces > 1 && !st->side) {
-                        JSP_HIP(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
-                        JSP_HIP(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
-                        st->ev_piece.assign((size_t)pieces, nullptr);
-                        for (hipEvent_t& e : st->ev_piece) JSP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                    }
-                    for (int q = 0; q < pieces; ++q) tile_major(er, st->piece_first[q], st->piece_first[q + 1]);
+                    tile_major(er, 0, nf);
                     JSP_HIP(hipMemcpyAsync(st->d_recs_emit.p, er, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
                     st->scrub.clear();
                     if (opt_scrub_tables)

@@ -26,15 +26,13 @@
 #include "msv1.h"
 #include "msv1_lanes.h"
 #include "msv1_decode.h"
+#include <msv1_fused_hooks.h>   // (angle brackets: a lab build puts its own in front on the include path, see the Makefile)
 
 namespace jsp {
 namespace {
 
 constexpr int PWG = 256;                 // lanes per workgroup
-#ifndef JSP_BATCH_LS
-#define JSP_BATCH_LS 32                  // 32: 16 KiB tiles, 16: 8 KiB tiles (staged batches; one-frame launches of small frames always use 16)
-#endif
-constexpr int LSLOTS = JSP_BATCH_LS;     // slots (2 bytes each) per lane
+constexpr int LSLOTS = JSP_BATCH_LS;     // slots (2 bytes each) per lane (msv1_fused_hooks.h)
 constexpr int TSLOTS = PWG * LSLOTS;     // slots per tile
 constexpr uint32_t BSAT = (1u << 28) - 1;
 
@@ -396,23 +394,6 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // MODE 0 is the batch form (no report); its frames never read a previous frame (msv1_codec.cpp only fuses frames without
 // skipped blocks and without a stage-2 compare), so it is compiled without the copy and compare paths: its decode loop
 // then holds no load at all, and the row stores of consecutive blocks are never waited for.
-#ifdef JSP_FUSED_CLOCKS   // lab build: thread 0 of every tile adds the cycles of each phase to its own counters behind the tile tables (`want` = tiles of the batch)
-#define JSP_CLOCK(k) do { if (MODE == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
-    agg[(size_t)want * 9u + (size_t)(tile0 + blockIdx.x) * 8u + (k)] += now_ - clk_; clk_ = now_; } } while (0)
-#elif defined(JSP_FUSED_STOP)   // lab build: the batch form returns after phase JSP_FUSED_STOP (instruction counts per phase, by subtraction)
-#define JSP_CLOCK(k) do { if (MODE == 0 && (k) == JSP_FUSED_STOP) return; } while (0)
-#else
-#define JSP_CLOCK(k) do { } while (0)
-#endif
-#ifndef JSP_FUSED_ALIGN
-#define JSP_FUSED_ALIGN 1      // lab: 0 = staging windows start at the tile's first block (row stores begin anywhere in a memory line)
-#endif
-#ifndef JSP_FUSED_VMCNT
-#define JSP_FUSED_VMCNT 4      // row stores of earlier blocks a wave may still have in flight when it issues a block's four (63 = no limit)
-#endif
-#ifndef JSP_FUSED_WAVES
-#define JSP_FUSED_WAVES 4      // __launch_bounds__: waves per SIMD the register allocation must leave room for
-#endif
 // LS = slots (2 bytes) per lane: 32 (16 KiB tiles) for the batch forms, 16 (8 KiB tiles) for the one-frame-per-launch forms,
 // whose few dozen workgroups have the GPU to themselves: half the serial work per tile, twice the tiles.
 template <int BITS, int MODE, int LS>
@@ -480,9 +461,7 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
     // record (a uniform, scalar load); its bytes sit at t * TILE_BYTES (frames start on tile boundaries), so the
     // stream loads do not wait for the record: under a saturated write stream every dependent global round trip
     // costs microseconds.
-#ifdef JSP_FUSED_CLOCKS
-    unsigned long long clk_ = __builtin_readcyclecounter();
-#endif
+    JSP_CLOCK_BEGIN();
     Msv1TileRec r = MODE == 3 ? (rider ? rd.rec : one_rec_p) : recs[tile0 + blockIdx.x];   // MODE 3: the record is a kernel argument
     if (MODE == 3) r.k = bid;
     const uint32_t t = PREFIX ? r.first_tile + r.k : tile0 + bid;   // the tile's number in stream order (its slot in `agg`)
@@ -506,9 +485,16 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
         }
     };
     if (MODE == 3) {
-        // (uniform over the launch: only earlier launches on this stream, or this one after its verdict, set the word)
+        // (Set by earlier launches on this stream — then every tile of this launch sees it — or by a frame of THIS launch after its verdict:
+        // with several frames per launch a tile dispatched late may see the word while an earlier tile of its frame did not.  A tile that
+        // leaves here therefore marks its frame "left unpainted by launch `epoch`" first: the frame behind reads that mark once all tiles of
+        // this frame have finished, and stays unpainted with it, whichever of this frame's tiles got as far as the verdict.)
         if (__hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            if (threadIdx.x == 0) { arrive(); finish(); }
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&info->pad[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrive();
+                finish();
+            }
             return;
         }
     }
@@ -556,21 +542,6 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
             if (o < (uint32_t)BYTES_W * 4u && at < data_end && !(MODE == 3 && data_end - at < 16u))
                 v[q] = *reinterpret_cast<const uint4*>(stream + at);   // buffers are padded
         }
-#if defined(JSP_FUSED_LAB_TOUCH)
-        // lab: the tile JSP_FUSED_LAB_TOUCH launches ahead (a multiple of 8: the same XCD, the same L2) is touched — one LDS-DMA load per thread, a word of
-        // each of its 256 64-byte lines, into a sink — so that its own loads, a few microseconds from now, come out of the L2.  Behind this tile's loads
-        // (loads return in order) and as asm (no register, and the compiler's vmcnt bookkeeping does not see it).
-        if (MODE == 0 && blockIdx.x + (uint32_t)JSP_FUSED_LAB_TOUCH < gridDim.x) {
-            const Msv1TileRec& ra = recs[tile0 + blockIdx.x + (uint32_t)JSP_FUSED_LAB_TOUCH];
-            const uint32_t ta = ra.byte0 + (uint32_t)tid * 64u;
-            if (!(ra.flags & MSV1_TILE_SKIP) && ta < ra.data_end) {
-                __shared__ uint32_t s_touch_sink[64];
-                const uint32_t sink_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)s_touch_sink);
-                const uint8_t* tp = stream + ta;
-                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(tp), "s"(sink_off) : "memory");
-            }
-        }
-#endif
 #pragma unroll
         for (int q = 0; q < NLOAD; ++q) {
             const uint32_t o = tid * 16u + (uint32_t)q * (PWG * 16u), at = tile_byte0 + o;
@@ -949,9 +920,6 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
             if (coded) {
                 uint32_t px[16];
                 decode_block<BITS>(lds_bytes + o, data_end - (tile_byte0 + o), s_pal, px);
-#ifdef JSP_FUSED_NOSTORE   // lab build: the decode runs, its rows are not written (parse + decode time without the store stream)
-                if ((px[0] ^ px[5] ^ px[10] ^ px[15]) == 0xDEADBEEFu) atomicOr(fault, 2u);
-#else
                 // Store throttle.  A CU's loads and stores share one in-order queue: every row store a wave leaves in flight is
                 // something the other workgroups' loads (tile bytes, look-back word) wait behind.  Keeping at most a few rows per
                 // wave in flight keeps the memory pipe full without that queue growing: profiles/r03_fused_notes.txt.
@@ -959,7 +927,6 @@ __global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const 
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
                     __builtin_nontemporal_store(fu32x4{px[y * 4], px[y * 4 + 1], px[y * 4 + 2], px[y * 4 + 3]}, (fgu32x4*)(dst + (size_t)y * X));
-#endif
                 if (USES_PREV && compare) {                            // stage-2 significance, MSVideo1.hx:195-204
                     // (all four rows are looked at, rows below the first compared one masked out: no load is left pending
                     // behind a condition, so the loop's next round need not wait for this round's stores)

@@ -38,17 +38,16 @@ struct IRun {
     uint32_t start;  // linear pixel index of the first pixel
     uint32_t word;   // low 24 bits: colour or addend; bits 24..25: RunKind; bits 26..31 zero
 };
-// Tile layout (sp_iframe_tile_kernel): the same 8 bytes say where the word goes and what it is, ready to use — `start` is
-// the BYTE offset of the run's first pixel inside its span's row of words (4 x column within the span), `word` keeps the low
-// 24 bits, has kTileHead set (the kernel tells "a run starts here" from "nothing" by it) and ONE of the two predictor bits
-// (or neither: a constant): each is a sign-extending bit-field extract away from being a lane mask.
+// Tile layout (sp_iframe_tile_kernel): 4 bytes per record — bits 31..24 the column of the run's first pixel inside its 256-column span,
+// bits 23..0 the colour / addend.  The kind travels beside it: a row's records are stored sorted by kind (constants, "above",
+// "above-left") and the row's counts — n_const | n_above << 16 — sit next to its left pixel (FrameOut::left).  In the kernel a
+// scattered record becomes the word `value | kTileHead | kind bit`: kTileHead tells "a run starts here" from "nothing", and each of
+// the two (exclusive) predictor bits is a sign-extending bit-field extract away from being a lane mask.
 constexpr uint32_t kTileAbove = 1u << 24;       // the pixel starts from the pixel above (RUN_ABOVE)
 constexpr uint32_t kTileAboveLeft = 1u << 25;   // ... from the pixel above and one to the left (RUN_ABOVE_LEFT), kTileAbove clear
 constexpr uint32_t kTileHead = 0x80000000u;
-inline IRun tile_record(const IRun& r, uint32_t span_row_origin) {   // span_row_origin: linear index of (row, first column of the span)
-    uint32_t w = r.word;
-    if (w & kTileAboveLeft) w &= ~kTileAbove;
-    return IRun{(r.start - span_row_origin) * 4u, w | kTileHead};
+inline uint32_t tile_record32(const IRun& r, uint32_t span_row_origin) {   // span_row_origin: linear index of (row, first column of the span)
+    return ((r.start - span_row_origin) << 24) | (r.word & 0x00FFFFFFu);
 }
 
 // ---- P-frame descriptors --------------------------------------------------------------------
@@ -57,7 +56,7 @@ struct PBlock {        // 16 bytes
     uint8_t flags;
     uint8_t x1, y1, x2, y2;  // changed rectangle relative to the block origin, x2/y2 exclusive
     uint8_t pad;
-    uint16_t back;     // group launches (link_group_tables): frames back to the previous record of this block that painted anything, 0 = none
+    uint16_t pad2;
     int16_t mx, my;
     uint32_t payload;  // index of the rectangle's first literal pixel (group launches: inside the batch's payload, not the frame's)
 };
@@ -86,8 +85,8 @@ struct FrameOut {
     // Intra, tile layout (set_iframe_layout with a span): `runs` is then ordered tile by tile (band-major,
     // then column span, then row, then column; no sentinel) and these two tables describe the tiles
     int span_px = 0;
-    std::vector<uint32_t> tile_idx;  // per tile band_rows+1 offsets into runs: first record of each of its rows (| kRowRepeats), then the end
-    std::vector<uint32_t> left;      // per tile band_rows words: the pixel left of the span's first pixel, one row up
+    std::vector<uint32_t> tile_idx;  // per tile band_rows+1 offsets into the 4-byte records (which travel in `runs`' memory): first record of each of its rows (| kRowRepeats), then the end
+    std::vector<uint32_t> left;      // per tile band_rows PAIRS: the pixel left of the span's first pixel, one row up; the row's kind counts (n_const | n_above << 16)
     std::vector<PBlock> blocks;      // Inter
     std::vector<uint32_t> payload;   // Inter: literal pixels of the data rectangles
     uint64_t prev_pixels = 0;        // Inter: pixels the stream takes from the previous frame
@@ -122,7 +121,8 @@ public:
     // rows per band of the following key frames (0 = whole frame is one band, no seeds)
     void set_band_rows(int rows) { band_rows_ = rows < 0 ? 0 : rows; span_px_ = 0; }
     // bands AND column spans: key frames come out as independent tiles (see FrameOut::tile_idx); span 0 = row-major
-    void set_iframe_layout(int band_rows, int span_px) { band_rows_ = band_rows < 0 ? 0 : band_rows; span_px_ = span_px < 0 ? 0 : span_px; }
+    // (a tile record's column has 8 bits: spans of at most 256 columns)
+    void set_iframe_layout(int band_rows, int span_px) { band_rows_ = band_rows < 0 ? 0 : band_rows; span_px_ = span_px < 0 ? 0 : (span_px > 256 ? 256 : span_px); }
     // Rewrites the motion rectangles of the inter frame just decoded as literal rectangles (pixels from
     // the shadow frame appended to the payload): no block of `out` then reads the previous frame anywhere
     // but at its own position, which is what lets consecutive inter frames share one launch.
@@ -173,6 +173,7 @@ private:
     int band_rows_ = 0, span_px_ = 0;
     std::vector<IRun> tiled_;        // scratch of the tile regrouping (kept: no per-frame allocation)
     std::vector<uint32_t> cursor_;
+    std::vector<uint32_t> recs32_;   // the 4-byte tile records of the frame being regrouped
     std::vector<uint32_t> slot_of_;  // tile slot of every record, in emission order
     std::vector<uint32_t> row_slot_; // tile slot of (row, span 0) for the current layout
     int row_slot_rows_ = 0, row_slot_span_ = 0;
@@ -237,18 +238,7 @@ struct PGroupFrame {   // one per frame of the group, in decode order
 };
 void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev,
                          const PBlock* d_blocks, const uint32_t* d_payload, bool aligned16, hipStream_t stream);
-// The same frames with the time axis split as well: a workgroup = 8 blocks x `chunk` frames (4, 8 or 16), its starting pixels found
-// by a last-writer look-back over the block records.  Needs the tables linked by link_group_tables() — which also says how many
-// literal words the fullest (8 blocks x chunk) cell of the group holds: the LDS a workgroup needs.
-constexpr int kGroupMaxFrames = 65535;        // PBlock::back is 16 bits
-// Links the block tables of the `nframes` consecutive frames of a group launch (frame f's records at blocks + f * nbx * nby) and
-// makes their literal indices absolute (gframes[f].payload_off is added to every painting record and set to 0: every group kernel
-// adds the two).  Returns the literal words of the fullest cell for chunks of `chunk` frames.
-uint32_t link_group_tables(PBlock* blocks, PGroupFrame* gframes, int nframes, int nbx, int nby, int chunk);
-size_t pframe_chunk_lds_bytes(int chunk, uint32_t lit_words);
-bool pframe_chunks_ok(const Geometry& g, const int32_t* prev, bool aligned16, int chunk, uint32_t lit_words);
-void launch_pframe_chunks(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev, const PBlock* d_blocks,
-                          const uint32_t* d_payload, int chunk, uint32_t lit_words, hipStream_t stream);
+constexpr int kGroupMaxFrames = 65535;        // frames one group launch may walk
 size_t iframe_lds_bytes(const Geometry& g, int band_rows = 0);
 constexpr int kMaxIntraWidth = 8192;  // LDS plan of the row-wavefront kernel
 

@@ -29,8 +29,6 @@ struct SpStaged : jsp_staged {
         int32_t* dst;          // Inter
         const int32_t* prev;   // Inter, InterGroup: the frame before the (first) frame
         size_t block_off, payload_off;
-        int chunk = 0;         // InterGroup: frames per workgroup of the time-split kernel (0: the loader-wave kernel walks the whole group)
-        uint32_t lit_words = 0;   // InterGroup: literal words of the fullest (8 blocks x chunk frames) cell
     };
     std::vector<Op> ops;
     DeviceBuffer d_runs, d_rows, d_seeds, d_tileidx, d_left, d_iargs, d_blocks, d_payload, d_gframes;
@@ -49,9 +47,6 @@ struct SpStaged : jsp_staged {
                 launch_iframe_tiles(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, op.band_rows, stream);
             else if (op.kind == Op::Intra)
                 launch_iframes(geo, static_cast<const IFrameArgs*>(d_iargs.p) + op.first, op.count, op.band_rows, stream);
-            else if (op.kind == Op::InterGroup && op.chunk > 0)
-                launch_pframe_chunks(geo, static_cast<const PGroupFrame*>(d_gframes.p) + op.first, op.count, op.prev,
-                                     static_cast<const PBlock*>(d_blocks.p), static_cast<const uint32_t*>(d_payload.p), op.chunk, op.lit_words, stream);
             else if (op.kind == Op::InterGroup)
                 launch_pframe_group(geo, static_cast<const PGroupFrame*>(d_gframes.p) + op.first, op.count, op.prev,
                                     static_cast<const PBlock*>(d_blocks.p), static_cast<const uint32_t*>(d_payload.p),
@@ -97,7 +92,13 @@ struct SpCodec : jsp_codec, DstColumns {
         return col.data();
     }
     void after(const HostFrame& f, const HostDecoder& d, const FrameOut& out) override {
-        if (!out.adopted || f.dst_host) return;        // nothing was written there (host mode: the buffer is read afresh every time)
+        if (f.dst_host) return;                        // (host mode: the buffer is read afresh every time)
+        if (!out.adopted) {
+            // nothing was adopted.  A frame that FAILED part-way may still have painted: what the buffer holds is then neither the picture
+            // remembered here nor a picture of the decoder's — forget it, the next use asks the device.  (An unchanged frame wrote nothing.)
+            if (out.status != 0 && f.dst) { std::lock_guard<std::mutex> lk(col_mu); last_col.erase(f.dst); }
+            return;
+        }
         std::lock_guard<std::mutex> lk(col_mu);
         if (last_col.size() > 8192) last_col.clear();  // (a caller that keeps handing in new buffers: forget, fetch again when asked)
         std::vector<int32_t>& col = last_col[f.dst];
@@ -402,15 +403,6 @@ struct SpCodec : jsp_codec, DstColumns {
     bool may_leave_pixels(const jsp_frame_in&) override { return false; }
     int opt_band_rows = -1;   // -1: chosen per batch (choose_band_rows); 0: one band per frame; n: n rows per band
     bool opt_inter_fusion = true;   // consecutive inter frames of a staged batch share one launch
-    int opt_group_chunk = default_group_chunk();   // frames per workgroup of a group launch (0: whole group per workgroup)
-    static int default_group_chunk() {
-        // Measured (profiles/r04_sp_chunk_ab.txt, one box, 2 x 299 frames at 1080p, digests verified): the loader-wave kernel 1 110 us per
-        // step (0.60 of 8 TB/s); time-split with 16 frames per workgroup 1 272 us (0.52), 8: 1 397 us (0.48), 4: 1 697 us (0.39).  A
-        // workgroup's life is 7.5 us of look-back + 3.7 us per frame, and the 3.7 us is the SAME 17.6 GB/s per CU the long-lived kernel
-        // gets: what bounds this store shape is not how long a workgroup lives, and the look-back is pure cost.  So the default stays 0.
-        if (const char* e = std::getenv("JSP_SP_GROUP_CHUNK")) { const int v = std::atoi(e); return v == 4 || v == 8 || v == 16 ? v : 0; }   // lab
-        return 0;
-    }
     int set_option(const char* key, const char* value) override {
         if (std::strcmp(key, "sp_host_threads") == 0) {
             if (std::strcmp(value, "auto") == 0) { opt_host_threads = 0; return 0; }
@@ -430,10 +422,11 @@ struct SpCodec : jsp_codec, DstColumns {
             opt_async_threads = (int)v;
             return 0;
         }
-        if (std::strcmp(key, "sp_group_chunk") == 0) {
-            const int v = std::atoi(value);
-            if (!(v == 0 || v == 4 || v == 8 || v == 16) || (v == 0 && std::strcmp(value, "0") != 0)) return -1;
-            opt_group_chunk = v;
+        if (std::strcmp(key, "sp_forget_buffers") == 0) {   // the caller has written into frame buffers itself: what they hold is asked for again
+            if (next_ticket != oldest_ticket) return -1;
+            worker_drain();
+            std::lock_guard<std::mutex> lk(col_mu);
+            last_col.clear();
             return 0;
         }
         if (std::strcmp(key, "sp_inter_fusion") == 0) {
@@ -600,20 +593,6 @@ struct SpCodec : jsp_codec, DstColumns {
             w0 = w1;
         }
         if (!one && outs.size() > 1) outs.resize(1);   // (a wave's worth of frame tables is hundreds of MB: only the per-frame calls' one stays)
-        // Group launches: every record is linked to the last record of its block that painted anything (the time-split kernel's
-        // look-back) and the literal indices become absolute; the launch is split along the time axis when the group is long
-        // enough for that to matter and a workgroup's LDS holds the fullest cell of the split.
-        for (auto& op : st->ops) {
-            if (op.kind != SpStaged::Op::InterGroup) continue;
-            const int chunk = opt_group_chunk;
-            op.lit_words = (link_group_tables(blocks.data() + gframes[op.first].block_off, gframes.data() + op.first, op.count, g.nbx, g.nby, chunk) + 63u) & ~63u;
-            // (workgroups of different chunks run side by side: every frame of the group needs a buffer of its own, and none may be the
-            // frame before the group — a player's three-buffer rotation keeps the kernel whose workgroups own their pixels for good)
-            std::unordered_set<const void*> seen{op.prev};
-            bool distinct = true;
-            for (int i = 0; i < op.count && distinct; ++i) distinct = seen.insert(gframes[op.first + i].dst).second;
-            op.chunk = chunk > 0 && distinct && op.count >= 2 * chunk && pframe_chunks_ok(st->geo, op.prev, st->geo.aligned16, chunk, op.lit_words) ? chunk : 0;
-        }
         st->info.frames = nf;
         st->info.pixels = (uint64_t)g.X * g.Y * nf;
         st->info.kernel_launches = st->ops.size();
@@ -632,7 +611,7 @@ struct SpCodec : jsp_codec, DstColumns {
                     st->note_kernel(op.tiles ? "sp_iframe_tile_kernel" : "sp_iframe_rows_search_kernel");
                 } else if (op.kind == SpStaged::Op::InterGroup) {
                     moved += 4 * npx * op.count + 4 * npx;
-                    st->note_kernel(op.chunk > 0 ? "sp_pframe_chunk_kernel" : "sp_pframe_group_kernel");
+                    st->note_kernel("sp_pframe_group_kernel");
                 } else {
                     moved += 8 * npx;
                     st->note_kernel("sp_pframe_kernel");

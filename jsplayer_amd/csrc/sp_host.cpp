@@ -255,8 +255,15 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
             // Screen content repeats itself from row to row: a row of a tile whose records equal, column for column, those
             // of the row above it in the same tile is not stored at all — bit 31 of its index entry (kRowRepeats) says "the
             // same words as the row above", and the wave keeps using the words it has in registers.
+            // What is stored is 4 bytes per record (tile_record32, sp.h): column inside the span | 24-bit colour / addend.  The record's KIND is
+            // not in it: a row's records are stored sorted by kind — constants, then "above", then "above-left" — and the row's two counts sit
+            // beside its left pixel (out.left: two words per row).  Scattering records into the row is order-independent, so the kernel
+            // loses nothing by the sort, and a key frame's records are half the bytes they were (8-byte {offset, word} pairs until round 4).
             runs.clear();
             cursor.assign(idx.begin(), idx.end());        // the index into `tiled`; idx is rewritten to index the packed records
+            std::vector<uint32_t>& recs = recs32_;
+            recs.clear();
+            out.left.assign(ntiles * rows_per * 2, 0);
             for (size_t t = 0; t < ntiles; ++t) {
                 const size_t base = t * stride;
                 for (int r = 0; r < rows_per; ++r) {
@@ -265,16 +272,24 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
                     const uint32_t plo = same ? cursor[base + r - 1] : 0;
                     for (uint32_t k = 0; same && k < hi - lo; ++k)
                         same = tiled[lo + k].word == tiled[plo + k].word && tiled[lo + k].start - tiled[plo + k].start == (uint32_t)X;
-                    idx[base + r] = (uint32_t)runs.size() | (same ? kRowRepeats : 0u);
+                    idx[base + r] = (uint32_t)recs.size() | (same ? kRowRepeats : 0u);
                     if (!same) {
                         const size_t b = t / (size_t)nspans, sp = t % (size_t)nspans;
                         const uint32_t origin = (uint32_t)((b * (size_t)rows_per + (size_t)r) * (size_t)X + sp * (size_t)span_px_);
-                        for (uint32_t k = lo; k < hi; ++k) runs.push_back(tile_record(tiled[k], origin));
+                        uint32_t n_const = 0, n_above = 0;
+                        for (uint32_t k = lo; k < hi; ++k) if ((tiled[k].word >> 24) == RUN_CONST) { recs.push_back(tile_record32(tiled[k], origin)); ++n_const; }
+                        for (uint32_t k = lo; k < hi; ++k) if ((tiled[k].word >> 24) == RUN_ABOVE) { recs.push_back(tile_record32(tiled[k], origin)); ++n_above; }
+                        for (uint32_t k = lo; k < hi; ++k) if ((tiled[k].word >> 24) == RUN_ABOVE_LEFT) recs.push_back(tile_record32(tiled[k], origin));
+                        out.left[(t * rows_per + (size_t)r) * 2 + 1] = n_const | (n_above << 16);
                     }
                 }
-                idx[base + rows_per] = (uint32_t)runs.size();   // the tile's end
+                idx[base + rows_per] = (uint32_t)recs.size();   // the tile's end
             }
-            out.left.assign(ntiles * rows_per, 0);
+            // (the records travel in `runs`' memory, two to an element, padded to an even count: every frame's records then start on an
+            // 8-byte boundary in the batch's table, which the kernel's two-record loads rely on)
+            if (recs.size() & 1) recs.push_back(0);
+            runs.resize(recs.size() / 2);
+            if (!recs.empty()) std::memcpy(static_cast<void*>(runs.data()), recs.data(), recs.size() * 4);
             for (int b = 0; b < nbands; ++b)
                 for (int sp = 0; sp < nspans; ++sp)
                     for (int r = 0; r < rows_per && b * rows_per + r < g_.Y; ++r) {
@@ -282,7 +297,7 @@ void HostDecoder::decode_i(const uint8_t* src, size_t n, FrameOut& out) {
                         // what "above-left" of the span's first pixel reads: one row up, one column left;
                         // for column 0 the linear index wraps to the last pixel two rows up
                         const long i = y * X + (long)sp * span_px_ - X - 1;
-                        out.left[((size_t)b * nspans + sp) * rows_per + r] = i >= 0 ? (uint32_t)dst[i] : 0u;
+                        out.left[(((size_t)b * nspans + sp) * rows_per + r) * 2] = i >= 0 ? (uint32_t)dst[i] : 0u;
                     }
             out.span_px = span_px_;
         }
@@ -489,36 +504,6 @@ void HostDecoder::note_key_compare(FrameOut& out, bool had_prev) const {
 void HostDecoder::last_column(int32_t* out) const {
     const int32_t* pic = shadow_[cur_ ^ 1].data();            // (the decoders swap after a frame: this is the picture just decoded)
     for (int y = 0; y < g_.Y; ++y) out[y] = pic[(size_t)y * g_.X + g_.X - 1];
-}
-
-uint32_t link_group_tables(PBlock* blocks, PGroupFrame* gframes, int nframes, int nbx, int nby, int chunk) {
-    const size_t nblk = (size_t)nbx * (size_t)nby;
-    const int ngx = (nbx + 7) / 8;                         // block groups per block row (8 blocks per workgroup)
-    std::vector<int32_t> last(nblk, -1);                   // the last frame that painted the block
-    std::vector<uint32_t> cell((size_t)ngx * (size_t)nby, 0u);
-    uint32_t fullest = 0;
-    for (int f = 0; f < nframes; ++f) {
-        PBlock* pb = blocks + (size_t)f * nblk;
-        const uint32_t off = gframes[f].payload_off;
-        if (chunk > 0 && f % chunk == 0) std::fill(cell.begin(), cell.end(), 0u);
-        for (int by = 0; by < nby; ++by)
-            for (int bx = 0; bx < nbx; ++bx) {
-                PBlock& b = pb[(size_t)by * nbx + bx];
-                int32_t& l = last[(size_t)by * nbx + bx];
-                b.back = l >= 0 ? (uint16_t)(f - l) : (uint16_t)0;
-                if (b.flags != 0) {
-                    b.payload += off;
-                    l = f;
-                    if (b.flags & PB_DATA) {
-                        uint32_t& c = cell[(size_t)by * ngx + (bx >> 3)];
-                        c += (uint32_t)(b.x2 - b.x1) * (uint32_t)(b.y2 - b.y1);
-                        if (c > fullest) fullest = c;
-                    }
-                }
-            }
-        gframes[f].payload_off = 0;
-    }
-    return fullest;
 }
 
 void HostDecoder::literalise_motion(FrameOut& out) const {

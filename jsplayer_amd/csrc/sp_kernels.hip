@@ -189,25 +189,16 @@ __device__ __forceinline__ uint32_t lane_to_the_left(uint32_t v) {   // lane i g
 // The kernel is bound by the instructions it issues (profiles/r03_sp_iframes_tile_sq_counters.txt: a wave64 VALU
 // instruction holds its SIMD for four cycles and the row loop ran to ~110 of them per row), so everything that is the
 // same for all 64 lanes lives on the scalar unit: a window's index entries and left pixels sit one per lane in two
-// registers and each row takes its own with v_readlane (no LDS read, no address arithmetic); a record arrives as
-// {byte offset inside the LDS row, word | kTileHead} (tile_record, sp.h) and is scattered by ONE ds_write with no arithmetic; the word's
-// two predictor bits are exclusive (kTileAbove / kTileAboveLeft), each a v_bfe_i32 away from being a lane mask.
+// registers and each row takes its own with v_readlane (no LDS read, no address arithmetic); a record arrives as 4 bytes
+// {column inside the span, 24-bit colour / addend} (tile_record32, sp.h: half of round 4's 8-byte {offset, word} pairs), its kind is its
+// place among the row's records (sorted by kind, two scalar counts per row), and one ds_write puts `value | kTileHead | kind bit` at the
+// column; the word's two predictor bits are exclusive (kTileAbove / kTileAboveLeft), each a v_bfe_i32 away from being a lane mask.
 __device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFFFFFFF for 0
     uint32_t r;
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
-#if defined(JSP_SP_LAB_CACHED_RECORDS)
-#define JSP_TILE_OFF(x) ((x) & 1020u)
-#else
-#define JSP_TILE_OFF(x) (x)
-#endif
-#if defined(JSP_SP_LAB_TOUCH)
-#define JSP_TILE_BOUNDS __launch_bounds__(64, 8)   // (the touch's address would cost the kernel its eighth wave per SIMD)
-#else
-#define JSP_TILE_BOUNDS __launch_bounds__(64)
-#endif
-__global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
+__global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
                                                             int band_rows, int nspans, int win_cap, int tile_fastest) {
     constexpr int PPL = 4, SPAN = 64 * PPL;
     extern __shared__ __align__(16) uint32_t lds[];
@@ -227,17 +218,14 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
             for (int y = yb; y < ye; ++y) store4_global(dst + (size_t)y * X + x0, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
         return;
     }
-    uint32_t* head = lds;                             // SPAN words, at LDS address 0 of the wave's allocation: a record's offset is its address
-    uint32_t* idx = lds + SPAN;                       // band_rows + 1 offsets (relative to fa.runs)
-    uint32_t* left = idx + ((band_rows + 1 + 3) & ~3);   // band_rows words
-    uint2* win = reinterpret_cast<uint2*>(left + ((band_rows + 3) & ~3));   // win_cap records
-#if defined(JSP_SP_LAB_TOUCH)
-    const uint32_t touch_sink_off = (uint32_t)((reinterpret_cast<char*>(win + win_cap)) - reinterpret_cast<char*>(lds));   // 64 words nobody reads, behind the window
-#endif
+    uint32_t* head = lds;                             // SPAN words, at LDS address 0 of the wave's allocation: 4 x a record's column is its address
+    uint32_t* idx = lds + SPAN;                       // band_rows + 1 offsets (relative to the frame's records)
+    uint2* left = reinterpret_cast<uint2*>(idx + ((band_rows + 1 + 3) & ~3));   // band_rows pairs {left pixel, kind counts}
+    uint32_t* win = reinterpret_cast<uint32_t*>(left + ((band_rows + 1) & ~1));   // win_cap + 2 records (8-byte aligned)
     const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
-    const uint32_t* gleft = fa.left + (size_t)tile * band_rows;
+    const uint2* gleft = reinterpret_cast<const uint2*>(fa.left) + (size_t)tile * band_rows;
     for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
-    for (int k = lane; k < band_rows; k += 64) left[k] = load1_global(gleft + k);
+    for (int k = lane; k < band_rows; k += 64) left[k] = load2_global(gleft + k);
     *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
     uint32_t p[PPL] = {0, 0, 0, 0};                   // this lane's pixels of the row above
     if (yb > 0 && active) {
@@ -250,7 +238,7 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt/lgkmcnt untouched
     __builtin_amdgcn_wave_barrier();
 
-    const uint2* __restrict__ gruns = reinterpret_cast<const uint2*>(fa.runs);
+    const uint32_t* __restrict__ grecs = reinterpret_cast<const uint32_t*>(fa.runs);   // 4-byte records (sp.h: tile_record32), 8-byte aligned per frame
     constexpr uint32_t OFF = ~kRowRepeats;            // an index entry = record offset | kRowRepeats ("same words as the row above")
     // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the word itself (colour / addend in
     // its low 24 bits), its low 7 bits per byte, and the two masks that pick the pixel's starting value — the pixel to the upper
@@ -259,72 +247,49 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
     const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // the lanes below this one
     // window: rows [y, y + n) whose records fit in win_cap (at most 63 rows: a window's index entries live one per lane).  A
     // single row with more records than that (more than one run every other pixel) is scattered straight from global memory.
-    constexpr int WMAX = 6;                                    // win_cap <= 64 * WMAX (tile_plan)
+    constexpr int WMAX = 5;                                    // win_cap <= 128 * WMAX - 2 (tile_plan): a lane fetches two records per load
     // The window's loads are written as asm and waited for BY COUNT.  A wave's loads and stores share one in-order counter
     // (vmcnt): the compiler, seeing loads whose results are used after a loop of row stores, waits for vmcnt(0) — every window
     // then also waited for the acknowledgement of all its own row stores, 2-3 us a dozen times per tile.  Issued as asm the
     // loads are invisible to that bookkeeping; exactly WMAX load instructions go out per window (lanes past the window's end
-    // re-read its last record) and every row issues exactly one row store, so after R rows `s_waitcnt vmcnt(R)` says precisely
+    // re-read its last pair) and every row issues exactly one row store, so after R rows `s_waitcnt vmcnt(R)` says precisely
     // "the window's records have landed" while the R stores behind them stay in flight.
     unsigned long long wva[WMAX];
     // (Tried and not kept, round 4: touching the window AFTER the next as well — one LDS-DMA load per window into a sink, so that the
     // records are in the caches when the real request comes.  With every window read out of the same 8 KB the launch takes 0.39 - 0.42 ms
     // instead of 0.47 (profiles/r04_sp_tile_parts.txt), but the touch made it 0.49 - 0.51 through the builtin (the compiler then waits for
-    // vmcnt(0) at the next LDS access) and still 0.47 - 0.49 issued as asm behind the window's loads (-DJSP_SP_LAB_TOUCH, profiles/
+    // vmcnt(0) at the next LDS access) and still 0.47 - 0.49 issued as asm behind the window's loads (profiles/
     // r04_sp_tile_touch_ab.txt): what the cached build saves is the requests, not the wait for them.)
-#if defined(JSP_SP_LAB_TOUCH)
-    const uint32_t tile_rec_last = ((uint32_t)__builtin_amdgcn_readfirstlane((int)idx[ye - yb]) & OFF) - 1u;   // the tile's last record (scalar)
-#endif
-    struct Window { uint32_t ve, vl; uint32_t w0; int n, wn; bool direct; };   // ve / vl: lane r = index entry / left pixel of row (first + r)
+    // ve / vl / vk: lane r = index entry / left pixel / kind counts of row (first + r); wb = the window's first record rounded down to an
+    // even one (two-record loads stay 8-byte aligned); wn2 = records from wb to the window's end
+    struct Window { uint32_t ve, vl, vk; uint32_t w0, wb; int n, wn2; bool direct; };
     auto plan_and_fetch = [&](int from) {
         Window w;
         const int k = from + lane;
         w.ve = idx[(k < ye ? k : ye) - yb];
-        w.vl = left[(k < ye ? k : ye - 1) - yb];
+        const uint2 lk = left[(k < ye ? k : ye - 1) - yb];
+        w.vl = lk.x;
+        w.vk = lk.y;
         w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ve) & OFF;
+        w.wb = w.w0 & ~1u;
         const bool fits = lane >= 1 && k <= ye && (int)((w.ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
         const unsigned long long m = __ballot(fits) >> 1;
         int n = __builtin_ctzll(~m);                           // (bit 63 of ~m is always set: at most 63 rows)
         w.direct = n == 0;                                     // the first row alone is too much for the window
         if (n == 0) n = 1;
         w.n = n;
-        w.wn = w.direct ? 0 : (int)(((uint32_t)__builtin_amdgcn_readlane((int)w.ve, n) & OFF) - w.w0);
+        w.wn2 = w.direct ? 0 : (int)(((uint32_t)__builtin_amdgcn_readlane((int)w.ve, n) & OFF) - w.wb);
+        const int npairs = (w.wn2 + 1) >> 1;
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
-            const int kq = lane + 64 * q, kk = kq < w.wn ? kq : (w.wn > 0 ? w.wn - 1 : 0);
-#if defined(JSP_SP_LAB_CACHED_RECORDS)   // lab: every window comes out of the same 8 KB of the frame's records (cache hits: the kernel's reads never reach DRAM); pixels are garbage
-            const uint2* src = gruns + ((w.w0 + kk) & 1023u);
-#else
-            const uint2* src = gruns + w.w0 + kk;              // (always a record of this tile)
-#endif
-#if defined(JSP_SP_LAB_NOFETCH)   // lab (with JSP_SP_LAB_STOREONLY): the row loop without its record fetches — no load at all behind the row stores
-            wva[q] = (unsigned long long)(uintptr_t)src;
-#else
+            const int kq = lane + 64 * q, kk = kq < npairs ? kq : (npairs > 0 ? npairs - 1 : 0);
+            const uint32_t* src = grecs + w.wb + 2 * kk;       // (a pair of this frame's records: its table is padded to an even count)
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wva[q]) : "v"(src) : "memory");
-#endif
         }
-#if defined(JSP_SP_LAB_TOUCH)
-        // lab: the window AFTER this one is touched as well — one LDS-DMA load (no register: a sink in LDS), lane i asking for a word of the
-        // i-th 64-byte line behind this window's records — so that its records are in the caches when they are asked for in earnest.  As asm,
-        // like the window's loads: a load the compiler knows of makes it wait for vmcnt(0) — every row store in flight — at the next LDS access.
-        // One more operation between the window's loads and the row stores: settle_window counts it.
-        {
-            uint32_t rr = ((uint32_t)__builtin_amdgcn_readfirstlane((int)(w.w0 + (uint32_t)w.wn))) + (uint32_t)lane * JSP_SP_LAB_TOUCH;
-            rr = rr < tile_rec_last ? rr : tile_rec_last;
-            const uint2* tp = gruns + rr;
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(tp), "s"(touch_sink_off) : "memory");
-        }
-#endif
         return w;
     };
     // wait until at most `stores_behind` vector-memory operations of this wave are outstanding (the newest ones)
     auto settle_window = [&](int stores_behind) {
-#if defined(JSP_SP_LAB_NOFETCH)
-        return;
-#endif
-#if defined(JSP_SP_LAB_TOUCH)
-        stores_behind += 1;                                    // (the touch behind the window's loads)
-#endif
         switch (stores_behind < 16 ? stores_behind : 16) {     // (more than 16 rows per window: waiting down to 16 is just as exact)
 #define JSP_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
             JSP_VM(0) JSP_VM(1) JSP_VM(2) JSP_VM(3) JSP_VM(4) JSP_VM(5) JSP_VM(6) JSP_VM(7) JSP_VM(8)
@@ -333,6 +298,12 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
         }
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) asm volatile("" : "+v"(wva[q]));   // (the values are defined from here on)
+    };
+    // a record -> the word the row's resolver reads.  The kind is the record's place among the row's records: the first `nc` are
+    // constants, the next up to `nca` start from the pixel above, the rest from the pixel above and to the left (scalar counts)
+    auto scatter = [&](uint32_t rec, int k, uint32_t nc, uint32_t nca) {
+        const uint32_t kind = (uint32_t)k < nc ? kTileHead : ((uint32_t)k < nca ? (kTileHead | kTileAbove) : (kTileHead | kTileAboveLeft));
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + ((rec >> 22) & 0x3FCu)) = (rec & 0x00FFFFFFu) | kind;
     };
     Window nw = plan_and_fetch(yb);
     int rows_since_fetch = 0;                                  // row stores issued after the loads in flight
@@ -344,10 +315,13 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
         // dozen windows.  Now a window costs one wait for the stores behind its loads.
         const Window cw = nw;
         settle_window(rows_since_fetch);
+        {
+            const int npairs = (cw.wn2 + 1) >> 1;
 #pragma unroll
-        for (int q = 0; q < WMAX; ++q) {
-            const int k = lane + 64 * q;
-            if (k < cw.wn) win[k] = make_uint2((uint32_t)wva[q], (uint32_t)(wva[q] >> 32));
+            for (int q = 0; q < WMAX; ++q) {
+                const int k = lane + 64 * q;
+                if (k < npairs) *reinterpret_cast<uint2*>(win + 2 * k) = make_uint2((uint32_t)wva[q], (uint32_t)(wva[q] >> 32));
+            }
         }
         if (y + cw.n < ye) nw = plan_and_fetch(y + cw.n);      // the next window's records start travelling now
         rows_since_fetch = 0;
@@ -355,38 +329,28 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
         uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 1);
         {
             const int nfirst = (int)((e1 & OFF) - cw.w0);
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cw.vk, 0);
+            const uint32_t nc = c0 & 0xFFFFu, nca = nc + (c0 >> 16);
             if (cw.direct) {
-                for (int r = lane; r < nfirst; r += 64) {
-                    const uint2 q = load2_global(gruns + cw.w0 + r);
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(q.x)) = q.y;
-                }
+                for (int r = lane; r < nfirst; r += 64) scatter(load1_global(grecs + cw.w0 + r), r, nc, nca);
                 __builtin_amdgcn_s_waitcnt(0x0F70);            // (its scatter read straight from memory)
             }
             __builtin_amdgcn_wave_barrier();
-            if (!cw.direct)
-                for (int r = lane; r < nfirst; r += 64) {
-                    const uint2 q = win[r];
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(q.x)) = q.y;
-                }
+            if (!cw.direct) {
+                const int at = (int)(cw.w0 - cw.wb);
+                for (int r = lane; r < nfirst; r += 64) scatter(win[at + r], r, nc, nca);
+            }
         }
-#if defined(JSP_SP_LAB_STOREONLY)   // lab: the row stores and nothing else
-        for (int r = 0; r < cw.n; ++r, ++y) {
-#if defined(JSP_SP_LAB_SLEEP)      // lab: the wave sleeps between its row stores for as long as the row's arithmetic takes it in the full kernel (no VALU used)
-            for (int z = 0; z < JSP_SP_LAB_SLEEP; ++z) __builtin_amdgcn_s_sleep(16);
-#endif
-            if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(p[0], p[1], p[2], p[3]));
-            ++rows_since_fetch;
-        }
-        continue;
-#endif
         for (int r = 0; r < cw.n; ++r, ++y) {
             const bool more = r + 1 < cw.n;
             const uint32_t e2 = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2) : e1;   // (r + 2 <= n <= 63)
             const bool repeat = (e0 & kRowRepeats) != 0u;                  // (uniform) no records: the words of the row above stay
             const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw.vl, r);
             const int n_next = (int)((e2 & OFF) - (e1 & OFF));             // records of the next row (0 past the window's last)
-            const int next_at = (int)((e1 & OFF) - cw.w0);
-            uint2 nrec = make_uint2(0, 0);
+            const int next_at = (int)((e1 & OFF) - cw.wb);
+            const uint32_t cn = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.vk, r + 1) : 0u;   // the next row's kind counts
+            const uint32_t nc = cn & 0xFFFFu, nca = nc + (cn >> 16);
+            uint32_t nrec = 0;
             if (lane < n_next) nrec = win[next_at + lane];
             uint32_t u0 = lane_to_the_left(p[PPL - 1]);
             u0 = lane == 0 ? eg : u0;
@@ -420,19 +384,12 @@ __global__ JSP_TILE_BOUNDS void sp_iframe_tile_kernel(const IFrameArgs* __restri
                 const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
                 q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
             }
-#if defined(JSP_SP_LAB_NOSTORE)   // lab: everything but the row store (one that never happens keeps the arithmetic alive)
-            if (active && q[0] == 0xFEEDBEEFu) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));
-#else
             if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));   // (nontemporal: same time, measured)
-#endif
 #pragma unroll
             for (int j = 0; j < PPL; ++j) p[j] = q[j];
             ++rows_since_fetch;                                // (one row store per row, issued by every wave with an active lane)
-            if (lane < n_next) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(nrec.x)) = nrec.y;
-            for (int k = lane + 64; k < n_next; k += 64) {     // rows with more records than lanes
-                const uint2 q2 = win[next_at + k];
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + JSP_TILE_OFF(q2.x)) = q2.y;
-            }
+            if (lane < n_next) scatter(nrec, lane, nc, nca);
+            for (int k = lane + 64; k < n_next; k += 64) scatter(win[next_at + k], k, nc, nca);   // rows with more records than lanes
             __builtin_amdgcn_wave_barrier();
             e0 = e1;
             e1 = e2;
@@ -701,9 +658,6 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 5) s_ready[tid] = 0u;
     __syncthreads();
-#if defined(JSP_SP_LAB_STAGGER)   // lab: workgroups start in eight classes, JSP_SP_LAB_STAGGER x ~0.5 us apart, so that the launch's write fronts stand in different frames
-    for (int i = 0; i < (int)((blockIdx.x + blockIdx.y) & 7u) * JSP_SP_LAB_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
-#endif
     const int by = blockIdx.y;
     const int nb_here = nbx - (int)blockIdx.x * G2_BLOCKS < G2_BLOCKS ? nbx - (int)blockIdx.x * G2_BLOCKS : G2_BLOCKS;
 
@@ -838,227 +792,10 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// Inter-frame groups, third form: SHORT-LIVED workgroups — the time axis is split as well.
-//
-// What bounds the two kernels above is not their arithmetic but how long their workgroups keep storing: the same bytes written
-// with the same 16-byte stores reach 6.9 TB/s when a workgroup stores once and leaves, 6.2 with four visits, 5.8 with sixteen,
-// 5.3 with 256 (tools/sp_store_lab.hip, profiles/r03_sp_store_lab.txt) — and a workgroup of the loader-wave kernel stores for
-// all 299 frames of a clip.  Here the grid is (block group) x (chunk of C frames): a workgroup emits C frames and exits.
-// The pixels it starts from — the state of its 8 blocks after frame f0 - 1 — are found WITHOUT running the earlier frames, by a
-// last-writer look-back over the block records: the host stage links every record to the previous record of the same block
-// that painted anything (PBlock::back, frames back; 0 = none since the group began), so a lane hops from writer to writer, takes
-// from each rectangle the pixels it still misses (a rectangle's literal pixels are its final value for that frame: motion
-// rectangles were literalised) and stops when nothing is missing; what is never painted comes from the frame before the group.
-// The look-back is a pure function of the tables: no workgroup waits for another.
-//   phase A (loads only): the chunk's 8 x C records and their literal pixels straight into LDS (global_load_lds, every request
-//                         out before any is waited for), the look-back chain per lane beside it;
-//   phase B (stores only): C frames from registers + LDS, two 16-byte row stores per lane and frame — the loop holds no load.
-constexpr int G3_BLOCKS = 8;
-constexpr int G3_WG = 256;
-constexpr int G3_CMAX = 16;                    // frames per chunk, at most (8 x 16 records = two per lane of a wave)
-
-template <int C>
-__global__ __launch_bounds__(G3_WG) void sp_pframe_chunk_kernel(const PGroupFrame* __restrict__ frames, int nframes,
-                                                               const uint32_t* __restrict__ prev,
-                                                               const PBlock* __restrict__ blocks,
-                                                               const uint32_t* __restrict__ payload, int X, int Y, int nbx,
-                                                               int lit_words) {
-    static_assert(C >= 1 && C <= G3_CMAX, "chunk length");
-    constexpr int NITEM = C * G3_BLOCKS;                   // (frame, block) records of the chunk, frame-major
-    constexpr int PER_LANE = (NITEM + 63) / 64;            // ... one or two per lane of a wave
-    extern __shared__ __align__(16) uint8_t g3_lds[];
-    PBlock* s_rec = reinterpret_cast<PBlock*>(g3_lds);                                   // [NITEM]
-    uint32_t* s_lit_at = reinterpret_cast<uint32_t*>(g3_lds + sizeof(PBlock) * NITEM);   // [NITEM]
-    uint32_t** s_dst = reinterpret_cast<uint32_t**>(s_lit_at + NITEM);                   // [C]
-    uint32_t* s_lits = reinterpret_cast<uint32_t*>(s_dst + C);                           // [lit_words]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int by = blockIdx.y;
-    const int f0 = (int)blockIdx.z * C;
-    const int nf = nframes - f0 < C ? nframes - f0 : C;
-    const int nb_here = nbx - (int)blockIdx.x * G3_BLOCKS < G3_BLOCKS ? nbx - (int)blockIdx.x * G3_BLOCKS : G3_BLOCKS;
-    const uint32_t block_off0 = frames[0].block_off, nblocks_frame = (uint32_t)nbx * (uint32_t)gridDim.y;
-    // lane = 16-byte chunk of two rows (r and r + 8 of the block row), as in the loader-wave kernel
-    const int r = tid >> 5, ch = tid & 31;
-    const int kb = ch >> 2;
-    const int cx0 = (ch & 3) * 4;
-    const int bx = blockIdx.x * G3_BLOCKS + kb;
-    const int x0 = bx * 16 + cx0;
-    const int ya = by * 16 + r, yb2 = ya + 8;
-    const bool col = bx < nbx && x0 < X;
-    const bool mine_a = col && ya < Y, mine_b = col && yb2 < Y;
-    const size_t ia = (size_t)ya * X + x0, ib = (size_t)yb2 * X + x0;
-
-    // ---- phase A.1: the records — the lane's own block at frame f0 (entry of the look-back) and the chunk's table
-    const PBlock* my_rec0 = blocks + (size_t)block_off0 + (size_t)by * nbx + (col ? bx : 0);   // my block in frame 0 of the group
-    PBlock entry{};
-    if (col) entry = my_rec0[(size_t)f0 * nblocks_frame];
-    if (tid < nf) s_dst[tid] = reinterpret_cast<uint32_t*>(frames[f0 + tid].dst);
-    PBlock item_rec[PER_LANE];
-#pragma unroll
-    for (int h = 0; h < PER_LANE; ++h) {
-        const int item = lane * PER_LANE + h, f = item >> 3, k = item & 7;
-        PBlock pb{};
-        if (item < nf * G3_BLOCKS && k < nb_here)
-            pb = blocks[(size_t)block_off0 + (size_t)(f0 + f) * nblocks_frame + (size_t)by * nbx + blockIdx.x * G3_BLOCKS + k];
-        item_rec[h] = pb;
-    }
-    // ---- phase A.2: where each changed rectangle's literals go (every wave computes the same scan: no hand-over), then the
-    //      literal pixels, rectangle by rectangle, 64 words per LDS-DMA; wave w asks for the rectangles of lanes = w (mod 4)
-    uint32_t need[PER_LANE], from[PER_LANE], sum = 0;
-#pragma unroll
-    for (int h = 0; h < PER_LANE; ++h) {
-        need[h] = from[h] = 0;
-        const PBlock& pb = item_rec[h];
-        if (pb.flags & PB_DATA) {
-            need[h] = (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
-            from[h] = pb.payload;                          // (absolute inside `payload`: see link_group_tables)
-        }
-        sum += need[h];
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += up;
-    }
-    uint32_t at[PER_LANE];
-    at[0] = incl - sum;
-#pragma unroll
-    for (int h = 1; h < PER_LANE; ++h) at[h] = at[h - 1] + need[h - 1];
-    if (wave == 0) {
-#pragma unroll
-        for (int h = 0; h < PER_LANE; ++h) {
-            const int item = lane * PER_LANE + h;
-            if (item < NITEM) { s_rec[item] = item_rec[h]; s_lit_at[item] = at[h]; }
-        }
-    }
-#pragma unroll 1
-    for (int h = 0; h < PER_LANE; ++h) {
-        unsigned long long m = __ballot(need[h] != 0u && at[h] + need[h] <= (uint32_t)lit_words && (lane & 3) == wave);
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)need[h], l);
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)at[h], l);
-            const uint32_t* src = payload + (uint32_t)__builtin_amdgcn_readlane((int)from[h], l);
-            for (uint32_t i = 0; i < n; i += 64)
-                if (i + lane < n) __builtin_amdgcn_global_load_lds((g2_gvoid*)(src + i + lane), (g2_lvoid*)&s_lits[a + i], 4, 0, 0);
-        }
-    }
-
-    // ---- phase A.3: the look-back.  `miss` = the lane's pixels without a value yet (bits 0..3 row a, 4..7 row b)
-    uint32_t pa[4] = {0, 0, 0, 0}, pb4[4] = {0, 0, 0, 0};
-    uint32_t miss = (mine_a ? 0x0Fu : 0u) | (mine_b ? 0xF0u : 0u);
-    {
-        int t = f0;
-        uint32_t back = entry.back;                        // frames back from f0 to the last record that painted this block
-        PBlock w{};
-        bool have = miss != 0u && back != 0u;
-        if (have) { t -= (int)back; w = my_rec0[(size_t)t * nblocks_frame]; }
-        while (__builtin_amdgcn_ballot_w64(have)) {
-            PBlock nxt{};
-            bool more = false;
-            uint32_t take = 0;
-            if (have) {
-                // which of the missing pixels this rectangle supplies
-                const bool cols = cx0 < w.x2 && cx0 + 4 > w.x1;
-                if (cols) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int rx = cx0 + j;
-                        const bool in = rx >= w.x1 && rx < w.x2;
-                        if (in && r >= w.y1 && r < w.y2) take |= 1u << j;
-                        if (in && r + 8 >= w.y1 && r + 8 < w.y2) take |= 16u << j;
-                    }
-                }
-                take &= miss;
-                miss &= ~take;
-                more = miss != 0u && w.back != 0u;
-                if (more) nxt = my_rec0[(size_t)(t - (int)w.back) * nblocks_frame];   // the next hop goes out before this one's pixels
-                if (take) {
-                    const int wd = w.x2 - w.x1;
-                    const uint32_t* lit = payload + w.payload + (cx0 - (int)w.x1);
-                    if (take & 0x0Fu) {
-                        const uint32_t* la = lit + (r - (int)w.y1) * wd;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (take & (1u << j)) pa[j] = load1_global(la + j);
-                    }
-                    if (take & 0xF0u) {
-                        const uint32_t* lb = lit + (r + 8 - (int)w.y1) * wd;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (take & (16u << j)) pb4[j] = load1_global(lb + j);
-                    }
-                }
-                t -= (int)w.back;
-            }
-            w = nxt;
-            have = more;
-        }
-    }
-    // never painted since the group began: the frame before the group
-    if (miss & 0x0Fu) {
-        const uint4 q = *reinterpret_cast<const uint4*>(prev + ia);
-        if (miss & 1u) pa[0] = q.x;
-        if (miss & 2u) pa[1] = q.y;
-        if (miss & 4u) pa[2] = q.z;
-        if (miss & 8u) pa[3] = q.w;
-    }
-    if (miss & 0xF0u) {
-        const uint4 q = *reinterpret_cast<const uint4*>(prev + ib);
-        if (miss & 16u) pb4[0] = q.x;
-        if (miss & 32u) pb4[1] = q.y;
-        if (miss & 64u) pb4[2] = q.z;
-        if (miss & 128u) pb4[3] = q.w;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every load of this workgroup is in before its first store goes out
-    __syncthreads();
-
-    // ---- phase B: C frames, stores only
-    if (col) {
-        for (int f = 0; f < nf; ++f) {
-            const PBlock pb = s_rec[f * G3_BLOCKS + kb];
-            uint32_t* out = s_dst[f];
-            if (pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
-                const int w = pb.x2 - pb.x1;
-                const uint32_t a = s_lit_at[f * G3_BLOCKS + kb];
-                const uint32_t n = (uint32_t)w * (uint32_t)(pb.y2 - pb.y1);
-                if (a + n <= (uint32_t)lit_words) {
-                    const uint32_t* lit0 = s_lits + a - pb.x1;
-                    if (r >= pb.y1 && r < pb.y2) {
-                        const uint32_t* lit = lit0 + (uint32_t)((r - pb.y1) * w);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pa[j] = lit[rx]; }
-                    }
-                    if (r + 8 >= pb.y1 && r + 8 < pb.y2) {
-                        const uint32_t* lit = lit0 + (uint32_t)((r + 8 - pb.y1) * w);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pb4[j] = lit[rx]; }
-                    }
-                } else {
-                    // (cannot happen with the launch's LDS plan — link_group_tables sizes it for the fullest chunk —: kept so that a
-                    // plan that is wrong is slow, not wrong)
-                    const uint32_t* lit0 = payload + pb.payload - pb.x1;
-                    if (r >= pb.y1 && r < pb.y2) {
-                        const uint32_t* lit = lit0 + (uint32_t)((r - pb.y1) * w);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pa[j] = load1_global(lit + rx); }
-                    }
-                    if (r + 8 >= pb.y1 && r + 8 < pb.y2) {
-                        const uint32_t* lit = lit0 + (uint32_t)((r + 8 - pb.y1) * w);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pb4[j] = load1_global(lit + rx); }
-                    }
-                }
-            }
-            if (mine_a) store4_global(out + ia, make_uint4(pa[0], pa[1], pa[2], pa[3]));
-            if (mine_b) store4_global(out + ib, make_uint4(pb4[0], pb4[1], pb4[2], pb4[3]));
-        }
-    }
-}
+// (Round 4 also split the group launch along the TIME axis — sp_pframe_chunk_kernel: a workgroup emits 4 / 8 / 16 frames and exits, its starting
+// pixels found by a last-writer look-back over block records the host stage linked: bit-exact, 0.39 - 0.52 of peak against 0.60,
+// profiles/r04_sp_chunk_ab.txt; round 5's store-shape lab (profiles/r05_front_lab_instep.txt) confirms that fresh workgroups per chunk get
+// what looping ones get from this shape.  Removed in round 5; commit history has kernel, host linking and tests.)
 
 }  // namespace
 
@@ -1118,17 +855,14 @@ TilePlan tile_plan(const Geometry& g, int band_rows) {
     t.rows = rows_in_band(g, band_rows);
     t.span = iframe_tile_span(g);
     t.nspans = (g.X + t.span - 1) / t.span;
-    // per wave: head row + row index + left column + record window; ~4.5 KB keeps 32 waves on a CU
-    const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + (((size_t)t.rows + 3) & ~size_t(3));
+    // per wave: head row + row index + {left pixel, kind counts} per row + record window (4-byte records); ~4.5 KB keeps 32 waves on a CU
+    const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + 2 * (((size_t)t.rows + 1) & ~size_t(1));
     const size_t budget = 4608 / 4;
-    size_t cap = budget > fixed ? (budget - fixed) / 2 : 0;
+    size_t cap = budget > fixed + 2 ? (budget - fixed - 2) & ~size_t(1) : 0;
     if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
-    if (cap > 384) cap = 384;                                  // the kernel fetches a window with at most six loads per lane
+    if (cap > 638) cap = 638;                                  // the kernel fetches a window with five two-record loads per lane (640 records, one may be the pad in front)
     t.win_cap = (int)cap;
-    t.lds = 4 * (fixed + 2 * cap);
-#if defined(JSP_SP_LAB_TOUCH)
-    t.lds += 4 * 64;                                           // (the sink of the lab build's look-ahead touches)
-#endif
+    t.lds = 4 * (fixed + cap + 2);
     return t;
 }
 }  // namespace
@@ -1149,35 +883,6 @@ void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const P
     dim3 grid((g.nbx + 3) / 4, g.nby);
     hipLaunchKernelGGL(sp_pframe_kernel, grid, dim3(PWG), 0, stream, reinterpret_cast<uint32_t*>(dst),
                        reinterpret_cast<const uint32_t*>(prev), d_blocks, d_payload, g.X, g.Y, g.nbx, vec);
-}
-
-size_t pframe_chunk_lds_bytes(int chunk, uint32_t lit_words) {
-    return (size_t)chunk * G3_BLOCKS * (sizeof(PBlock) + 4) + (size_t)chunk * sizeof(void*) + (size_t)lit_words * 4;
-}
-bool pframe_chunks_ok(const Geometry& g, const int32_t* prev, bool aligned16, int chunk, uint32_t lit_words) {
-    return (g.X & 3) == 0 && aligned16 && (reinterpret_cast<uintptr_t>(prev) & 15) == 0 && (chunk == 4 || chunk == 8 || chunk == 16) &&
-           pframe_chunk_lds_bytes(chunk, lit_words) <= 150 * 1024;
-}
-void launch_pframe_chunks(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev, const PBlock* d_blocks,
-                          const uint32_t* d_payload, int chunk, uint32_t lit_words, hipStream_t stream) {
-    if (nframes <= 0) return;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_chunk_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_chunk_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_pframe_chunk_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    // x = block group fastest, then block row, then chunk: the workgroups of a chunk are dispatched together, so the launch's write
-    // fronts stand in the 2 - 3 chunks in flight, not in all frames at once
-    const dim3 grid((g.nbx + G3_BLOCKS - 1) / G3_BLOCKS, g.nby, (nframes + chunk - 1) / chunk);
-    const size_t lds = pframe_chunk_lds_bytes(chunk, lit_words);
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(prev);
-    if (chunk == 4)
-        hipLaunchKernelGGL(sp_pframe_chunk_kernel<4>, grid, dim3(G3_WG), lds, stream, d_frames, nframes, p, d_blocks, d_payload, g.X, g.Y, g.nbx, (int)lit_words);
-    else if (chunk == 8)
-        hipLaunchKernelGGL(sp_pframe_chunk_kernel<8>, grid, dim3(G3_WG), lds, stream, d_frames, nframes, p, d_blocks, d_payload, g.X, g.Y, g.nbx, (int)lit_words);
-    else
-        hipLaunchKernelGGL(sp_pframe_chunk_kernel<16>, grid, dim3(G3_WG), lds, stream, d_frames, nframes, p, d_blocks, d_payload, g.X, g.Y, g.nbx, (int)lit_words);
 }
 
 void launch_pframe_group(const Geometry& g, const PGroupFrame* d_frames, int nframes, const int32_t* prev,

@@ -189,6 +189,18 @@ class StagedWorkload:
         for c in self.codecs:
             c.sync()
 
+    def scrub(self) -> None:
+        """Every destination frame of the batches overwritten with 0xEE bytes (ordered before the next step() on the codecs' stream):
+        what a later step() leaves is then what THAT step wrote, not what an earlier one left behind.  (An inter-mode clip's key
+        frame in `firsts`, which a step only reads, stays.)"""
+        import torch
+        for c in self.codecs:
+            c.sync()
+        for dsts in self.dsts:
+            for d in dsts:
+                d.fill_(-286331154)            # 0xEEEEEEEE
+        torch.cuda.synchronize()
+
     def lookback_fallbacks(self) -> int:
         """Staged MSVideo1 batches that were re-run through the descriptor kernels because a tile of the fused kernel gave up waiting
         (jsp_counter): 0 when the launches named by kernels() are what ran.  ScreenPressor has no such path."""

@@ -87,16 +87,6 @@ void hs_fetch(void* p, uint32_t* runs /*2 per run*/, uint32_t* rows, uint8_t* bl
     if (payload && !o.payload.empty()) std::memcpy(payload, o.payload.data(), o.payload.size() * 4);
 }
 
-// link_group_tables(): the records of a group launch linked for the time-split kernel's look-back.  `blocks` = nframes * nbx * nby
-// records of 16 bytes, frame-major, rewritten in place; `payload_off` = the frames' literal bases (set to 0 on return).
-uint32_t hs_link_group(uint8_t* blocks, uint32_t* payload_off, int nframes, int nbx, int nby, int chunk) {
-    std::vector<PGroupFrame> gf(nframes);
-    for (int f = 0; f < nframes; ++f) gf[f] = PGroupFrame{nullptr, (uint32_t)((size_t)f * nbx * nby), payload_off[f]};
-    const uint32_t fullest = link_group_tables(reinterpret_cast<PBlock*>(blocks), gf.data(), nframes, nbx, nby, chunk);
-    for (int f = 0; f < nframes; ++f) payload_off[f] = gf[f].payload_off;
-    return fullest;
-}
-
 // MSVideo1 host parser (msv1_host.cpp): descriptors + the facts it settles without pixels.
 // out: [early_out, changes, s1, aborted, n_coded, n_skipped, n_untouched, consumed]
 void hs_msv1_parse(int bits, int w, int h, const uint8_t* src, size_t n, int have_prev, int lines, uint32_t* desc,

@@ -183,12 +183,14 @@ def expand_iframe_tiles(desc, X, Y):
     the seed row above its band and its column of left pixels — nothing another tile produced."""
     if desc["kind"] == KIND_FLAT:
         return np.full(X * Y, desc["flat_colour"], dtype=np.uint32)
-    span, runs, idx, left, seeds = desc["span_px"], desc["runs"], desc["tile_idx"], desc["left"], desc["seeds"]
+    span, idx, seeds = desc["span_px"], desc["tile_idx"], desc["seeds"]
+    recs = desc["runs"].reshape(-1)            # tile layout: 4-byte records (sp.h tile_record32) travelling in the run table's memory, padded to an even count
+    left = desc["left"].reshape(-1, 2)         # per tile row: {pixel left of the span one row up, kind counts n_const | n_above << 16}
     rows_per = desc["band_rows"] if 0 < desc["band_rows"] < Y else Y
     nbands, nspans = (Y + rows_per - 1) // rows_per, (X + span - 1) // span
-    assert idx.size == nbands * nspans * (rows_per + 1) and left.size == nbands * nspans * rows_per
+    assert idx.size == nbands * nspans * (rows_per + 1) and left.shape[0] == nbands * nspans * rows_per
     out = np.zeros((Y, X), dtype=np.uint32)
-    covered = np.zeros(len(runs), dtype=bool)
+    covered = np.zeros(len(recs), dtype=bool)
     for b in range(nbands):
         for s in range(nspans):
             t = b * nspans + s
@@ -201,24 +203,30 @@ def expand_iframe_tiles(desc, X, Y):
                 if e >> 31:        # kRowRepeats: no records of its own, the words of the row above stay in force
                     assert r > 0 and lo == hi, (b, s, r)
                 else:
-                    rec = runs[lo:hi]
+                    rec = recs[lo:hi]
                     covered[lo:hi] = True
-                    # tile records (sp.h tile_record): byte offset inside the span's row of words; kTileHead set; ONE predictor bit at most
-                    assert np.all(rec[:, 0] % 4 == 0) and np.all(rec[:, 1] >> 31 == 1) and np.all((rec[:, 1] >> 26) & 31 == 0), (b, s, r)
-                    cols = rec[:, 0].astype(np.int64) // 4
+                    counts = int(left[t * rows_per + r, 1])
+                    nc, na = counts & 0xFFFF, counts >> 16
+                    assert nc + na <= len(rec), (b, s, r)
+                    # a record's kind is its place among the row's records: constants, then "above", then "above-left"
+                    kinds_sorted = np.concatenate([np.full(nc, RUN_CONST), np.full(na, RUN_ABOVE), np.full(len(rec) - nc - na, TILE_ABOVE_LEFT)]).astype(np.uint32)
+                    order = np.argsort(rec >> 24, kind="stable")
+                    cols = (rec >> 24).astype(np.int64)[order]
+                    vals = (rec & 0xFFFFFF)[order]
+                    kinds = kinds_sorted[order]
+                    for part in (slice(0, nc), slice(nc, nc + na), slice(nc + na, len(rec))):   # inside a kind the columns ascend
+                        assert np.all(np.diff((rec[part] >> 24).astype(np.int64)) > 0), (b, s, r)
                 assert len(rec) and cols[0] == 0 and np.all(np.diff(cols) > 0) and cols[-1] < xe - xs, (b, s, r)
                 k = np.searchsorted(cols, np.arange(xe - xs), side="right") - 1
-                w = rec[k, 1]
-                kind, val = (w >> 24) & 3, w & 0xFFFFFF
-                assert np.all(kind != 3)
+                kind, val = kinds[k], vals[k]
                 lft = np.empty(xe - xs, np.uint32)
                 lft[1:] = up[:-1]
-                lft[0] = left[t * rows_per + r]
+                lft[0] = left[t * rows_per + r, 0]
                 v = np.where(kind == RUN_ABOVE, _add_bytes(up, val), val)
                 v = np.where(kind == TILE_ABOVE_LEFT, lft, v).astype(np.uint32)
                 out[y, xs:xe] = v
                 up = v
-    assert covered.all()
+    assert covered[:int(idx[-1]) & 0x7FFFFFFF].all()
     return out.reshape(-1)
 
 

@@ -11,10 +11,20 @@ from jsplayer_amd import _native as N
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "jsplayer_amd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(jsp_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("jsplayer_amd.h", "jsplayer_amd_lab.h")):
+    """Every jsp_* function the headers under include/ declare: the drop-in boundary and the measurement helpers beside it."""
+    syms = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(jsp_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+def test_measurement_helpers_are_not_part_of_the_boundary():
+    boundary = declared_symbols(("jsplayer_amd.h",))
+    assert "jsp_measure_fill" not in boundary and "jsp_measure_h2d" not in boundary
+    assert declared_symbols(("jsplayer_amd_lab.h",)) == ["jsp_measure_fill", "jsp_measure_h2d"]
 
 
 def test_header_declares_the_ivideocodec_surface():

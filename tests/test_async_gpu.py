@@ -158,6 +158,45 @@ def test_msvideo1_async_frames_out_of_prefetched_ranges_match_oracle(bits, size,
         assert seen["prefetched"] == 0, seen                    # (odd geometry: every frame is staged synchronously, from the caller's bytes)
 
 
+def test_a_host_address_prefetched_again_means_the_bytes_that_are_there_now():
+    """A caller's buffer is a ring: the same pinned address is handed to jsp_prefetch again with OTHER bytes in it (the next stretch of the
+    file).  Frames submitted afterwards must decode what is there now — the newest copy of that address — not an older copy still held in
+    the codec's ring of ranges (until round 4 the oldest matching range was taken)."""
+    import torch
+    w, h, n = 320, 240, 6
+    clips = [sg.msv1_clip(200 + k, w, h, n, bits=16, key_every=1) for k in range(3)]
+    size = max(sum(len(f) + 2 for f in c[0]) for c in clips) + 64
+    arena = HostBuffer(size)
+    gpu = MSVideo1_16bit(w, h)
+    gpu.set_option("msv1_parse", "gpu")
+    gpu.Preinit(36)
+    gpu.set_option("async_depth", "4")
+    bufs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(n)]
+    for frames, keys, pal in clips:                              # three passes, three different clips through the SAME host bytes
+        pos, srcs = 0, []
+        for f in frames:
+            arena.array[pos:pos + len(f)] = np.frombuffer(f, dtype=np.uint8)
+            srcs.append(arena.array[pos:pos + len(f)])
+            pos += len(f) + (len(f) & 1)
+        gpu.prefetch(arena.array[:pos])
+        orc = OracleMSVideo1(16, w, h, pal)
+        orc.Preinit(36)
+        tickets = []
+        for i, src in enumerate(srcs):
+            if len(tickets) == 4:
+                gpu.wait(tickets.pop(0))
+            tickets.append(gpu.DecompressI_async(src, bufs[i]))
+        for t in tickets:
+            gpu.wait(t)
+        for i, f in enumerate(frames):
+            want = np.zeros(w * h, dtype=np.int32)
+            assert orc.DecompressI(bytes(f), want) == 0
+            assert np.array_equal(bufs[i].cpu().numpy(), want), f"frame {i}: decoded from a stale copy of the range"
+    assert gpu.counter("prefetched_frames") == 3 * n
+    gpu.StopAndClean()
+    arena.close()
+
+
 @pytest.mark.parametrize("bits,size", [(16, (320, 240)), (8, (320, 240)), (16, (1920, 1080))], ids=["16-320x240", "8-320x240", "16-1080p"])
 @pytest.mark.parametrize("pairs", ["on", "off"])
 def test_msvideo1_async_two_frames_per_launch(bits, size, pairs):

@@ -388,6 +388,34 @@ def test_cpp_player_shards_streams_over_devices(tmp_path):
     line = json.loads(res.stdout.decode().strip().splitlines()[-1])
     assert line["devices"] == [0, 0] and sum(line["per_device_frames"]) == line["frames"] == 2 * (2 * len(single[0]) + 2 * len(single[1]))
     assert line["total_pixels"] == line["frames"] * 320 * 240
+    assert line["async_reruns"] == 0, "a frame the GPU could not settle alone was re-run on the host: see DESIGN.md 3.3"
+    # BASELINE.json configs[4] in one process: eight streams over eight listed devices (here the one device eight times): a host thread, a
+    # codec instance and a pool per stream, stream s -> devices[s mod 8]; every stream shows what a single-device run of its file shows
+    eight = "0,0,0,0,0,0,0,0"
+    res = subprocess.run([exe, ",".join(str(p) for p in paths), "--pipelined", "--depth", "3", "--devices", eight, "--streams", "8"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    assert res.returncode == 0, res.stderr.decode()
+    streams, cur, total = {}, None, None
+    for ln in res.stdout.decode().splitlines():
+        if ln.startswith("# stream"):
+            cur = int(ln.split()[2])
+            streams[cur] = []
+        elif ln.startswith("# total"):
+            total = ln.split()
+        elif ln[:1].isdigit():
+            streams[cur].append(ln)
+    assert sorted(streams) == list(range(8))
+    for s_ in range(8):
+        assert streams[s_] == single[s_ % 2], f"stream {s_}"
+    nframes8 = 4 * len(single[0]) + 4 * len(single[1])
+    assert int(total[3]) == nframes8 and int(total[5]) == nframes8 * 320 * 240
+    res = subprocess.run([exe, ",".join(str(p) for p in paths), "--pipelined", "--quiet", "--devices", eight, "--streams", "8", "--repeat", "3"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    assert res.returncode == 0, res.stderr.decode()
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["devices"] == [0] * 8 and len(line["per_device_frames"]) == 8
+    assert line["per_device_frames"] == [3 * len(single[s_ % 2]) for s_ in range(8)] and sum(line["per_device_frames"]) == line["frames"]
+    assert line["async_reruns"] == 0
     bad = subprocess.run([exe, str(paths[0]), "--pipelined", "--devices", "0,99"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert bad.returncode == 2
     # the collective itself: one rank per distinct device; on this box one device, so a communicator of one rank — the all-reduce runs on the GPU

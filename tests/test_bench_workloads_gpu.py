@@ -38,10 +38,41 @@ def test_staged_workload_matches_oracle_digests(name, kernels):
         work.step()
         work.sync()
         assert work.mismatches(gold) == []
-        # a replay (what the timed steps are) leaves the same frames
+        # a replay (what the timed steps are) writes the same frames: the destinations are overwritten with 0xEE bytes first, so
+        # frames that match afterwards were written by the replay itself
         work.step()
+        work.scrub()
         work.step()
         work.sync()
         assert work.mismatches(gold) == []
+        # ... by the kernels named above: no batch was re-run through the descriptor path behind a look-back time-out
+        assert work.lookback_fallbacks() == 0
+    finally:
+        work.close()
+
+
+# BASELINE.json configs[4] (8 streams, one per GPU): what ranks >= 1 of the driver's N-GPU run decode.  Their clips come from other
+# seeds than rank 0's (workloads._seed), their digests from the oracle (make_bench_digests.py wrote ranks 0 - 7 of the three
+# workloads of the default bench line).  Ranks 1 and 7 whole, rank 4 its first clip
+# (that the eight ranks' streams differ is checked on the CPU: test_bench_digests.py).
+DRIVER_LINE = ["msvideo1_16_1080p_keyframes_m1", "screenpressor_v4_1080p_iframes", "screenpressor_v4_1080p_pclip300"]
+
+
+@pytest.mark.parametrize("rank", [1, 4, 7])
+@pytest.mark.parametrize("name", DRIVER_LINE)
+def test_other_ranks_streams_match_oracle_digests(name, rank):
+    gold = wl.golden_digests(name, rank)
+    assert gold is not None, "run tests/golden/make_bench_digests.py --ranks 8"
+    clips = wl.build_clips(name, rank)
+    if rank not in (1, 7):
+        clips, gold = clips[:1], gold[:1]
+    work = wl.StagedWorkload(name, clips)
+    try:
+        work.step()
+        work.scrub()
+        work.step()
+        work.sync()
+        assert work.mismatches(gold) == []
+        assert work.lookback_fallbacks() == 0
     finally:
         work.close()

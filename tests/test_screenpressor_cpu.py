@@ -116,12 +116,13 @@ def test_key_frame_bands_expand_from_their_seed_rows(band_rows):
 
 
 @pytest.mark.parametrize("size", [(100, 48), (37, 23), (600, 40), (256, 17), (260, 9)], ids=lambda s: f"{s[0]}x{s[1]}")
-@pytest.mark.parametrize("span", [256, 512])
+@pytest.mark.parametrize("span", [128, 256])
 @pytest.mark.parametrize("band_rows", [0, 1, 5, 24])
 def test_key_frame_tiles_stand_alone(size, band_rows, span):
     """Tile layout of key frames (one wave per band x 256-column span on the GPU): every tile is rebuilt from its
-    own records, the seed row above its band and its column of left pixels only, and the mosaic is the oracle's
-    frame.  Widths below, at, just above and well above one span (256 or 512 columns)."""
+    own 4-byte records (column inside the span | value, sorted by kind, two counts per row), the seed row above its band and its
+    column of left pixels only, and the mosaic is the oracle's frame.  Widths below, at, just above and well above one span (128
+    or 256 columns: a record's column has 8 bits)."""
     w, h = size
     chunks, keys, frames = sg.sp_clip(660 + w, w, h, 3, version=4, key_every=1, rects=30, gradients=8)
     host = hs.HostStage(w, h, 24)
@@ -328,100 +329,3 @@ def test_left_of_column_zero_is_the_destinations_old_content(version):
     assert np.array_equal(np.asarray(prev).view(np.uint32).reshape(h, w), three)
 
 
-def test_group_tables_linked_for_the_look_back():
-    """The time-split group kernel (sp_pframe_chunk_kernel) finds the pixels a chunk of frames starts from without running the
-    earlier frames: link_group_tables() links every record to the last record of its block that painted anything, a lane hops
-    back from writer to writer taking the pixels it still misses, and what is never painted comes from the frame before the
-    group.  Modelled here in numpy on random tables and compared, at every chunk start, with painting the frames in order."""
-    import ctypes as C
-    from hoststage_binding import lib, PB_DATA, PB_SUBRECT
-    rng = np.random.default_rng(11)
-    nbx, nby, F = 5, 3, 37
-    X, Y = nbx * 16, nby * 16
-    nblk = nbx * nby
-    rec = np.zeros((F, nblk), dtype=[("flags", "u1"), ("x1", "u1"), ("y1", "u1"), ("x2", "u1"), ("y2", "u1"), ("pad", "u1"), ("back", "<u2"),
-                                     ("mx", "<i2"), ("my", "<i2"), ("payload", "<u4")])
-    assert rec.dtype.itemsize == 16
-    payloads, offs = [], []
-    total = 0
-    for f in range(F):
-        offs.append(total)
-        at = 0
-        for b in range(nblk):
-            u = rng.random()
-            if u < 0.75 or (b == 7):                 # block 7 is never painted: it must come from the frame before the group
-                continue
-            if u < 0.85:
-                x1, y1, x2, y2, fl = 0, 0, 16, 16, PB_DATA
-            else:
-                x1, y1 = int(rng.integers(0, 15)), int(rng.integers(0, 15))
-                x2, y2 = int(rng.integers(x1 + 1, 17)), int(rng.integers(y1 + 1, 17))
-                fl = PB_DATA | PB_SUBRECT
-            rec[f, b] = (fl, x1, y1, x2, y2, 0, 0, 0, 0, at)
-            at += (x2 - x1) * (y2 - y1)
-        payloads.append(rng.integers(0, 1 << 24, size=at, dtype=np.uint32))
-        total += at
-    payload = np.concatenate(payloads)
-    prev = rng.integers(0, 1 << 24, size=(Y, X), dtype=np.uint32)
-    # painting in order: state[f] = the picture after frame f
-    states, cur = [], prev.copy()
-    for f in range(F):
-        for b in range(nblk):
-            r = rec[f, b]
-            if r["flags"]:
-                by, bx = divmod(b, nbx)
-                w, h = int(r["x2"]) - int(r["x1"]), int(r["y2"]) - int(r["y1"])
-                lit = payload[offs[f] + int(r["payload"]):][:w * h].reshape(h, w)
-                cur[by * 16 + r["y1"]:by * 16 + r["y2"], bx * 16 + r["x1"]:bx * 16 + r["x2"]] = lit
-        states.append(cur.copy())
-    linked = rec.copy()
-    po = np.array(offs, dtype=np.uint32)
-    L = lib()
-    L.hs_link_group.restype = C.c_uint32
-    L.hs_link_group.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
-    for chunk in (4, 8, 16):
-        linked = rec.copy()
-        po = np.array(offs, dtype=np.uint32)
-        fullest = L.hs_link_group(linked.ctypes.data, po.ctypes.data, F, nbx, nby, chunk)
-        assert not po.any()
-        # the fullest (8 blocks x chunk frames) cell, by hand
-        want = 0
-        for f0 in range(0, F, chunk):
-            for by in range(nby):
-                for g0 in range(0, nbx, 8):
-                    n = 0
-                    for f in range(f0, min(F, f0 + chunk)):
-                        for bx in range(g0, min(nbx, g0 + 8)):
-                            r = rec[f, by * nbx + bx]
-                            if r["flags"] & PB_DATA:
-                                n += (int(r["x2"]) - int(r["x1"])) * (int(r["y2"]) - int(r["y1"]))
-                    want = max(want, n)
-        assert fullest == want
-        # the look-back, as the kernel's lanes do it
-        for f0 in range(0, F, chunk):
-            got = np.zeros((Y, X), dtype=np.uint32)
-            for b in range(nblk):
-                by, bx = divmod(b, nbx)
-                miss = np.ones((16, 16), dtype=bool)
-                t, back = f0, int(linked[f0, b]["back"])
-                hops = 0
-                while miss.any() and back:
-                    t -= back
-                    r = linked[t, b]
-                    assert r["flags"], "a link must lead to a record that painted"
-                    w, h = int(r["x2"]) - int(r["x1"]), int(r["y2"]) - int(r["y1"])
-                    lit = payload[int(r["payload"]):][:w * h].reshape(h, w)       # absolute now
-                    take = np.zeros((16, 16), dtype=bool)
-                    take[r["y1"]:r["y2"], r["x1"]:r["x2"]] = True
-                    take &= miss
-                    blk = got[by * 16:by * 16 + 16, bx * 16:bx * 16 + 16]
-                    full = np.zeros((16, 16), dtype=np.uint32)
-                    full[r["y1"]:r["y2"], r["x1"]:r["x2"]] = lit
-                    blk[take] = full[take]
-                    miss &= ~take
-                    back = int(r["back"])
-                    hops += 1
-                blk = got[by * 16:by * 16 + 16, bx * 16:bx * 16 + 16]
-                blk[miss] = prev[by * 16:by * 16 + 16, bx * 16:bx * 16 + 16][miss]
-            ref = prev if f0 == 0 else states[f0 - 1]
-            assert np.array_equal(got, ref), f"chunk starting at frame {f0}"

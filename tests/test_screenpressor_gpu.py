@@ -268,25 +268,20 @@ def test_fused_inter_frames(size, version):
     st.close()
 
 
-@pytest.mark.parametrize("chunk", ["4", "8", "16", "0"])
 @pytest.mark.parametrize("size", [(640, 360), (100, 52), (1928, 24)], ids=lambda s: f"{s[0]}x{s[1]}")
-def test_time_split_inter_groups(size, chunk):
-    """Runs of inter frames in one launch whose workgroups each emit `sp_group_chunk` frames and find the pixels they start from
-    by a last-writer look-back over the block records (sp_pframe_chunk_kernel): every frame of a 75-frame clip against the
-    images the encoder was given — full and sub-rectangle repaints, literalised motion, unchanged frames inside the run, the
-    partial last block row and column, a group length that is not a multiple of the chunk, replays.  "0" = the loader-wave
-    kernel on the same tables (they are linked either way).  With a three-buffer rotation the launch must fall back (workgroups
-    of different chunks would race on a shared buffer) and still be right."""
+def test_inter_groups_at_odd_sizes_and_in_a_three_buffer_rotation(size):
+    """Runs of inter frames in one launch (sp_pframe_group_kernel: the workgroups walk the whole group with their pixels in registers):
+    every frame of a 75-frame clip against the images the encoder was given — full and sub-rectangle repaints, literalised motion,
+    unchanged frames inside the run, the partial last block row and column, replays — with a buffer per frame and with three buffers
+    in rotation (what a player has)."""
     w, h = size
     n = 76
     chunks, keys, frames = sg.sp_clip(985, w, h, n, version=4, unchanged_at=(7, 20, 21), p_mix_at={9: dict(unchanged=0.5, motion=0.2), 30: dict(unchanged=0.97, motion=0.01)})
     gpu = ScreenPressor(w, h, 24)
     gpu.Preinit(36)
-    gpu.set_option("sp_group_chunk", chunk)
     dsts = [dev_buf(w * h, -1) for _ in range(n)]
     st = gpu.stage_batch(chunks, dsts, is_key=keys)
-    want = "sp_pframe_chunk_kernel" if chunk != "0" else "sp_pframe_group_kernel"
-    assert want in st.kernels(), st.kernels()
+    assert "sp_pframe_group_kernel" in st.kernels(), st.kernels()
     for _ in range(2):
         st.decode()
     gpu.sync()
@@ -298,17 +293,14 @@ def test_time_split_inter_groups(size, chunk):
     assert not adopted[7] and not adopted[20]
     st.close()
     gpu.StopAndClean()
-    # three buffers in rotation: the time-split launch does not apply
     gpu = ScreenPressor(w, h, 24)
     gpu.Preinit(36)
-    gpu.set_option("sp_group_chunk", chunk)
     pool = [dev_buf(w * h, -1) for _ in range(3)]
     order, k = [], 0
     for i in range(n):
         order.append(pool[k % 3])
         k += 1 if adopted[i] else 0
     st = gpu.stage_batch(chunks, order, is_key=keys)
-    assert "sp_pframe_chunk_kernel" not in st.kernels()
     st.decode()
     gpu.sync()
     for b in pool:

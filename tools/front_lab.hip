@@ -96,6 +96,103 @@ __global__ __launch_bounds__(256) void group_kernel(uint32_t* __restrict__ pool,
     }
 }
 
+
+// round 5: FULL-WIDTH STRIPS.  A workgroup owns R whole rows of the picture (R x 7 680 contiguous bytes; with P > 1 the strip is cut
+// into P pieces of 7 680 / P bytes per row) and writes them into `nframes` consecutive frames: lane = 16-byte column chunk, R row stores per
+// lane and frame (a wave's store instruction = 1 KB of one row, the workgroup's waves side by side in the row).  col_major = 0: all lanes
+// store row 0, then row 1 ...; 1: linear — the strip is one run of R x 480 chunks, chunk = t + k x WG (the same bytes, every store
+// instruction of a wave 1 KB further along the run).
+__global__ void strip_kernel(uint32_t* __restrict__ pool, int nframes, int R, int P, int linear) {
+    const int tid = threadIdx.x, WG = blockDim.x;
+    const int s = (int)blockIdx.x / P, part = (int)blockIdx.x - s * P;
+    const int y0 = s * R;
+    const int rows = y0 + R <= Y ? R : Y - y0;
+    if (rows <= 0) return;
+    const int cpr = (X / 4) / P;                     // chunks per row piece
+    uint32_t a = (uint32_t)(blockIdx.x * 131 + tid);
+    if (linear && P == 1) {
+        const int n = rows * (X / 4);
+        for (int f = 0; f < nframes; ++f) {
+            u32x4* dst = (u32x4*)(pool + (size_t)f * X * Y + (size_t)y0 * X);
+            a = a * 1664525u + 1013904223u;
+            for (int c = tid; c < n; c += WG) *(gu32x4*)(dst + c) = u32x4{a, a + 1, a + 2, (uint32_t)c};
+        }
+        return;
+    }
+    for (int f = 0; f < nframes; ++f) {
+        uint32_t* dst = pool + (size_t)f * X * Y + (size_t)y0 * X + part * cpr * 4;
+        a = a * 1664525u + 1013904223u;
+        for (int c = tid; c < cpr; c += WG)
+            for (int r = 0; r < rows; ++r) *(gu32x4*)(dst + (size_t)r * X + c * 4) = u32x4{a, a + 1, a + 2, (uint32_t)r};
+    }
+}
+
+
+// round 5: is it the UNEQUAL PROGRESS of looping workgroups?  The group shape (8 blocks x 16 rows per workgroup, 299 frames) with all workgroups
+// kept in step — every `sync_every` frames each workgroup arrives on a counter and waits until all have (all are resident: 1 020 x 4 waves) —
+// and the same shape with FRESH workgroups: grid.z = chunks of C frames, a workgroup writes its piece into C frames and leaves.
+__global__ __launch_bounds__(256) void group_sync_kernel(uint32_t* __restrict__ pool, int nframes, int sync_every, unsigned* counter, unsigned base) {
+    const int tid = threadIdx.x;
+    const unsigned nwg = gridDim.x * gridDim.y;
+    uint32_t a = (uint32_t)(blockIdx.x * 131 + blockIdx.y * 7 + tid);
+    const int r = tid >> 5, ch = tid & 31;
+    const int x0 = (int)blockIdx.x * 128 + ch * 4, ya = (int)blockIdx.y * 16 + r, yb = ya + 8;
+    unsigned round = 0;
+    for (int f = 0; f < nframes; ++f) {
+        if (sync_every > 0 && f > 0 && f % sync_every == 0) {
+            ++round;
+            if (tid == 0) {
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; spin < (1 << 20); ++spin) {
+                    if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base >= round * nwg) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (x0 >= X) continue;
+        uint32_t* dst = pool + (size_t)f * X * Y;
+        a = a * 1664525u + 1013904223u;
+        if (ya < Y) *(gu32x4*)(dst + (size_t)ya * X + x0) = u32x4{a, a + 1, a + 2, a + 3};
+        if (yb < Y) *(gu32x4*)(dst + (size_t)yb * X + x0) = u32x4{a, a + 1, a + 2, a + 4};
+    }
+}
+__global__ __launch_bounds__(256) void group_fresh_kernel(uint32_t* __restrict__ pool, int nframes, int C) {
+    const int tid = threadIdx.x;
+    uint32_t a = (uint32_t)(blockIdx.x * 131 + blockIdx.y * 7 + tid);
+    const int r = tid >> 5, ch = tid & 31;
+    const int x0 = (int)blockIdx.x * 128 + ch * 4, ya = (int)blockIdx.y * 16 + r, yb = ya + 8;
+    if (x0 >= X) return;
+    const int f0 = (int)blockIdx.z * C, f1 = f0 + C < nframes ? f0 + C : nframes;
+    for (int f = f0; f < f1; ++f) {
+        uint32_t* dst = pool + (size_t)f * X * Y;
+        a = a * 1664525u + 1013904223u;
+        if (ya < Y) *(gu32x4*)(dst + (size_t)ya * X + x0) = u32x4{a, a + 1, a + 2, a + 3};
+        if (yb < Y) *(gu32x4*)(dst + (size_t)yb * X + x0) = u32x4{a, a + 1, a + 2, a + 4};
+    }
+}
+
+
+// round 5: any piece geometry for a frame-walking workgroup: a workgroup owns PR rows x PB bytes (PB / 16 lanes per row) of the picture and
+// writes it into `nframes` consecutive frames; its 256 lanes take the piece's 16-byte chunks row-major, chunk = tid + k x 256.
+__global__ __launch_bounds__(1024) void piece_kernel(uint32_t* __restrict__ pool, int nframes, int PR, int PB, int pieces_per_row) {
+    const int tid = threadIdx.x, WG = blockDim.x;
+    const int L = PB / 16;
+    const int prow = (int)blockIdx.x / pieces_per_row, pcol = (int)blockIdx.x - prow * pieces_per_row;
+    const int y0 = prow * PR, xb = pcol * PB;
+    uint32_t a = (uint32_t)(blockIdx.x * 131 + tid);
+    const int n = PR * L;
+    for (int f = 0; f < nframes; ++f) {
+        uint8_t* dst = (uint8_t*)(pool + (size_t)f * X * Y);
+        a = a * 1664525u + 1013904223u;
+        for (int c = tid; c < n; c += WG) {
+            const int r = c / L, l = c - r * L;
+            const int y = y0 + r, x = xb + l * 16;
+            if (y < Y && x < X * 4) *(gu32x4*)(dst + (size_t)y * X * 4 + x) = u32x4{a, a + 1, a + 2, (uint32_t)c};
+        }
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -201,6 +298,105 @@ int main(int argc, char** argv) {
                     group_ms[wide] = (float)((double)GF * FRAME_BYTES * 3 / group_ms[wide] / 1e6);
                 }
                 printf("pool %d: group shape (299 frames per workgroup): 8 blocks x 16 rows, 2 x 512 B per wave %5.0f | 16 blocks x 16 rows, 1 KB per wave %5.0f GB/s\n", k, group_ms[0], group_ms[1]);
+                {   // round 5: full-width strips (R rows x 7 680 B contiguous per workgroup and frame), next to the group shapes above
+                    const int GF = F < 299 ? F : 299;
+                    struct Shape { int R, P, WG, linear; };
+                    const Shape shapes[] = {{1, 1, 512, 0}, {2, 1, 512, 0}, {4, 1, 512, 0}, {8, 1, 512, 0}, {16, 1, 512, 0}, {4, 1, 256, 0}, {4, 1, 1024, 1}, {2, 1, 256, 1},
+                                            {4, 2, 256, 0}, {8, 2, 256, 0}, {16, 2, 256, 0}, {16, 4, 128, 0}, {16, 15, 64, 0}};
+                    printf("pool %d: strips (R rows x 7680/P bytes per workgroup, %d frames each; R.P.WG[l = linear run]):", k, GF);
+                    for (const Shape& sh : shapes) {
+                        const int strips = (Y + sh.R - 1) / sh.R;
+                        auto go = [&] { hipLaunchKernelGGL(strip_kernel, dim3(strips * sh.P), dim3(sh.WG), 0, 0, pools[k], GF, sh.R, sh.P, sh.linear); };
+                        go();
+                        CK(hipDeviceSynchronize());
+                        float ms = 0;
+                        CK(hipEventRecord(e0));
+                        for (int i = 0; i < 3; ++i) go();
+                        CK(hipEventRecord(e1));
+                        CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        printf(" %d.%d.%d%s %4.0f |", sh.R, sh.P, sh.WG, sh.linear ? "l" : "", (double)GF * FRAME_BYTES * 3 / ms / 1e6);
+                    }
+                    printf(" GB/s\n");
+                }
+                {   // round 5: the group shape in step / with fresh workgroups
+                    const int GF = F < 299 ? F : 299;
+                    static unsigned* counter = nullptr;
+                    static unsigned base = 0;
+                    if (!counter) { CK(hipMalloc(&counter, 64)); CK(hipMemset(counter, 0, 64)); }
+                    printf("pool %d: group shape kept in step (arrive + wait every n frames): ", k);
+                    for (int se : {0, 1, 4, 16, 64}) {
+                        const int rounds = se ? (GF - 1) / se : 0;
+                        auto go = [&] { hipLaunchKernelGGL(group_sync_kernel, dim3(15, 68), dim3(256), 0, 0, pools[k], GF, se, counter, base); base += (unsigned)rounds * 15u * 68u; };
+                        go();
+                        CK(hipDeviceSynchronize());
+                        float ms = 0;
+                        CK(hipEventRecord(e0));
+                        for (int i = 0; i < 3; ++i) go();
+                        CK(hipEventRecord(e1));
+                        CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        printf(" n=%d %4.0f |", se, (double)GF * FRAME_BYTES * 3 / ms / 1e6);
+                    }
+                    printf(" fresh workgroups per chunk of C frames: ");
+                    for (int C : {1, 2, 4, 16, 64}) {
+                        auto go = [&] { hipLaunchKernelGGL(group_fresh_kernel, dim3(15, 68, (GF + C - 1) / C), dim3(256), 0, 0, pools[k], GF, C); };
+                        go();
+                        CK(hipDeviceSynchronize());
+                        float ms = 0;
+                        CK(hipEventRecord(e0));
+                        for (int i = 0; i < 3; ++i) go();
+                        CK(hipEventRecord(e1));
+                        CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        printf(" C=%d %4.0f |", C, (double)GF * FRAME_BYTES * 3 / ms / 1e6);
+                    }
+                    printf(" GB/s\n");
+                }
+                if (getenv("LAB_PIECES2")) {   // round 5: FEW, FAT frame-walking workgroups (rows x bytes . lanes per workgroup)
+                    const int GF = F < 299 ? F : 299;
+                    struct Sh { int PR, PB, WG; };
+                    const Sh shapes[] = {{16, 512, 256}, {16, 3840, 256}, {16, 3840, 512}, {16, 3840, 1024}, {8, 7680, 256}, {8, 7680, 512}, {8, 7680, 1024}, {16, 7680, 512},
+                                         {16, 7680, 1024}, {32, 3840, 512}, {32, 3840, 1024}, {32, 7680, 1024}, {24, 7680, 1024}, {48, 7680, 1024}, {12, 7680, 512}, {4, 7680, 256}, {4, 7680, 128}, {2, 7680, 64}};
+                    printf("pool %d: few fat walkers (rows x bytes . lanes, workgroups):", k);
+                    for (const Sh& sh : shapes) {
+                        const int ppr = (X * 4 + sh.PB - 1) / sh.PB, prow = (Y + sh.PR - 1) / sh.PR;
+                        auto go = [&] { hipLaunchKernelGGL(piece_kernel, dim3(ppr * prow), dim3(sh.WG), 0, 0, pools[k], GF, sh.PR, sh.PB, ppr); };
+                        go();
+                        CK(hipDeviceSynchronize());
+                        float ms = 0;
+                        CK(hipEventRecord(e0));
+                        for (int i = 0; i < 3; ++i) go();
+                        CK(hipEventRecord(e1));
+                        CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        printf(" %dx%d.%d(%dwg) %4.0f |", sh.PR, sh.PB, sh.WG, ppr * prow, (double)GF * FRAME_BYTES * 3 / ms / 1e6);
+                    }
+                    printf(" GB/s\n");
+                    fflush(stdout);
+                }
+                if (getenv("LAB_PIECES")) {   // round 5: piece geometries for frame-walking workgroups
+                    const int GF = F < 299 ? F : 299;
+                    printf("pool %d: walkers by piece (rows x bytes per workgroup and frame, %d frames):", k, GF);
+                    for (int PB : {512, 1536, 2560, 3840, 7680})
+                        for (int PR : {1, 2, 4, 8, 16, 32}) {
+                            const int L = PB / 16, n = PR * L;
+                            if (n < 128 || n > 256 * 16) continue;
+                            const int ppr = (X * 4 + PB - 1) / PB, prow = (Y + PR - 1) / PR;
+                            auto go = [&] { hipLaunchKernelGGL(piece_kernel, dim3(ppr * prow), dim3(256), 0, 0, pools[k], GF, PR, PB, ppr); };
+                            go();
+                            CK(hipDeviceSynchronize());
+                            float ms = 0;
+                            CK(hipEventRecord(e0));
+                            for (int i = 0; i < 3; ++i) go();
+                            CK(hipEventRecord(e1));
+                            CK(hipEventSynchronize(e1));
+                            CK(hipEventElapsedTime(&ms, e0, e1));
+                            printf(" %dx%d(%dwg) %4.0f |", PR, PB, ppr * prow, (double)GF * FRAME_BYTES * 3 / ms / 1e6);
+                        }
+                    printf(" GB/s\n");
+                    fflush(stdout);
+                }
                 printf("pool %d: plain fill %5.0f | band-walking waves %5.0f | ", k, (double)F * FRAME_BYTES * 3 / fill_ms / 1e6, (double)F * FRAME_BYTES * 3 / band_ms / 1e6);
                 printf("tile-major %5.0f | frame-major %5.0f | staggered %5.0f | scattered %5.0f GB/s\n", (double)F * FRAME_BYTES * 3 / by_order[1] / 1e6,
                        (double)F * FRAME_BYTES * 3 / by_order[0] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[2] / 1e6, (double)F * FRAME_BYTES * 3 / by_order[3] / 1e6);

@@ -3,7 +3,7 @@
 R="${GRAFT_REPO_ROOT:-$(pwd)}"; O="$R/gpurun_out"; export TMPDIR=/tmp
 for k in ${PHASES:-0 1 2 3 4 5 9}; do
   rm -rf /tmp/alt && mkdir /tmp/alt && cp -r $R/jsplayer_amd $R/include $R/bench.py $R/tests $R/oracle $R/profiles $R/__graft_entry__.py /tmp/alt/ 2>/dev/null
-  (cd /tmp/alt/jsplayer_amd/csrc && touch msv1_parse_kernels.hip && make CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -DJSP_FUSED_STOP=$k" > /tmp/alt/make.log 2>&1 || tail -5 /tmp/alt/make.log)
+  (cd /tmp/alt/jsplayer_amd/csrc && touch msv1_parse_kernels.hip && make HOOKS="-I$R/tools/lab/hooks_clocks -DJSP_FUSED_STOP=$k" > /tmp/alt/make.log 2>&1 || tail -5 /tmp/alt/make.log)
   cd /tmp
   rm -rf /tmp/pc
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/pc -- python3 /tmp/alt/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > /dev/null 2> /tmp/pc.err
