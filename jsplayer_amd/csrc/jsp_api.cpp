@@ -299,11 +299,46 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
             p->hold_limit = hold_limit;
             try {
                 JSP_HIP(hipMalloc(reinterpret_cast<void**>(&d_table), sizeof(uint32_t*) * (size_t)nbuf));
-                for (int a = 0; a < kCandidates; ++a) {
+                // the yardstick: what a plain fill takes from this device right now (a slab of its own, given back at once)
+                {
+                    void* slab = nullptr;
+                    const size_t slab_bytes = (size_t)std::min<uint64_t>(one, 2ull << 30);
+                    if (hipMalloc(&slab, slab_bytes) == hipSuccess) {
+                        yardstick = jsp::pool_fill_rate(static_cast<uint32_t*>(slab), slab_bytes);
+                        (void)hipFree(slab);
+                    } else (void)hipGetLastError();
+                }
+                // Round 5 (tools/front_lab.hip, profiles/r05_front_lab_chunks.txt, r05_front_lab_spread.txt): what makes a pool slow is not WHICH memory
+                // its frames lie in but that they lie NEXT TO each other — chunks of 64 frames of slow and of fast pools, put together into one pool,
+                // take 7.1 TB/s whichever chunks they are; separately allocated chunks of 16 frames take 5.6 - 6.0 as neighbours and 7.05 (four times out of
+                // four) when only every fourth of them is used.  So the first candidate is exactly that: four times the chunks the pool needs, every
+                // fourth kept, the others given back at once; the older forms stay behind it, and the measurement decides as before.
+                const int kChunkFrames = 16;
+                int spread = 4;
+                while (spread > 1 && (uint64_t)spread * one > hold_limit) --spread;
+                for (int a = spread > 1 ? -1 : 0; a < kCandidates; ++a) {
                     if (best >= 0 && (uint64_t)(cands.size() + 1) * one > hold_limit) break;   // holding another candidate would pass the limit
                     Candidate c;
                     bool ok = true;
-                    if (a % 3 == 1) {                          // all frames in one allocation, back to back
+                    if (a < 0) {                               // chunks of 16 frames, every `spread`-th of a run of allocations
+                        const int nch = (nbuf + kChunkFrames - 1) / kChunkFrames;
+                        std::vector<void*> all;
+                        for (int q = 0; q < nch * spread && ok; ++q) {
+                            void* d = nullptr;
+                            const int in_chunk = std::min(kChunkFrames, nbuf - (q / spread) * kChunkFrames);
+                            ok = hipMalloc(&d, bytes * (size_t)in_chunk) == hipSuccess;
+                            if (ok) all.push_back(d);
+                        }
+                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)(cands.size() + spread) * one);
+                        for (size_t q = 0; q < all.size(); ++q) {
+                            if (ok && q % (size_t)spread == 0) {
+                                c.allocs.push_back(all[q]);
+                                const int first = (int)(q / (size_t)spread) * kChunkFrames;
+                                for (int i = first; i < std::min(nbuf, first + kChunkFrames); ++i) c.frames.push_back(static_cast<int32_t*>(all[q]) + (size_t)(i - first) * width * height);
+                            } else (void)hipFree(all[q]);
+                        }
+                        if (!ok) { (void)hipGetLastError(); c.allocs.clear(); c.frames.clear(); continue; }   // (not enough room for the run: the older forms)
+                    } else if (a % 3 == 1) {                   // all frames in one allocation, back to back
                         void* d = nullptr;
                         ok = hipMalloc(&d, bytes * (size_t)nbuf) == hipSuccess;
                         if (ok) { c.allocs.push_back(d); for (int i = 0; i < nbuf; ++i) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)i * width * height); }
@@ -328,14 +363,14 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         throw std::runtime_error("out of device memory for the frame pool");
                     }
                     JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
-                    if (a == 1) yardstick = jsp::pool_fill_rate(reinterpret_cast<uint32_t*>(c.allocs[0]), bytes * (size_t)nbuf);
+                    if (a == 1 && yardstick <= 0) yardstick = jsp::pool_fill_rate(reinterpret_cast<uint32_t*>(c.allocs[0]), bytes * (size_t)nbuf);
                     c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
                     p->tried.push_back(c.rate);
-                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", a, a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
+                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", a, a < 0 ? "chunks of 16 frames, every fourth of a run" : a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     cands.push_back(std::move(c));
                     p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)cands.size() * one);
                     if (best < 0 || cands.back().rate > cands[best].rate) best = (int)cands.size() - 1;
-                    if (a >= 1 && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill
+                    if ((a >= 1 || yardstick > 0) && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill
                                                                                    // takes, 6.9 - 7.0 TB/s; the others 5.4 - 6.5; one candidate in
                                                                                    // six is fast in a bad session, the first one in a good one)
                 }

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) u32x4 gu32x4;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -233,6 +234,117 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     };
+    if (argc > 2 && getenv("LAB_SPREAD")) {   // round 5: pools put together from separately allocated chunks of CH frames: neighbours, every g-th, random
+        const int NC = atoi(argv[2]), CH = getenv("LAB_CH") ? atoi(getenv("LAB_CH")) : 64, NCH = F / CH;
+        std::vector<uint32_t*> chunk(NC);
+        for (int c = 0; c < NC; ++c) { CK(hipMalloc(&chunk[c], FRAME_BYTES * CH)); CK(hipMemset(chunk[c], 0, FRAME_BYTES * CH)); }
+        printf("%d chunks of %d frames, first at %p, second at %p, last at %p\n", NC, CH, (void*)chunk[0], (void*)chunk[1], (void*)chunk[NC - 1]);
+        const int T = 8192, tpf = (NBLK + T - 1) / T;
+        auto rate = [&](const std::vector<uint32_t*>& fr) {
+            const int n = (int)fr.size();
+            CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * n, hipMemcpyHostToDevice));
+            auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * n), dim3(256), 0, 0, d_table, n, T, tpf, 1); };
+            launch();
+            CK(hipDeviceSynchronize());
+            float best = 1e9f;
+            for (int rep = 0; rep < 2; ++rep) {
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / 3 < best) best = ms / 3;
+            }
+            return (double)n * FRAME_BYTES / best / 1e6;
+        };
+        auto pool_of = [&](const std::vector<int>& ids) {
+            std::vector<uint32_t*> fr;
+            for (int id : ids) for (int i = 0; i < CH; ++i) fr.push_back(chunk[id] + (size_t)i * X * Y);
+            return fr;
+        };
+        printf("neighbouring chunks [a, a + %d):", NCH);
+        for (int a = 0; a + NCH <= NC; a += NCH) { std::vector<int> ids; for (int q = 0; q < NCH; ++q) ids.push_back(a + q); printf(" %5.0f", rate(pool_of(ids))); }
+        printf(" GB/s\n");
+        const int g = NC / NCH;
+        printf("every %d-th chunk, from a:", g);
+        for (int a = 0; a < g; ++a) { std::vector<int> ids; for (int q = 0; q < NCH; ++q) ids.push_back(a + q * g); printf(" %5.0f", rate(pool_of(ids))); }
+        printf(" GB/s\n");
+        printf("random chunks:");
+        unsigned long long seed = 12345;
+        for (int t = 0; t < g; ++t) {
+            std::vector<int> all(NC), ids;
+            for (int c = 0; c < NC; ++c) all[c] = c;
+            for (int q = 0; q < NCH; ++q) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; const int j = q + (int)((seed >> 33) % (unsigned)(NC - q)); std::swap(all[q], all[j]); ids.push_back(all[q]); }
+            printf(" %5.0f", rate(pool_of(ids)));
+        }
+        printf(" GB/s\n");
+        // frames dealt round-robin over ALL chunks: frame i in chunk i %% NC (each chunk holds only F / NC of the pool's frames)
+        {
+            std::vector<uint32_t*> fr;
+            for (int i = 0; i < F; ++i) fr.push_back(chunk[i % NC] + (size_t)(i / NC) * X * Y);
+            printf("frames dealt round-robin over all %d chunks: %5.0f GB/s\n", NC, rate(fr));
+        }
+        return 0;
+    }
+    if (argc > 2 && getenv("LAB_CHUNKS")) {   // round 5: is a slow pool slow EVERYWHERE?  Chunks of 64 frames probed one by one, then a pool put together from the fastest chunks of all pools
+        const int K = atoi(argv[2]), CH = 64, NCH = F / CH;
+        std::vector<uint32_t*> pools(K);
+        for (int k = 0; k < K; ++k) { CK(hipMalloc(&pools[k], FRAME_BYTES * F)); CK(hipMemset(pools[k], 0, FRAME_BYTES * F)); }
+        const int T = 8192, tpf = (NBLK + T - 1) / T;
+        auto rate = [&](const std::vector<uint32_t*>& fr) {
+            const int n = (int)fr.size();
+            CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * n, hipMemcpyHostToDevice));
+            auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * n), dim3(256), 0, 0, d_table, n, T, tpf, 1); };
+            launch();
+            CK(hipDeviceSynchronize());
+            float best = 1e9f;
+            for (int rep = 0; rep < 2; ++rep) {
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / 3 < best) best = ms / 3;
+            }
+            return (double)n * FRAME_BYTES / best / 1e6;
+        };
+        struct Chunk { double r; int k, c; };
+        std::vector<Chunk> chunks;
+        for (int k = 0; k < K; ++k) {
+            std::vector<uint32_t*> all(F);
+            for (int i = 0; i < F; ++i) all[i] = pools[k] + (size_t)i * X * Y;
+            printf("pool %d: whole (512 fronts) %5.0f | chunks of %d frames:", k, rate(all), CH);
+            for (int c = 0; c < NCH; ++c) {
+                std::vector<uint32_t*> fr(all.begin() + c * CH, all.begin() + (c + 1) * CH);
+                const double r = rate(fr);
+                chunks.push_back({r, k, c});
+                printf(" %5.0f", r);
+            }
+            // interleaved: every 8th frame (64 frames spread over the whole pool)
+            printf(" | every 8th frame:");
+            for (int o = 0; o < 2; ++o) {
+                std::vector<uint32_t*> fr;
+                for (int i = o; i < F; i += 8) fr.push_back(all[i]);
+                printf(" %5.0f", rate(fr));
+            }
+            printf(" GB/s\n");
+            fflush(stdout);
+        }
+        std::sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.r > b.r; });
+        for (int pick = 0; pick < 2; ++pick) {    // the fastest NCH chunks, then the slowest
+            std::vector<uint32_t*> fr;
+            printf("%s %d chunks:", pick ? "slowest" : "fastest", NCH);
+            for (int q = 0; q < NCH; ++q) {
+                const Chunk& ch = pick ? chunks[chunks.size() - 1 - q] : chunks[q];
+                printf(" p%dc%d(%.0f)", ch.k, ch.c, ch.r);
+                for (int i = 0; i < CH; ++i) fr.push_back(pools[ch.k] + (size_t)(ch.c * CH + i) * X * Y);
+            }
+            printf(" -> as one pool of %d fronts: %5.0f GB/s\n", F, rate(fr));
+        }
+        return 0;
+    }
     if (argc > 2) {   // several pools in ONE process, none freed before the last is measured: do they differ?
         const int K = atoi(argv[2]);
         uint32_t* sink;

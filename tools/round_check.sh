@@ -36,6 +36,9 @@ for step in "$@"; do
       timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$W" -o p -- python3 "$R/bench.py" --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-also > "$O/${T}_${W}_bench_under_rocprof.json" 2> "$O/${T}_${W}_rocprof.err" || { tail -20 "$O/${T}_${W}_rocprof.err"; exit 1; }
       find "$O/prof_$W" -name "*kernel_stats.csv" -exec cp {} "$O/${T}_${W}_kernel_stats.csv" \;
       rm -rf "$O/prof_$W"
+      # the same command WITHOUT the profiler, same call: the pair is what profiles/ keeps (tools/profile_pair.py)
+      timeout -k 10 400 python3 "$R/bench.py" --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-also > "$O/${T}_${W}_bench_same_call.json" 2>> "$O/${T}_${W}_rocprof.err" || { tail -20 "$O/${T}_${W}_rocprof.err"; exit 1; }
+      python3 "$R/tools/profile_pair.py" "$O/${T}_${W}_kernel_stats.csv" "$O/${T}_${W}_bench_under_rocprof.json" "$O/${T}_${W}_bench_same_call.json" "$O/${T}_${W}_pair.json" || exit 1
       timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --no-also > /dev/null 2> "$O/${T}_${W}_pmc_f.err" || { tail -20 "$O/${T}_${W}_pmc_f.err"; exit 1; }
       timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w_$W" -- python3 "$R/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --no-also > /dev/null 2> "$O/${T}_${W}_pmc_w.err" || { tail -20 "$O/${T}_${W}_pmc_w.err"; exit 1; }
       cd "$R"
