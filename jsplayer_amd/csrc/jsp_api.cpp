@@ -285,6 +285,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         if (probe) {
             struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; };
             std::vector<Candidate> cands;
+            std::vector<void*> run;                            // the run of chunk allocations behind the first candidates (spread x the pool)
             auto release = [](Candidate& c) { for (void* d : c.allocs) (void)hipFree(d); c.allocs.clear(); };
             uint32_t** d_table = nullptr;
             int best = -1;
@@ -308,37 +309,70 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         (void)hipFree(slab);
                     } else (void)hipGetLastError();
                 }
-                // Round 5 (tools/front_lab.hip, profiles/r05_front_lab_chunks.txt, r05_front_lab_spread.txt): what makes a pool slow is not WHICH memory
-                // its frames lie in but that they lie NEXT TO each other — chunks of 64 frames of slow and of fast pools, put together into one pool,
-                // take 7.1 TB/s whichever chunks they are; separately allocated chunks of 16 frames take 5.6 - 6.0 as neighbours and 7.05 (four times out of
-                // four) when only every fourth of them is used.  So the first candidate is exactly that: four times the chunks the pool needs, every
-                // fourth kept, the others given back at once; the older forms stay behind it, and the measurement decides as before.
+                // Round 5 (tools/front_lab.hip; profiles/r05_front_lab_chunks.txt, r05_front_lab_spread.txt, r05_front_lab_spread_shapes.txt,
+                // r05_front_lab_frame_order.txt).  Two things make a pool slow, and neither is visible to any query:
+                //  (1) frames lying NEXT TO each other.  Chunks of 64 frames of slow and of fast pools, put together into one pool, take 7.1 TB/s
+                //      whichever chunks they are; separately allocated chunks of 16 frames take 5.6 - 6.0 as neighbours and 7.0 when only every
+                //      fourth of them is used.  Kernels whose workgroups WALK the frames (the inter-frame group kernels, the key-frame tile kernel)
+                //      are hit hardest: the same 512 slots of one allocation give their store shapes 5.0 / 5.9 TB/s when frame i lies in slot i and
+                //      6.3 / 6.9 when it lies in slot 17 i mod 512 — consecutive frames must not be neighbours in memory;
+                //  (2) stretches of memory that are slow whatever the arrangement (5.7 against 7.0, the first 4 GB a process gets in one session).
+                // So: four times the chunks the pool needs, allocated in one run; candidate k = every fourth chunk starting with the k-th, its frames
+                // DEALT round-robin over the chunks (frame i and frame i + 1 in different chunks, >= 0.5 GB apart); the first candidate that takes what
+                // a plain fill takes is kept, the other chunks are given back.  Only when none of the four comes near do the older forms get a try.
                 const int kChunkFrames = 16;
                 int spread = 4;
                 while (spread > 1 && (uint64_t)spread * one > hold_limit) --spread;
-                for (int a = spread > 1 ? -1 : 0; a < kCandidates; ++a) {
+                const int nch = (nbuf + kChunkFrames - 1) / kChunkFrames;
+                auto chunk_frames = [&](int ch) { return std::min(kChunkFrames, nbuf - ch * kChunkFrames); };
+                if (spread > 1) {
+                    bool ok = true;
+                    for (int q = 0; q < nch * spread && ok; ++q) {
+                        void* d = nullptr;
+                        ok = hipMalloc(&d, bytes * (size_t)chunk_frames(q / spread)) == hipSuccess;   // chunks q = ch * spread + k: the k-th candidate's ch-th chunk
+                        if (ok) run.push_back(d);
+                    }
+                    if (!ok) { (void)hipGetLastError(); for (void* d : run) (void)hipFree(d); run.clear(); }
+                    else p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)spread * one);
+                }
+                int spread_best = -1;
+                double spread_rate = 0;
+                std::vector<int32_t*> dealt;
+                auto deal = [&](int k) {                       // candidate k's frames, dealt round-robin over its chunks
+                    dealt.clear();
+                    for (int slot = 0; slot < kChunkFrames; ++slot)
+                        for (int ch = 0; ch < nch; ++ch)
+                            if (slot < chunk_frames(ch)) dealt.push_back(static_cast<int32_t*>(run[(size_t)ch * spread + k]) + (size_t)slot * width * height);
+                };
+                for (int k = 0; k < spread && k < kCandidates && !run.empty(); ++k) {
+                    deal(k);
+                    JSP_HIP(hipMemcpy(d_table, dealt.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
+                    const double rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
+                    p->tried.push_back(rate);
+                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (chunks of 16 frames, every %d-th of a run from the %d-th, frames dealt over them): %.0f GB/s (plain fill %.0f)\n", k, spread, k, rate, yardstick);
+                    if (rate > spread_rate) { spread_rate = rate; spread_best = k; }
+                    if (yardstick > 0 && rate >= 0.985 * yardstick) break;
+                }
+                if (spread_best >= 0) {                        // keep the best of them as a candidate like any other, give the other chunks back
+                    Candidate c;
+                    deal(spread_best);
+                    c.frames = dealt;
+                    for (size_t q = 0; q < run.size(); ++q) {
+                        if ((int)(q % (size_t)spread) == spread_best) c.allocs.push_back(run[q]);
+                        else (void)hipFree(run[q]);
+                    }
+                    run.clear();
+                    c.rate = spread_rate;
+                    cands.push_back(std::move(c));
+                    best = 0;
+                }
+                const int tried_spread = (int)p->tried.size();
+                const bool spread_good = best == 0 && (yardstick <= 0 || cands[0].rate >= 0.95 * yardstick);
+                for (int a = 0; a < kCandidates - tried_spread && !spread_good; ++a) {
                     if (best >= 0 && (uint64_t)(cands.size() + 1) * one > hold_limit) break;   // holding another candidate would pass the limit
                     Candidate c;
                     bool ok = true;
-                    if (a < 0) {                               // chunks of 16 frames, every `spread`-th of a run of allocations
-                        const int nch = (nbuf + kChunkFrames - 1) / kChunkFrames;
-                        std::vector<void*> all;
-                        for (int q = 0; q < nch * spread && ok; ++q) {
-                            void* d = nullptr;
-                            const int in_chunk = std::min(kChunkFrames, nbuf - (q / spread) * kChunkFrames);
-                            ok = hipMalloc(&d, bytes * (size_t)in_chunk) == hipSuccess;
-                            if (ok) all.push_back(d);
-                        }
-                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)(cands.size() + spread) * one);
-                        for (size_t q = 0; q < all.size(); ++q) {
-                            if (ok && q % (size_t)spread == 0) {
-                                c.allocs.push_back(all[q]);
-                                const int first = (int)(q / (size_t)spread) * kChunkFrames;
-                                for (int i = first; i < std::min(nbuf, first + kChunkFrames); ++i) c.frames.push_back(static_cast<int32_t*>(all[q]) + (size_t)(i - first) * width * height);
-                            } else (void)hipFree(all[q]);
-                        }
-                        if (!ok) { (void)hipGetLastError(); c.allocs.clear(); c.frames.clear(); continue; }   // (not enough room for the run: the older forms)
-                    } else if (a % 3 == 1) {                   // all frames in one allocation, back to back
+                    if (a % 3 == 1) {                          // all frames in one allocation, back to back
                         void* d = nullptr;
                         ok = hipMalloc(&d, bytes * (size_t)nbuf) == hipSuccess;
                         if (ok) { c.allocs.push_back(d); for (int i = 0; i < nbuf; ++i) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)i * width * height); }
@@ -366,7 +400,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (a == 1 && yardstick <= 0) yardstick = jsp::pool_fill_rate(reinterpret_cast<uint32_t*>(c.allocs[0]), bytes * (size_t)nbuf);
                     c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
                     p->tried.push_back(c.rate);
-                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", a, a < 0 ? "chunks of 16 frames, every fourth of a run" : a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
+                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", tried_spread + a, a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     cands.push_back(std::move(c));
                     p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)cands.size() * one);
                     if (best < 0 || cands.back().rate > cands[best].rate) best = (int)cands.size() - 1;
@@ -376,12 +410,13 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                 }
             } catch (...) {
                 for (auto& c : cands) release(c);
+                for (void* d : run) (void)hipFree(d);
                 if (d_table) (void)hipFree(d_table);
                 throw;
             }
             (void)hipFree(d_table);
             for (int i = 0; i < (int)cands.size(); ++i) if (i != best) release(cands[i]);
-            p->attempts = (int)cands.size();
+            p->attempts = (int)p->tried.size();
             p->store_rate = cands[best].rate;
             p->fill_rate = yardstick;
             p->allocs = cands[best].allocs;

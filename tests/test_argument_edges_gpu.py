@@ -53,7 +53,7 @@ def test_degenerate_but_legal_inputs():
 @pytest.mark.parametrize("count,size", [(3, (320, 240)), (40, (320, 240)), (33, (322, 242))], ids=["small", "placed", "large-odd-size"])
 def test_frame_pool_buffers_are_usable_whichever_way_they_were_placed(count, size):
     """jsp_pool_create: a small pool is one allocation per frame; a pool of 32 frames or more whose size the probe's store shape
-    fits is placed by measuring candidate allocations.  Either way every buffer is zeroed, distinct, 16-byte aligned and decodes
+    fits is placed by measuring candidate allocations (first: chunks of 16 frames, every fourth of a run of allocations).  Either way every buffer is zeroed, distinct, 16-byte aligned and decodes
     exactly as a torch tensor does."""
     import torch
     from jsplayer_amd import FramePool
@@ -62,7 +62,7 @@ def test_frame_pool_buffers_are_usable_whichever_way_they_were_placed(count, siz
     pool = FramePool(w, h, count)
     try:
         placed = count >= 32 and w % 4 == 0 and h % 4 == 0
-        assert (pool.attempts >= 2 and pool.store_rate > 0) if placed else (pool.attempts == 0 and pool.store_rate == 0)
+        assert (pool.attempts >= 1 and pool.store_rate > 0) if placed else (pool.attempts == 0 and pool.store_rate == 0)
         assert pool.attempts <= 16
         ptrs = [f.data_ptr() for f in pool.frames]
         assert len(set(ptrs)) == count and all(p % 16 == 0 for p in ptrs)
@@ -126,7 +126,7 @@ def test_measure_h2d_and_the_bounded_pool_probe(monkeypatch):
     pool = FramePool(1920, 1080, 32)
     try:
         assert 1 <= pool.attempts <= 2 and pool.store_rate > 100.0
-        assert pool.probe_ms > 0 and 32 * 1920 * 1080 * 4 <= pool.held_bytes <= 2 * 32 * 1920 * 1080 * 4 and pool.held_bytes <= pool.hold_limit
+        assert pool.probe_ms > 0 and 32 * 1920 * 1080 * 4 <= pool.held_bytes <= 4 * 32 * 1920 * 1080 * 4 and pool.held_bytes <= pool.hold_limit   # (the first candidate: four times the pool's chunks, every fourth kept)
     finally:
         pool.close()
     monkeypatch.setenv("JSP_POOL_PROBE_HOLD_GB", "0.1")          # less than one candidate: the pool itself is still allowed, nothing beside it

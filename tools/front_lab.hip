@@ -194,6 +194,35 @@ __global__ __launch_bounds__(1024) void piece_kernel(uint32_t* __restrict__ pool
     }
 }
 
+
+// table-based forms of the band-walking and frame-walking shapes (frames anywhere): LAB_SPREAD
+__global__ __launch_bounds__(64) void band_table_kernel(uint32_t* const* __restrict__ frames, int nframes, int B, int bands, int D) {
+    const int f = blockIdx.x % nframes, g = blockIdx.x / nframes;
+    const int band = g / 8, sx = g - band * 8;
+    const int x = sx * 256 + (int)threadIdx.x * 4;
+    if (x >= X) return;
+    uint32_t* dst = frames[f];
+    uint32_t a = (uint32_t)(f + g);
+    const int y1 = (band + 1) * B < Y ? (band + 1) * B : Y;
+    for (int y = band * B; y < y1; ++y) {
+        for (int i = 0; i < D; ++i) a = a * 1664525u + 1013904223u;
+        *(gu32x4*)(dst + (size_t)y * X + x) = u32x4{a, a + 1, a + 2, a + 3};
+    }
+}
+__global__ __launch_bounds__(256) void group_table_kernel(uint32_t* const* __restrict__ frames, int nframes) {
+    const int tid = threadIdx.x;
+    uint32_t a = (uint32_t)(blockIdx.x * 131 + blockIdx.y * 7 + tid);
+    const int r = tid >> 5, ch = tid & 31;
+    const int x0 = (int)blockIdx.x * 128 + ch * 4, ya = (int)blockIdx.y * 16 + r, yb = ya + 8;
+    if (x0 >= X) return;
+    for (int f = 0; f < nframes; ++f) {
+        uint32_t* dst = frames[f];
+        a = a * 1664525u + 1013904223u;
+        if (ya < Y) *(gu32x4*)(dst + (size_t)ya * X + x0) = u32x4{a, a + 1, a + 2, a + 3};
+        if (yb < Y) *(gu32x4*)(dst + (size_t)yb * X + x0) = u32x4{a, a + 1, a + 2, a + 4};
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -258,17 +287,61 @@ int main(int argc, char** argv) {
             }
             return (double)n * FRAME_BYTES / best / 1e6;
         };
+        auto timed = [&](auto&& launch, double bytes) {
+            launch();
+            CK(hipDeviceSynchronize());
+            float best = 1e9f;
+            for (int rep = 0; rep < 2; ++rep) {
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / 3 < best) best = ms / 3;
+            }
+            return bytes / best / 1e6;
+        };
+        auto shapes = [&](const std::vector<uint32_t*>& fr) {   // "fronts / band-walkers (256 frames) / frame-walkers (299 frames)"
+            static char buf[96];
+            const double a = rate(fr);
+            CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * fr.size(), hipMemcpyHostToDevice));
+            const int nb = 256 < (int)fr.size() ? 256 : (int)fr.size(), ng = 299 < (int)fr.size() ? 299 : (int)fr.size();
+            const double b = timed([&] { hipLaunchKernelGGL(band_table_kernel, dim3((unsigned)(nb * 12 * 8)), dim3(64), 4608, 0, d_table, nb, 90, 12, 20); }, (double)nb * FRAME_BYTES);
+            const double c = timed([&] { hipLaunchKernelGGL(group_table_kernel, dim3(15, 68), dim3(256), 0, 0, d_table, ng); }, (double)ng * FRAME_BYTES);
+            std::snprintf(buf, sizeof buf, " %4.0f/%4.0f/%4.0f", a, b, c);
+            return buf;
+        };
         auto pool_of = [&](const std::vector<int>& ids) {
             std::vector<uint32_t*> fr;
             for (int id : ids) for (int i = 0; i < CH; ++i) fr.push_back(chunk[id] + (size_t)i * X * Y);
             return fr;
         };
+        printf("(fronts / band-walkers / frame-walkers, GB/s)\n");
+        if (getenv("LAB_PERM")) {   // ONE allocation per pool, frames back to back, but taken in another ORDER: frame i lies in slot (i x K) mod F
+            const int P = 3;
+            for (int k = 0; k < P; ++k) {
+                uint32_t* pool;
+                CK(hipMalloc(&pool, FRAME_BYTES * F));
+                CK(hipMemset(pool, 0, FRAME_BYTES * F));
+                printf("one allocation %d, frame i in slot (i x K) mod %d:", k, F);
+                for (int K : {1, 3, 7, 17, 37, 65, 101, 171, 255}) {
+                    std::vector<uint32_t*> fr(F);
+                    for (int i = 0; i < F; ++i) fr[i] = pool + (size_t)((i * K) % F) * X * Y;
+                    printf(" K=%d%s |", K, shapes(fr));
+                }
+                printf(" GB/s\n");
+                fflush(stdout);
+                // (kept allocated: the next pool lies elsewhere)
+            }
+            return 0;
+        }
         printf("neighbouring chunks [a, a + %d):", NCH);
-        for (int a = 0; a + NCH <= NC; a += NCH) { std::vector<int> ids; for (int q = 0; q < NCH; ++q) ids.push_back(a + q); printf(" %5.0f", rate(pool_of(ids))); }
+        for (int a = 0; a + NCH <= NC; a += NCH) { std::vector<int> ids; for (int q = 0; q < NCH; ++q) ids.push_back(a + q); printf("%s", shapes(pool_of(ids))); }
         printf(" GB/s\n");
         const int g = NC / NCH;
         printf("every %d-th chunk, from a:", g);
-        for (int a = 0; a < g; ++a) { std::vector<int> ids; for (int q = 0; q < NCH; ++q) ids.push_back(a + q * g); printf(" %5.0f", rate(pool_of(ids))); }
+        for (int a = 0; a < g; ++a) { std::vector<int> ids; for (int q = 0; q < NCH; ++q) ids.push_back(a + q * g); printf("%s", shapes(pool_of(ids))); }
         printf(" GB/s\n");
         printf("random chunks:");
         unsigned long long seed = 12345;
@@ -276,14 +349,14 @@ int main(int argc, char** argv) {
             std::vector<int> all(NC), ids;
             for (int c = 0; c < NC; ++c) all[c] = c;
             for (int q = 0; q < NCH; ++q) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; const int j = q + (int)((seed >> 33) % (unsigned)(NC - q)); std::swap(all[q], all[j]); ids.push_back(all[q]); }
-            printf(" %5.0f", rate(pool_of(ids)));
+            printf("%s", shapes(pool_of(ids)));
         }
         printf(" GB/s\n");
         // frames dealt round-robin over ALL chunks: frame i in chunk i %% NC (each chunk holds only F / NC of the pool's frames)
         {
             std::vector<uint32_t*> fr;
             for (int i = 0; i < F; ++i) fr.push_back(chunk[i % NC] + (size_t)(i / NC) * X * Y);
-            printf("frames dealt round-robin over all %d chunks: %5.0f GB/s\n", NC, rate(fr));
+            printf("frames dealt round-robin over all %d chunks: %s GB/s\n", NC, shapes(fr));
         }
         return 0;
     }

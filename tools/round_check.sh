@@ -11,7 +11,7 @@ cd "$R"
 for step in "$@"; do
   case "$step" in
     tests)
-      timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$O/${T}_gpu_tests.log" 2>&1 || { tail -30 "$O/${T}_gpu_tests.log"; exit 1; }
+      timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=12 > "$O/${T}_gpu_tests.log" 2>&1 || { tail -30 "$O/${T}_gpu_tests.log"; exit 1; }
       tail -2 "$O/${T}_gpu_tests.log" ;;
     newtests)
       timeout -k 10 900 python -m pytest tests/test_bench_workloads_gpu.py -m gpu -x -q > "$O/${T}_gpu_newtests.log" 2>&1 || { tail -30 "$O/${T}_gpu_newtests.log"; exit 1; }
