@@ -579,6 +579,7 @@ struct SpCodec : jsp_codec, DstColumns {
                     }
                     blocks.insert(blocks.end(), fo.blocks.begin(), fo.blocks.end());
                     payload.insert(payload.end(), fo.payload.begin(), fo.payload.end());
+                    payload.resize((payload.size() + 3) & ~size_t(3), 0u);   // every frame's literals start on a 16-byte boundary of the batch's table (so does every rectangle inside it)
                     st->info.units_coded += fo.data_pixels;
                     st->info.units_copied += fo.prev_pixels;
                     // A = 4P written + 4 P_prev fetched + 16 N_blk + literal payload of the data rectangles

@@ -471,6 +471,7 @@ void HostDecoder::decode_p(const uint8_t* src, size_t n, FrameOut& out) {
                         cx_ = clr >> shiftc;
                     }
                     pb.flags |= PB_DATA;
+                    out.payload.resize((out.payload.size() + 3) & ~size_t(3), 0u);   // a rectangle's literals start on a 16-byte boundary (the group kernel's loader fetches 16 bytes per lane)
                     pb.payload = (uint32_t)out.payload.size();
                     for (int yy = y1; yy < y2; ++yy)
                         for (int xx = x1; xx < x2; ++xx) out.payload.push_back((uint32_t)dst[(long)yy * X + xx]);
@@ -516,6 +517,7 @@ void HostDecoder::literalise_motion(FrameOut& out) const {
             if (!(pb.flags & PB_MOTION)) continue;
             pb.flags = (uint8_t)((pb.flags & ~PB_MOTION) | PB_DATA);
             pb.mx = pb.my = 0;
+            out.payload.resize((out.payload.size() + 3) & ~size_t(3), 0u);   // (16-byte boundary, as for the coded rectangles)
             pb.payload = (uint32_t)out.payload.size();
             for (int y = by * 16 + pb.y1; y < by * 16 + pb.y2; ++y)
                 for (int x = bx * 16 + pb.x1; x < bx * 16 + pb.x2; ++x) out.payload.push_back((uint32_t)pic[(long)y * X + x]);

@@ -17,6 +17,7 @@
 //                                four worker waves and a loader wave that brings 16 frames' block records and literals
 //                                into LDS at a time (X % 4 == 0, aligned buffers);
 //   sp_pframe_group1_kernel      the same for any width / alignment: the workgroup stages its own chunks.
+#include <cstddef>
 #include <cstdlib>
 #include <mutex>
 
@@ -639,7 +640,9 @@ struct G2Chunk {
     uint32_t lit_at[G2_CF * G2_BLOCKS];       // where in `lits` the rectangle of (frame, block) starts
     uint32_t lits[G2_LW];
     int nf, next;
+    int pad[2];                               // (sizeof a multiple of 16: the second chunk's tables stay 16-byte aligned for the LDS-DMAs)
 };
+static_assert(sizeof(G2Chunk) % 16 == 0 && offsetof(G2Chunk, lits) % 16 == 0, "G2Chunk tables are 16-byte aligned");
 static_assert(sizeof(PGroupFrame) == 16, "one LDS-DMA lane per frame record");
 
 typedef __attribute__((address_space(1))) const void g2_gvoid;
@@ -694,7 +697,9 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
                 if (item < nf_try * G2_BLOCKS && (item & 7) < nb_here) {
                     const PBlock pb = ck.pb[item];
                     if (pb.flags & PB_DATA) {
-                        need[h] = (uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1);
+                        // (rounded up to 16 bytes: the host stage starts every rectangle's literals on a 16-byte boundary of the table — so does
+                        // its place in `lits` — and the fetch below moves 16 bytes per lane; what it reads past a rectangle's end is table too)
+                        need[h] = ((uint32_t)(pb.x2 - pb.x1) * (uint32_t)(pb.y2 - pb.y1) + 3u) & ~3u;
                         from[h] = ck.gf[item >> 3].payload_off + pb.payload;
                     }
                 }
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
             const bool over = (lane & 3) == 3 && lane * 2 + 1 < nf_try * G2_BLOCKS && incl > (uint32_t)G2_LW && lane >= 4;
             const unsigned long long om = __ballot(over);
             const int nf = om ? (__ffsll((long long)om) - 1) >> 2 : nf_try;
-            // 3. the literals: rectangle by rectangle, 64 words per LDS-DMA, every request out before any is waited for
+            // 3. the literals: rectangle by rectangle, 256 words per LDS-DMA, every request out before any is waited for
             unsigned long long want = __ballot(need[0] != 0u && lane * 2 < nf * G2_BLOCKS) ;
             unsigned long long want1 = __ballot(need[1] != 0u && lane * 2 + 1 < nf * G2_BLOCKS);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -727,8 +732,8 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
                     // (everything the loop needs comes out of registers: an LDS read here would be made to wait for the LDS-DMAs
                     // already in flight, one round trip per rectangle)
                     const uint32_t* src = payload + (uint32_t)__builtin_amdgcn_readlane((int)from[h], l);
-                    for (uint32_t i = 0; i < n; i += 64)
-                        if (i + lane < n) __builtin_amdgcn_global_load_lds((g2_gvoid*)(src + i + lane), (g2_lvoid*)&ck.lits[at + i], 4, 0, 0);
+                    for (uint32_t i = 0; i < n; i += 256)          // 1 KB per instruction (4-byte lanes until round 5: four times the requests for the same bytes)
+                        if (i + lane * 4 < n) __builtin_amdgcn_global_load_lds((g2_gvoid*)(src + i + lane * 4), (g2_lvoid*)&ck.lits[at + i], 16, 0, 0);
                 }
             }
             if (lane == 0) { ck.nf = nf; ck.next = f0 + nf; }
@@ -764,9 +769,18 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
         const G2Chunk& ck = chunks[c & 1];
         const int nf = ck.nf, next = ck.next;
         if (col) {
+            // (software-pipelined: frame f + 1's record and destination are asked for — LDS — before frame f's rows go out, so a frame's stores are
+            // never held back by the LDS round trip of its own record)
+            PBlock pb_next = ck.pb[kb];
+            uint32_t* out_next = reinterpret_cast<uint32_t*>(ck.gf[0].dst);
             for (int f = 0; f < nf; ++f) {
-                const PBlock pb = ck.pb[f * G2_BLOCKS + kb];
-                uint32_t* out = reinterpret_cast<uint32_t*>(ck.gf[f].dst);
+                const PBlock pb = pb_next;
+                uint32_t* out = out_next;
+                {
+                    const int fn = f + 1 < nf ? f + 1 : f;
+                    pb_next = ck.pb[fn * G2_BLOCKS + kb];
+                    out_next = reinterpret_cast<uint32_t*>(ck.gf[fn].dst);
+                }
                 if (pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
                     const int w = pb.x2 - pb.x1;
                     const uint32_t* lit0 = ck.lits + ck.lit_at[f * G2_BLOCKS + kb] - pb.x1;
