@@ -769,18 +769,11 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
         const G2Chunk& ck = chunks[c & 1];
         const int nf = ck.nf, next = ck.next;
         if (col) {
-            // (software-pipelined: frame f + 1's record and destination are asked for — LDS — before frame f's rows go out, so a frame's stores are
-            // never held back by the LDS round trip of its own record)
-            PBlock pb_next = ck.pb[kb];
-            uint32_t* out_next = reinterpret_cast<uint32_t*>(ck.gf[0].dst);
+            // (Asking for frame f + 1's record and destination before frame f's rows go out — the loop software-pipelined — changes nothing:
+            // 0.950 against 0.956 ms per 598 frames, profiles/r05_sp_group_pipelined_ab.txt; the simple loop stays.)
             for (int f = 0; f < nf; ++f) {
-                const PBlock pb = pb_next;
-                uint32_t* out = out_next;
-                {
-                    const int fn = f + 1 < nf ? f + 1 : f;
-                    pb_next = ck.pb[fn * G2_BLOCKS + kb];
-                    out_next = reinterpret_cast<uint32_t*>(ck.gf[fn].dst);
-                }
+                const PBlock pb = ck.pb[f * G2_BLOCKS + kb];
+                uint32_t* out = reinterpret_cast<uint32_t*>(ck.gf[f].dst);
                 if (pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
                     const int w = pb.x2 - pb.x1;
                     const uint32_t* lit0 = ck.lits + ck.lit_at[f * G2_BLOCKS + kb] - pb.x1;
