@@ -1,5 +1,6 @@
 // extern "C" surface of libjsplayer_amd.so (declared in include/jsplayer_amd.h).
 #include <algorithm>
+#include <numeric>
 #include <chrono>
 #include <cstdlib>
 #include <mutex>
@@ -396,6 +397,16 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         if (best >= 0) break;
                         throw std::runtime_error("out of device memory for the frame pool");
                     }
+                    {   // consecutive frames must not be neighbours in memory (see above): frame i takes slot (i x K) mod n, K coprime to n
+                        int K = 1;
+                        for (int cand : {17, 19, 23, 29, 31, 37, 41, 43})
+                            if (cand < nbuf && std::gcd(cand, nbuf) == 1) { K = cand; break; }
+                        if (K > 1) {
+                            std::vector<int32_t*> in_order(c.frames.size());
+                            for (int i = 0; i < nbuf; ++i) in_order[i] = c.frames[(size_t)((long long)i * K % nbuf)];
+                            c.frames.swap(in_order);
+                        }
+                    }
                     JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
                     if (a == 1 && yardstick <= 0) yardstick = jsp::pool_fill_rate(reinterpret_cast<uint32_t*>(c.allocs[0]), bytes * (size_t)nbuf);
                     c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
@@ -403,7 +414,9 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", tried_spread + a, a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     cands.push_back(std::move(c));
                     p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)cands.size() * one);
-                    if (best < 0 || cands.back().rate > cands[best].rate) best = (int)cands.size() - 1;
+                    // (an older form — its frames lie densely — must beat the chunked candidate by 3 % to replace it: the probe's shape does not mind density, the
+                    // key-frame kernel's does, profiles/r05_front_lab_frame_order.txt)
+                    if (best < 0 || cands.back().rate > cands[best].rate * (best == 0 && tried_spread > 0 ? 1.03 : 1.0)) best = (int)cands.size() - 1;
                     if ((a >= 1 || yardstick > 0) && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill
                                                                                    // takes, 6.9 - 7.0 TB/s; the others 5.4 - 6.5; one candidate in
                                                                                    // six is fast in a bad session, the first one in a good one)

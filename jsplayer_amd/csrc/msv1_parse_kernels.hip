@@ -397,7 +397,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // LS = slots (2 bytes) per lane: 32 (16 KiB tiles) for the batch forms, 16 (8 KiB tiles) for the one-frame-per-launch forms,
 // whose few dozen workgroups have the GPU to themselves: half the serial work per tile, twice the tiles.
 template <int BITS, int MODE, int LS>
-__global__ __launch_bounds__(PWG, JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream_p,
+__global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream_p,
                                                             const Msv1TileRec* __restrict__ recs,
                                                             const int32_t* __restrict__ palette,
                                                             unsigned long long* __restrict__ agg_p, uint32_t epoch_p,

@@ -16,6 +16,9 @@
 #ifndef JSP_FUSED_WAVES
 #define JSP_FUSED_WAVES 4
 #endif
+#ifndef JSP_FUSED_WAVES_TABLES
+#define JSP_FUSED_WAVES_TABLES 4
+#endif
 #if defined(JSP_FUSED_STOP)
 #define JSP_CLOCK_BEGIN() do { } while (0)
 #define JSP_CLOCK(k) do { if (MODE == 0 && (k) == JSP_FUSED_STOP) return; } while (0)
