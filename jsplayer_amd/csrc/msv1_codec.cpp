@@ -73,7 +73,7 @@ struct Msv1Staged : jsp_staged {
                                        sizeof(uint32_t) * (size_t)geo.nblocks, stream));
             msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
                               static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
-                              nullptr, 0, 4);
+                              nullptr, 0, 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);   // (`want`: where a lab build's phase clocks go, as for the batch form)
         }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);

@@ -777,7 +777,11 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
         }
         {
             // replay: every visited slot in order; a plain code leaves the offset of its code and is one block, a special slot
-            // (rare) is a skip code — its count comes from the word —, a slot past the data or the 8-bit end marker
+            // (rare) is a skip code — its count comes from the word —, a slot past the data or the 8-bit end marker.
+            // (Every window walks all of the lane's codes again.  Going on where the window before stopped — round 5, bit-exact — changes nothing
+            // for tiles of two or three windows: inter frames 1.023 / 1.027 against 1.016 / 1.013 ms, all-solid 0.660 against 0.656,
+            // profiles/r05_fused_replay_resume_ab.txt, although thread 0's clocks show 15 k of a table-writing tile's 34 k cycles here
+            // (r05_fused_clocks_inter70.txt): it waits at the window's barriers, it does not walk.)
             uint32_t blk = blk0;
             for (uint32_t left = visits; left; left &= left - 1u) {
                 const uint32_t sl = (uint32_t)lanes::first_bit(left), bit = left & (0u - left);

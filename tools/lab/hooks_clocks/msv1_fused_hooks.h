@@ -21,11 +21,11 @@
 #endif
 #if defined(JSP_FUSED_STOP)
 #define JSP_CLOCK_BEGIN() do { } while (0)
-#define JSP_CLOCK(k) do { if (MODE == 0 && (k) == JSP_FUSED_STOP) return; } while (0)
+#define JSP_CLOCK(k) do { if ((MODE == 0 || MODE == 4) && (k) == JSP_FUSED_STOP) return; } while (0)
 #else
 #define JSP_FUSED_CLOCKS 1
 #define JSP_CLOCK_BEGIN() unsigned long long clk_ = __builtin_readcyclecounter()
-#define JSP_CLOCK(k) do { if (MODE == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+#define JSP_CLOCK(k) do { if ((MODE == 0 || MODE == 4) && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
     agg[(size_t)want * 9u + (size_t)(tile0 + blockIdx.x) * 8u + (k)] += now_ - clk_; clk_ = now_; } } while (0)
 #endif
 #if defined(JSP_FUSED_STOP)
