@@ -43,7 +43,8 @@ struct Msv1Staged : jsp_staged {
     DeviceBuffer d_pframes, d_tile_frame, d_tile_tab, d_tile_entry, d_tile_block0, d_info;
     PinnedBuffer h_pframes, h_tile_frame, h_info;
     // fused parse + reconstruction (msv1_fused_kernel): published tile tables, ticket / fault words
-    DeviceBuffer d_agg, d_sync, d_recs, d_recs_emit;
+    DeviceBuffer d_agg, d_sync, d_recs, d_recs_emit, d_agg_emit;
+    int ntiles_emit = 0;       // tiles of the table-writing form: it parses in 8 KiB tiles (twice the workgroups per CU, half the serial work in each)
     PinnedBuffer h_fault, h_recs, h_recs_emit;
     uint32_t epoch = 0;
     bool needs_desc = false;   // some launch reads the descriptor table the parse kernels build
@@ -72,8 +73,8 @@ struct Msv1Staged : jsp_staged {
                 JSP_HIP(hipMemsetAsync(static_cast<uint32_t*>(d_desc.p) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE,
                                        sizeof(uint32_t) * (size_t)geo.nblocks, stream));
             msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                              static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), 0, ntiles, static_cast<uint32_t*>(d_sync.p), stream,
-                              nullptr, 0, 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);   // (`want`: where a lab build's phase clocks go, as for the batch form)
+                              static_cast<unsigned long long*>(d_agg_emit.p), next_epoch(epoch), 0, ntiles_emit, static_cast<uint32_t*>(d_sync.p), stream,
+                              nullptr, 0, 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles_emit, nullptr, /*small_tiles=*/true);   // (`want`: where a lab build's phase clocks go)
         }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
@@ -1096,34 +1097,54 @@ struct Msv1Codec : jsp_codec {
                 JSP_HIP(hipMemcpyAsync(st->d_recs.p, recs, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
                 if (st->needs_desc) {   // the same records for the descriptor form: `dst` = the frame's block table; frames whose
                                         // table nobody reads (fused groups) or that came from the host parser are skipped
-                    st->h_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
-                    st->d_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max(st->ntiles, 1));
+                    // The table-writing form has no pixel stores to hide its parse behind: it runs in 8 KiB tiles (msv1_fused_kernel<BITS, 4, 16>: 64 VGPRs and
+                    // 19 KB of LDS, eight workgroups per CU instead of four, half the serial work per tile).  Frames start on 16 KiB boundaries of the
+                    // stream buffer, so a frame's 8 KiB tiles are numbered from twice its first 16 KiB tile... minus the halves that are all padding: the
+                    // tiles are counted per frame, records and published words (d_agg_emit) are this form's own.
+                    const uint32_t tile8 = msv1_small_tile_bytes();
+                    std::vector<uint32_t> first8((size_t)nf), n8((size_t)nf);
+                    uint32_t nt8 = 0;
+                    for (int i = 0; i < nf; ++i) {
+                        first8[i] = nt8;
+                        n8[i] = h_pf[i].ntiles ? (uint32_t)((frames[i].n + tile8 - 1) / tile8) : 0u;
+                        nt8 += n8[i];
+                    }
+                    st->ntiles_emit = (int)nt8;
+                    st->h_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max<uint32_t>(nt8, 1));
+                    st->d_recs_emit.reserve(sizeof(Msv1TileRec) * (size_t)std::max<uint32_t>(nt8, 1));
+                    st->d_agg_emit.reserve(sizeof(unsigned long long) * (9 + 8) * (size_t)std::max<uint32_t>(nt8, 1));
                     auto* er = static_cast<Msv1TileRec*>(st->h_recs_emit.p);
-                    for (int i = 0; i < nf; ++i)                     // (from the frames again: `recs` is in launch order by now)
-                        for (uint32_t k = 0; k < h_pf[i].ntiles; ++k) {
-                            Msv1TileRec& r = er[h_pf[i].first_tile + k];
-                            r.byte0 = h_pf[i].beg + k * tile_bytes;
-                            r.frame_end = h_pf[i].end;
-                            r.data_end = geo.bits == 16 ? h_pf[i].end : h_frames[i].stream_end;
-                            r.k = k;
-                            r.first_tile = h_pf[i].first_tile;
-                            r.ntiles = h_pf[i].ntiles;
-                            r.signif = h_frames[i].signif;
-                            r.pad = 0;
-                        }
                     std::vector<uint8_t> in_fused(nf, 0);
                     for (const auto& g : st->groups)
                         if (g.fused) std::fill(in_fused.begin() + g.first, in_fused.begin() + g.first + g.count, 1);
-                    for (int i = 0; i < nf; ++i)
-                        for (uint32_t k = 0; k < h_pf[i].ntiles; ++k) {
-                            Msv1TileRec& r = er[h_pf[i].first_tile + k];
-                            r.dst = reinterpret_cast<int32_t*>(static_cast<uint32_t*>(st->d_desc.p) + (size_t)i * nblk);
-                            r.prev = nullptr;
-                            r.cmp_row_lo = 0xFFFFFFFFu;
-                            r.flags = (h_pf[i].host_parsed || in_fused[i]) ? MSV1_TILE_SKIP : 0u;
-                        }
-                    tile_major(er, 0, nf);
-                    JSP_HIP(hipMemcpyAsync(st->d_recs_emit.p, er, sizeof(Msv1TileRec) * (size_t)st->ntiles, hipMemcpyHostToDevice, stream));
+                    // launch order: tile-major over the frames, frame i (i mod 64) rounds late — as for the pixel-writing form above
+                    {
+                        uint32_t maxt = 0, o = 0;
+                        for (int i = 0; i < nf; ++i) maxt = std::max(maxt, n8[i]);
+                        const uint32_t stagger = 64u;
+                        for (uint32_t j = 0; j < maxt + stagger; ++j)
+                            for (int i = 0; i < nf; ++i) {
+                                const uint32_t late = nf > 1 ? (uint32_t)i % stagger : 0u;
+                                if (j < late || j - late >= n8[i]) continue;
+                                const uint32_t k = j - late;
+                                Msv1TileRec& r = er[o++];
+                                r = Msv1TileRec{};
+                                r.byte0 = h_pf[i].beg + k * tile8;
+                                r.frame_end = h_pf[i].end;
+                                r.data_end = geo.bits == 16 ? h_pf[i].end : h_frames[i].stream_end;
+                                r.k = k;
+                                r.first_tile = first8[i];
+                                r.ntiles = n8[i];
+                                r.signif = h_frames[i].signif;
+                                r.pad = 0;
+                                r.dst = reinterpret_cast<int32_t*>(static_cast<uint32_t*>(st->d_desc.p) + (size_t)i * nblk);
+                                r.prev = nullptr;
+                                r.cmp_row_lo = 0xFFFFFFFFu;
+                                r.flags = (h_pf[i].host_parsed || in_fused[i]) ? MSV1_TILE_SKIP : 0u;
+                            }
+                    }
+                    JSP_HIP(hipMemcpyAsync(st->d_recs_emit.p, er, sizeof(Msv1TileRec) * (size_t)nt8, hipMemcpyHostToDevice, stream));
+                    JSP_HIP(hipMemsetAsync(st->d_agg_emit.p, 0, sizeof(unsigned long long) * (9 + 8) * (size_t)std::max<uint32_t>(nt8, 1), stream));
                     st->scrub.clear();
                     if (opt_scrub_tables)
                         for (int i = 0; i < nf; ++i)

@@ -1005,14 +1005,14 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
     }
     const uint32_t s1_first = (uint32_t)(insignificant_blocks < 0 ? 0 : insignificant_blocks) * (uint32_t)geo.nbx;
     const Msv1TileRec rec = one_rec ? *one_rec : Msv1TileRec{};
-    if (mode == 0 || mode == 4) small_tiles = false;           // the batch forms lay frames out on 16 KiB boundaries
+    if (mode == 0) small_tiles = false;                        // the batch form lays frames out on 16 KiB boundaries (the table-writing form, mode 4, may take them in 8 KiB tiles: its records say where each begins)
 #define JSP_FUSED(BITS, MODE, LS)                                                                                            \
     hipLaunchKernelGGL((msv1_fused_kernel<BITS, MODE, LS>), dim3(ntiles), dim3(PWG), 0, stream, d_stream, d_recs, d_palette, \
                        d_agg, epoch, tile0, d_fault, (uint32_t)geo.nblocks, geo.nbx, geo.X, d_info, s1_first, bad_mask, d_poison, rec, h_info, want, d_keep, two)
 #define JSP_FUSED_LS(BITS, MODE) do { if (small_tiles) JSP_FUSED(BITS, MODE, 16); else JSP_FUSED(BITS, MODE, JSP_BATCH_LS); } while (0)
 #define JSP_FUSED_MODES(BITS)                                                                                                \
     switch (mode) { case 1: JSP_FUSED_LS(BITS, 1); break; case 2: JSP_FUSED_LS(BITS, 2); break; case 3: JSP_FUSED_LS(BITS, 3); break; \
-                    case 4: JSP_FUSED(BITS, 4, JSP_BATCH_LS); break; default: JSP_FUSED(BITS, 0, JSP_BATCH_LS); }
+                    case 4: JSP_FUSED_LS(BITS, 4); break; default: JSP_FUSED(BITS, 0, JSP_BATCH_LS); }
     if (geo.bits == 16) { JSP_FUSED_MODES(16) } else { JSP_FUSED_MODES(8) }
 #undef JSP_FUSED_MODES
 #undef JSP_FUSED_LS
