@@ -235,7 +235,8 @@ def resident_leg(job: Job, name: str, nfr_override=None, nclips=None):
         "clips_per_step": len(clips),
         "destination_frames": ({"from": "jsp_pool_create (the product's frame pool: one pool per clip, placed by probing candidate allocations, include/jsplayer_amd.h)",
                                 "allocations_tried": [p.attempts for p in work.pools], "probe_GBs": [round(p.store_rate) for p in work.pools],
-                                "probe_ms": [round(p.probe_ms, 1) for p in work.pools], "held_while_probing_GB": [round(p.held_bytes / 1e9, 2) for p in work.pools]}
+                                "probe_ms": [round(p.probe_ms, 1) for p in work.pools], "held_while_probing_GB": [round(p.held_bytes / 1e9, 2) for p in work.pools],
+                                "candidates_GBs": [[round(r) for r in p.tried_rates] for p in work.pools]}
                                if work.pools else {"from": "one torch tensor per frame" if os.environ.get("JSP_BENCH_FRAME_POOL") == "torch" else "one torch allocation, frames back to back"}),
         "inputs": ("raw stream bytes resident in HBM (on-GPU parse every step)" if spec.get("parse") == "gpu" else
                    "host-built descriptor tables (+ MSVideo1 stream bytes) resident in HBM"),

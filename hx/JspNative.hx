@@ -47,6 +47,7 @@ extern class JspNative {
     @:native("jsp_pool_create")        static function poolCreate(device:Int, w:Int, h:Int, nbuf:Int):RawPointer<JspPool>;
     @:native("jsp_pool_store_rate")    static function poolStoreRate(p:RawPointer<JspPool>, attempts:RawPointer<Int>):Float;   // diagnostics: what the placement probe of a large pool found
     @:native("jsp_pool_probe_info")    static function poolProbeInfo(p:RawPointer<JspPool>, probeMs:RawPointer<Float>, heldPeak:RawPointer<cpp.UInt64>, holdLimit:RawPointer<cpp.UInt64>):Int;
+    @:native("jsp_pool_probe_rates")   static function poolProbeRates(p:RawPointer<JspPool>, rates:RawPointer<Float>, cap:Int):Int;
     @:native("jsp_pool_buffer")        static function poolBuffer(p:RawPointer<JspPool>, i:Int):RawPointer<cpp.Int32>;
     @:native("jsp_pool_destroy")       static function poolDestroy(p:RawPointer<JspPool>):Void;
     @:native("jsp_download")           static function download(deviceFrame:RawConstPointer<cpp.Int32>, host:RawPointer<cpp.Int32>, npixels:SizeT):Int;

@@ -95,12 +95,16 @@ const char* jsp_last_error(void);
 
 /* ---- frame pool in HBM (Manager.hx:114-118: num_buffers+1 frame buffers) ---------------- */
 
-/* A pool of 32 frames or more (what batch decoding writes into: tile j of every frame at about the same time) is PLACED: where the
- * frames lie in physical memory, relative to each other, moves that store shape by a quarter (persistently per set of allocations; no
- * query reveals it), so the pool measures up to sixteen candidates with the shape (a few milliseconds each) — two frames per
- * allocation, one allocation for all, one per frame, in turn, the slow ones held until it has chosen — and keeps the first that takes what a plain fill
- * takes, or the best.  JSP_POOL_PROBE=0 in the environment: one allocation per frame, first come — what smaller pools (a player's
- * num_buffers + 1) always get.  The probe's appetite is bounded (jsp_pool_probe_info). */
+/* A pool of 32 frames or more (what batch decoding writes into: tile j of every frame at about the same time, or every frame of a clip one after
+ * the other from the same workgroups) is PLACED.  What the decode kernels' stores get from a pool depends on where its frames lie relative to each
+ * other: frames that are neighbours in memory cost the frame-walking kernels a sixth and can cost the batch kernels a quarter (no query
+ * reveals it).  The pool therefore allocates, in one run, four times the 16-frame chunks it needs, takes every fourth (candidate k: chunks k, k + 4, ...)
+ * and DEALS its frames round-robin over them — buffer i and buffer i + 1 never lie in the same chunk —, measures the candidate with the kernels' store
+ * shape (a few milliseconds), keeps the first that takes what a plain fill takes and gives the other chunks back; only when none of the four comes
+ * near do the older forms (one allocation, two frames per allocation, one per frame — frames taken in a strided order) get a try.  Decode consecutive
+ * frames into consecutive buffers of the pool and they are far apart.  JSP_POOL_PROBE=0 in the environment: one allocation per frame, first come — what
+ * smaller pools (a player's num_buffers + 1) always get.  The probe's appetite is bounded (jsp_pool_probe_info; while it chooses it holds four times
+ * the pool, or what JSP_POOL_PROBE_HOLD_GB / a quarter of the free memory allows). */
 jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf);
 int32_t* jsp_pool_buffer(jsp_pool* p, int i); /* device pointer, width*height ints, zeroed */
 /* GB/s the chosen allocation took from the probe (0: a pool that is not probed); *attempts = allocations tried. */
@@ -109,6 +113,9 @@ double jsp_pool_store_rate(jsp_pool* p, int* attempts);
  * has chosen) and what it was allowed to hold — a quarter of the device memory free when it began, JSP_POOL_PROBE_HOLD_GB (GB) if lower,
  * never more than JSP_POOL_PROBE_MAX candidates (default 16).  All 0 for a pool that is not probed.  Returns 0, -1 for a null pool. */
 int jsp_pool_probe_info(jsp_pool* p, double* probe_ms, uint64_t* held_peak_bytes, uint64_t* hold_limit_bytes);
+/* What every candidate the probe measured took (GB/s, in the order tried: first the chunked candidates, then the older forms): up to `cap` of them
+ * into `rates`; returns how many were measured (0 for a pool that is not probed, -1 for a null pool). */
+int jsp_pool_probe_rates(jsp_pool* p, double* rates, int cap);
 int jsp_pool_count(jsp_pool* p);
 void jsp_pool_destroy(jsp_pool* p);
 /* Copy one frame between a device frame buffer and host memory (parity checks, display). */

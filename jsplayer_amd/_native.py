@@ -57,6 +57,7 @@ SIGNATURES = {
     "jsp_pool_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "jsp_pool_store_rate": (C.c_double, [C.c_void_p, C.POINTER(C.c_int)]),
     "jsp_pool_probe_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jsp_pool_probe_rates": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "jsp_pool_buffer": (C.c_void_p, [C.c_void_p, C.c_int]),
     "jsp_pool_count": (C.c_int, [C.c_void_p]),
     "jsp_pool_destroy": (None, [C.c_void_p]),

@@ -366,6 +366,9 @@ class FramePool:
         ms, held, limit = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         self._lib.jsp_pool_probe_info(self._h, C.byref(ms), C.byref(held), C.byref(limit))
         self.probe_ms, self.held_bytes, self.hold_limit = ms.value, held.value, limit.value   # what placing the pool cost
+        rates = (C.c_double * 64)()
+        n = self._lib.jsp_pool_probe_rates(self._h, rates, 64)
+        self.tried_rates = [float(rates[i]) for i in range(max(0, min(n, 64)))]             # GB/s of every candidate measured, in order
         n = width * height
         self.frames = [torch.as_tensor(_DeviceView(int(self._lib.jsp_pool_buffer(self._h, i)), n), device=f"cuda:{device}") for i in range(count)]
 

@@ -472,6 +472,11 @@ int jsp_pool_probe_info(jsp_pool* p, double* probe_ms, uint64_t* held_peak_bytes
     if (hold_limit_bytes) *hold_limit_bytes = p->hold_limit;
     return 0;
 }
+int jsp_pool_probe_rates(jsp_pool* p, double* rates, int cap) {
+    if (!p) return -1;
+    for (int i = 0; rates && i < cap && i < (int)p->tried.size(); ++i) rates[i] = p->tried[(size_t)i];
+    return (int)p->tried.size();
+}
 int jsp_download(const int32_t* device_frame, int32_t* host, size_t npixels) {
     return guarded([&] {
         JSP_HIP(hipMemcpy(host, device_frame, npixels * sizeof(int32_t), hipMemcpyDeviceToHost));
