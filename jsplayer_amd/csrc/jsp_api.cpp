@@ -330,36 +330,64 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     bool ok = true;
                     for (int q = 0; q < nch * spread && ok; ++q) {
                         void* d = nullptr;
-                        ok = hipMalloc(&d, bytes * (size_t)chunk_frames(q / spread)) == hipSuccess;   // chunks q = ch * spread + k: the k-th candidate's ch-th chunk
+                        ok = hipMalloc(&d, bytes * (size_t)kChunkFrames) == hipSuccess;   // (whole chunks all: any chunk of the run can stand for any chunk of the pool)
                         if (ok) run.push_back(d);
                     }
                     if (!ok) { (void)hipGetLastError(); for (void* d : run) (void)hipFree(d); run.clear(); }
                     else p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)spread * one);
                 }
+                // Which chunks of the run a candidate takes.  "Every fourth" is not always the answer: in some sessions all four such candidates are slow
+                // (5.7 - 6.4 TB/s) while a form made of many small allocations is fast (profiles/r05_q_bench_all.jsonl: candidates_GBs) — the run's chunks
+                // do not always lie in memory in the order they were asked for.  So the candidates differ in kind: every fourth from the first, a
+                // pseudo-random choice, every third from the second, another pseudo-random choice.
+                auto pick = [&](int k) {
+                    std::vector<int> ids;
+                    const int total = (int)run.size();
+                    if (k == 0 || (k == 2 && spread < 3)) {
+                        for (int ch = 0; ch < nch; ++ch) ids.push_back(ch * spread + (k ? 1 : 0));
+                    } else if (k == 2) {
+                        for (int ch = 0; ch < nch; ++ch) ids.push_back(1 + ch * 3);
+                    } else {                                   // a partial Fisher-Yates shuffle, seeded by the candidate
+                        std::vector<int> all(total);
+                        for (int i = 0; i < total; ++i) all[i] = i;
+                        uint64_t seed = 0x9E3779B97F4A7C15ull * (uint64_t)(k + 1);
+                        for (int i = 0; i < nch; ++i) {
+                            seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+                            const int j = i + (int)((seed >> 33) % (uint64_t)(total - i));
+                            std::swap(all[i], all[j]);
+                            ids.push_back(all[i]);
+                        }
+                    }
+                    return ids;
+                };
                 int spread_best = -1;
                 double spread_rate = 0;
                 std::vector<int32_t*> dealt;
-                auto deal = [&](int k) {                       // candidate k's frames, dealt round-robin over its chunks
+                auto deal = [&](const std::vector<int>& ids) {  // the candidate's frames, dealt round-robin over its chunks
                     dealt.clear();
                     for (int slot = 0; slot < kChunkFrames; ++slot)
                         for (int ch = 0; ch < nch; ++ch)
-                            if (slot < chunk_frames(ch)) dealt.push_back(static_cast<int32_t*>(run[(size_t)ch * spread + k]) + (size_t)slot * width * height);
+                            if (slot < chunk_frames(ch)) dealt.push_back(static_cast<int32_t*>(run[(size_t)ids[(size_t)ch]]) + (size_t)slot * width * height);
                 };
-                for (int k = 0; k < spread && k < kCandidates && !run.empty(); ++k) {
-                    deal(k);
+                for (int k = 0; k < 4 && k < kCandidates && !run.empty(); ++k) {
+                    deal(pick(k));
                     JSP_HIP(hipMemcpy(d_table, dealt.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
                     const double rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
                     p->tried.push_back(rate);
-                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (chunks of 16 frames, every %d-th of a run from the %d-th, frames dealt over them): %.0f GB/s (plain fill %.0f)\n", k, spread, k, rate, yardstick);
+                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (chunks of 16 frames out of a run of %d x the pool: %s; frames dealt over them): %.0f GB/s (plain fill %.0f)\n", k, spread,
+                                                                        k == 0 ? "every fourth" : k == 2 ? "every third" : "a pseudo-random choice", rate, yardstick);
                     if (rate > spread_rate) { spread_rate = rate; spread_best = k; }
                     if (yardstick > 0 && rate >= 0.985 * yardstick) break;
                 }
                 if (spread_best >= 0) {                        // keep the best of them as a candidate like any other, give the other chunks back
                     Candidate c;
-                    deal(spread_best);
+                    const std::vector<int> ids = pick(spread_best);
+                    deal(ids);
                     c.frames = dealt;
+                    std::vector<char> kept(run.size(), 0);
+                    for (int id : ids) kept[(size_t)id] = 1;
                     for (size_t q = 0; q < run.size(); ++q) {
-                        if ((int)(q % (size_t)spread) == spread_best) c.allocs.push_back(run[q]);
+                        if (kept[q]) c.allocs.push_back(run[q]);
                         else (void)hipFree(run[q]);
                     }
                     run.clear();
