@@ -415,7 +415,7 @@ def e2e_leg(job: Job, name: str, clips, one_stream=True, batch_calls=True, secon
 
 def measured_ceilings(job: Job):
     """What THIS box's memory takes right now, measured in this run: nothing but 16-byte stores, one per lane, workgroups in
-    address order (the friendliest shape found, profiles/r03_sp_store_lab.txt) over 2 GiB, HIP events on the bench's stream —
+    address order (the friendliest shape found, profiles/archive/r03_sp_store_lab.txt) over 2 GiB, HIP events on the bench's stream —
     and the rate on file (tools/hbm_ceiling.hip, profiles/hbm_ceiling.json).  The boxes of the pool differ by up to a fifth
     here, so the fraction of this number travels better than the fraction of 8 TB/s."""
     import torch

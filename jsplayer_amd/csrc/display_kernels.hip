@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void frames_differ_kernel(const uint32_t* __re
 }
 
 // What the memory system takes when it is asked for nothing but stores in the friendliest shape this chip has been found to
-// have (profiles/r03_sp_store_lab.txt): 16 bytes per lane, ONE store per lane, workgroups of 256 lanes handed out in address order.
+// have (profiles/archive/r03_sp_store_lab.txt): 16 bytes per lane, ONE store per lane, workgroups of 256 lanes handed out in address order.
 typedef uint32_t fill_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void ceiling_fill_kernel(fill_u32x4* __restrict__ dst, size_t n, uint32_t v) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -268,7 +268,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         // A pool large enough for batches (the staged-batch calls write tile j of EVERY frame at about the same time: as many write
         // fronts as frames) is probed: the same store shape gets 5.4 - 7.0 TB/s from one set of allocations or another of the same
         // process, persistently — a property of where the frames lie in physical memory, relative to each other, that no query
-        // reveals (profiles/r03_fused_notes.txt, tools/front_lab.hip): sometimes one allocation per frame is the fast form and one
+        // reveals (profiles/archive/r03_fused_notes.txt, tools/front_lab.hip): sometimes one allocation per frame is the fast form and one
         // allocation for all the slow one, sometimes the other way round, sometimes the second try of the same form.  So the pool
         // measures what it was given (a few milliseconds per candidate), going round three forms (two frames per allocation, one
         // allocation for all, one per frame), keeps slow candidates

@@ -1078,7 +1078,7 @@ struct Msv1Codec : jsp_codec {
                     // ... and the frames do not march in step: frame i starts (i mod 64) rounds late, so that at any time the batch's write
                     // fronts stand at different depths of their frames instead of all at tile j.  What the memory system makes of
                     // hundreds of fronts depends on where the frames lie in physical memory; staggered, the same frames
-                    // take 2 - 6 % less time whichever way they lie (one process, same buffers: profiles/r03_stagger_one_process.txt).
+                    // take 2 - 6 % less time whichever way they lie (one process, same buffers: profiles/archive/r03_stagger_one_process.txt).
                     const uint32_t stagger = [] { const char* e = std::getenv("JSP_MSV1_STAGGER"); return e ? (uint32_t)std::atoi(e) : 64u; }();   // (lab: read at every staging)
                     for (uint32_t j = 0; j < maxt + stagger; ++j)
                         for (int i = f0; i < f1; ++i) {

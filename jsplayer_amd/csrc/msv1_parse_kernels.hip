@@ -379,7 +379,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 }
 
 // One launch: grid = tiles, in stream order.
-// Measured and dropped (profiles/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
+// Measured and dropped (profiles/archive/r02_fused_notes.txt): a persistent variant (rounds of tiles, the next tile's bytes
 // prefetched into registers) hid the tile load but ran the workgroups of a CU in lockstep — every phase then competes
 // for the same issue slots — and was 10 % slower.
 // The asynchronous per-frame path (one frame per launch):
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
     // Staging windows start on multiples of 256 blocks, whatever block the tile starts with: lane i of the workgroup then always
     // has block (multiple of 256) + i, so a wave's row store is 1 KiB starting on a 512-byte boundary of the frame and writes whole
     // memory lines.  (Windows that started at the tile's first block made every row store of every wave begin and end inside a
-    // line that the neighbouring wave completes: two partial-line writes per store, see profiles/r03_fused_notes.txt.)
+    // line that the neighbouring wave completes: two partial-line writes per store, see profiles/archive/r03_fused_notes.txt.)
     for (uint32_t w0 = JSP_FUSED_ALIGN ? tb0 & ~255u : tb0; w0 < span_end; w0 += FSTAGE) {   // more than one window only behind long skip runs / in tiles of short codes
         const uint32_t wn = span_end - w0 < (uint32_t)FSTAGE ? span_end - w0 : (uint32_t)FSTAGE;   // window entries [0, wn) ...
         const uint32_t wlo = tb0 > w0 ? tb0 - w0 : 0u;                 // ... of which [wlo, wn) are this tile's blocks (wlo < 256)
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
                 decode_block<BITS>(lds_bytes + o, data_end - (tile_byte0 + o), s_pal, px);
                 // Store throttle.  A CU's loads and stores share one in-order queue: every row store a wave leaves in flight is
                 // something the other workgroups' loads (tile bytes, look-back word) wait behind.  Keeping at most a few rows per
-                // wave in flight keeps the memory pipe full without that queue growing: profiles/r03_fused_notes.txt.
+                // wave in flight keeps the memory pipe full without that queue growing: profiles/archive/r03_fused_notes.txt.
                 if (MODE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JSP_FUSED_VMCNT) : "memory");
 #pragma unroll
                 for (int y = 0; y < 4; ++y)

@@ -187,7 +187,7 @@ __device__ __forceinline__ uint32_t lane_to_the_left(uint32_t v) {   // lane i g
 // loop is one wave's private instruction stream: row above in registers, run words scattered through an LDS row
 // of the span, branch-free predictor.
 //
-// The kernel is bound by the instructions it issues (profiles/r03_sp_iframes_tile_sq_counters.txt: a wave64 VALU
+// The kernel is bound by the instructions it issues (profiles/archive/r03_sp_iframes_tile_sq_counters.txt: a wave64 VALU
 // instruction holds its SIMD for four cycles and the row loop ran to ~110 of them per row), so everything that is the
 // same for all 64 lanes lives on the scalar unit: a window's index entries and left pixels sit one per lane in two
 // registers and each row takes its own with v_readlane (no LDS read, no address arithmetic); a record arrives as 4 bytes
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(PWG) void sp_pframe_group1_kernel(const PGroupFrame
 //
 // sp_pframe_group1_kernel above staged every chunk of frames itself: all four waves stopped at workgroup barriers — which wait
 // for the wave's row stores in flight — and then paid two load round trips behind the CU's store queue (54 % of its wave cycles
-// parked, profiles/r03_sp_pclip300_group_sq_counters.txt).  A loader wave cannot simply be added to it: with one wave per 16x16
+// parked, profiles/archive/r03_sp_pclip300_group_sq_counters.txt).  A loader wave cannot simply be added to it: with one wave per 16x16
 // block a 1080p frame needs 8 160 of the chip's 8 192 wave slots.  So a lane carries TWO rows of 4 pixels here (a workgroup = 8
 // adjacent blocks = 128 x 16 pixels, 256 worker lanes; a wave's store is two 512-byte row segments), half the waves do the
 // same work, and the fifth wave of every workgroup fetches the next chunk — block records, frame records, literal pixels —
@@ -854,7 +854,7 @@ void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, in
 bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; }
 // 4 pixels per lane, 256-column spans (8 per lane measured 189 us against 147 us at 64 x 1080p: half as many waves,
 // each with a longer serial row step)
-int iframe_tile_span(const Geometry&) { return 256; }   // (8 pixels per lane, 512-column spans: 0.71 vs 0.54 ms, profiles/r03_fused_notes.txt)
+int iframe_tile_span(const Geometry&) { return 256; }   // (8 pixels per lane, 512-column spans: 0.71 vs 0.54 ms, profiles/archive/r03_fused_notes.txt)
 namespace {
 struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {

@@ -1,5 +1,5 @@
 // lab: why do workgroups that KEEP storing get less from the memory system than workgroups that store once and leave?
-// (profiles/r03_sp_store_lab.txt: the same 2.1 GB written in 4 KB pieces — 6.9 TB/s with one piece per workgroup, 5.3 with 2 025
+// (profiles/archive/r03_sp_store_lab.txt: the same 2.1 GB written in 4 KB pieces — 6.9 TB/s with one piece per workgroup, 5.3 with 2 025
 // workgroups that loop.)  One explanation is a static split: a looping workgroup owns 1/N of the bytes whatever its CU / XCD gets
 // from memory, so the slowest finishes last, while fresh workgroups go wherever a slot frees up.  This tool writes the same buffer
 //   mode 0  one 4 KB piece per workgroup, address order                       (the plain fill)
