@@ -105,6 +105,16 @@ def cpu_baseline(spec, clip, budget_s=8.0):
     return out
 
 
+def _device_identity(index: int):
+    """Which GPU this is (the boxes of the pool differ in what their memory makes of the decode kernels' store shapes: DESIGN.md 6)."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        return {"name": p.name, "uuid": str(getattr(p, "uuid", "")), "gcn_arch": getattr(p, "gcnArchName", ""), "total_memory_GB": round(p.total_memory / 1e9, 1)}
+    except Exception:
+        return None
+
+
 def _spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this very command as a
     CHILD process — before anything has touched the GPU — and hand its output and exit code through."""
@@ -573,6 +583,7 @@ def main():
                 "frames_per_step": head["frames_per_step"],
                 "clips_per_step": head["clips_per_step"],
                 "destination_frames": head["destination_frames"],
+                "device": _device_identity(local_rank),
                 "streams": args.gpus,
                 "sharding": ("REHEARSAL: %d ranks, one independent stream each, all on GPU 0 (gloo, host-tensor collectives)" % args.gpus) if share else
                             "one independent AVI stream per GPU, no data-path collective",

@@ -263,6 +263,70 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     };
+    if (argc > 2 && getenv("LAB_SUBSETS")) {   // round 5: is "fast" a property of WHICH frames are written together?  2F single-frame allocations (or chunks of LAB_CH frames), random F-subsets, per-frame scores
+        const int CH = getenv("LAB_CH") ? atoi(getenv("LAB_CH")) : 1, OVER = atoi(argv[2]);      // OVER x F frames allocated
+        const int NA = F * OVER / CH;                                                              // allocations
+        std::vector<uint32_t*> alloc(NA);
+        for (int a = 0; a < NA; ++a) { CK(hipMalloc(&alloc[a], FRAME_BYTES * CH)); }
+        for (int a = 0; a < NA; ++a) CK(hipMemset(alloc[a], 0, FRAME_BYTES * CH));
+        const int T = 8192, tpf = (NBLK + T - 1) / T;
+        auto rate = [&](const std::vector<uint32_t*>& fr) {
+            const int n = (int)fr.size();
+            CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * n, hipMemcpyHostToDevice));
+            auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * n), dim3(256), 0, 0, d_table, n, T, tpf, 1); };
+            launch();
+            CK(hipDeviceSynchronize());
+            float ms = 0;
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 2; ++i) launch();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            return (double)n * FRAME_BYTES * 2 / ms / 1e6;
+        };
+        const int need = F / CH, NS = 96;
+        std::vector<double> score(NA, 0.0), cnt(NA, 0.0), rates;
+        double total = 0;
+        unsigned long long seed = 777;
+        auto frames_of = [&](const std::vector<int>& ids) {
+            std::vector<uint32_t*> fr;
+            for (int slot = 0; slot < CH; ++slot) for (int id : ids) fr.push_back(alloc[id] + (size_t)slot * X * Y);   // dealt over the allocations
+            return fr;
+        };
+        for (int t = 0; t < NS; ++t) {
+            std::vector<int> all(NA), ids;
+            for (int i = 0; i < NA; ++i) all[i] = i;
+            for (int q = 0; q < need; ++q) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; const int j = q + (int)((seed >> 33) % (unsigned)(NA - q)); std::swap(all[q], all[j]); ids.push_back(all[q]); }
+            const double r = rate(frames_of(ids));
+            rates.push_back(r);
+            total += r;
+            for (int id : ids) { score[id] += r; cnt[id] += 1; }
+        }
+        std::vector<double> sorted = rates;
+        std::sort(sorted.begin(), sorted.end());
+        printf("%d allocations of %d frame(s), %d random subsets of %d: min %.0f | 10%% %.0f | median %.0f | 90%% %.0f | max %.0f GB/s\n", NA, CH, NS, need, sorted.front(), sorted[NS / 10], sorted[NS / 2], sorted[NS * 9 / 10], sorted.back());
+        // per-allocation score: mean rate of the subsets it was in, against the overall mean
+        std::vector<int> order(NA);
+        for (int i = 0; i < NA; ++i) { order[i] = i; score[i] = cnt[i] > 0 ? score[i] / cnt[i] : total / NS; }
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return score[a] > score[b]; });
+        std::vector<int> top(order.begin(), order.begin() + need), bottom(order.end() - need, order.end());
+        printf("scores: best allocation %.0f, worst %.0f (mean %.0f)\n", score[order.front()], score[order.back()], total / NS);
+        printf("the %d best-scored allocations as one pool: %.0f GB/s | the %d worst: %.0f GB/s | allocation order [0, %d): %.0f | every %d-th: %.0f\n", need, rate(frames_of(top)), need, rate(frames_of(bottom)), need,
+               rate(frames_of([&] { std::vector<int> v; for (int i = 0; i < need; ++i) v.push_back(i); return v; }())), OVER, rate(frames_of([&] { std::vector<int> v; for (int i = 0; i < need; ++i) v.push_back(i * OVER); return v; }())));
+        // a second round: subsets drawn from the better-scored two thirds only
+        {
+            const int pool2 = NA * 2 / 3 > need ? NA * 2 / 3 : need;
+            std::vector<double> r2;
+            for (int t = 0; t < 24; ++t) {
+                std::vector<int> all(order.begin(), order.begin() + pool2), ids;
+                for (int q = 0; q < need; ++q) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; const int j = q + (int)((seed >> 33) % (unsigned)(pool2 - q)); std::swap(all[q], all[j]); ids.push_back(all[q]); }
+                r2.push_back(rate(frames_of(ids)));
+            }
+            std::sort(r2.begin(), r2.end());
+            printf("24 random subsets of the better-scored two thirds: min %.0f | median %.0f | max %.0f GB/s\n", r2.front(), r2[12], r2.back());
+        }
+        return 0;
+    }
     if (argc > 2 && getenv("LAB_SPREAD")) {   // round 5: pools put together from separately allocated chunks of CH frames: neighbours, every g-th, random
         const int NC = atoi(argv[2]), CH = getenv("LAB_CH") ? atoi(getenv("LAB_CH")) : 64, NCH = F / CH;
         std::vector<uint32_t*> chunk(NC);
