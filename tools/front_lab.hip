@@ -223,6 +223,22 @@ __global__ __launch_bounds__(256) void group_table_kernel(uint32_t* const* __res
     }
 }
 
+
+// the band-walking shape with the 8 spans of a band in ONE workgroup (8 waves side by side in the row: a row's 7 680 bytes go out from one CU at about
+// the same time); sync = 1: an LDS-only barrier after every row keeps the waves in step
+__global__ __launch_bounds__(512) void band_wg_table_kernel(uint32_t* const* __restrict__ frames, int nframes, int B, int bands, int D, int sync) {
+    const int f = blockIdx.x % nframes, band = blockIdx.x / nframes;
+    const int x = (int)threadIdx.x * 4;
+    uint32_t* dst = frames[f];
+    uint32_t a = (uint32_t)(f + band + threadIdx.x);
+    const int y1 = (band + 1) * B < Y ? (band + 1) * B : Y;
+    for (int y = band * B; y < y1; ++y) {
+        for (int i = 0; i < D; ++i) a = a * 1664525u + 1013904223u;
+        if (x < X) *(gu32x4*)(dst + (size_t)y * X + x) = u32x4{a, a + 1, a + 2, a + 3};
+        if (sync) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -367,12 +383,19 @@ int main(int argc, char** argv) {
             return bytes / best / 1e6;
         };
         auto shapes = [&](const std::vector<uint32_t*>& fr) {   // "fronts / band-walkers (256 frames) / frame-walkers (299 frames)"
-            static char buf[96];
+            static char buf[160];
             const double a = rate(fr);
             CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * fr.size(), hipMemcpyHostToDevice));
             const int nb = 256 < (int)fr.size() ? 256 : (int)fr.size(), ng = 299 < (int)fr.size() ? 299 : (int)fr.size();
             const double b = timed([&] { hipLaunchKernelGGL(band_table_kernel, dim3((unsigned)(nb * 12 * 8)), dim3(64), 4608, 0, d_table, nb, 90, 12, 20); }, (double)nb * FRAME_BYTES);
             const double c = timed([&] { hipLaunchKernelGGL(group_table_kernel, dim3(15, 68), dim3(256), 0, 0, d_table, ng); }, (double)ng * FRAME_BYTES);
+            if (getenv("LAB_BANDWG")) {
+                const double b8 = timed([&] { hipLaunchKernelGGL(band_wg_table_kernel, dim3((unsigned)(nb * 12)), dim3(512), 0, 0, d_table, nb, 90, 12, 20, 0); }, (double)nb * FRAME_BYTES);
+                const double b8s = timed([&] { hipLaunchKernelGGL(band_wg_table_kernel, dim3((unsigned)(nb * 12)), dim3(512), 0, 0, d_table, nb, 90, 12, 20, 1); }, (double)nb * FRAME_BYTES);
+                const double b8t = timed([&] { hipLaunchKernelGGL(band_wg_table_kernel, dim3((unsigned)(nb * 36)), dim3(512), 0, 0, d_table, nb, 30, 36, 20, 0); }, (double)nb * FRAME_BYTES);
+                std::snprintf(buf, sizeof buf, " %4.0f/%4.0f[wg8 %4.0f sync %4.0f 30rows %4.0f]/%4.0f", a, b, b8, b8s, b8t, c);
+                return buf;
+            }
             std::snprintf(buf, sizeof buf, " %4.0f/%4.0f/%4.0f", a, b, c);
             return buf;
         };
