@@ -219,6 +219,20 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
     if (seconds > 0) repeat = 1 << 30;
     struct Ahead { int pass; size_t begin, end; };          // frames [begin, end) of a pass whose bytes were handed to jsp_prefetch
     std::deque<Ahead> ahead;
+    // A file that fits in ONE range and is played over and over: the next pass's range is the very bytes this pass is decoding from, and a frame
+    // takes the NEWEST copy of its bytes (jsp_prefetch's rule) — so every pass would wait for an upload issued at its own start.  A player that reads
+    // ahead has the next stretch of its file in ANOTHER buffer: passes alternate between two pinned copies of the file, the copy for pass p + 1 travels
+    // while pass p is decoded from the other one.
+    uint8_t* alt = nullptr;
+    struct AltFree { uint8_t*& p; ~AltFree() { if (p) jsp_host_free(p); } } alt_free{alt};
+    if (g_prefetch_bytes && clip.kind != JSP_CODEC_SCREENPRESSOR && !clip.frames.empty() && (repeat > 1 || seconds > 0 || warmup > 0)) {
+        const size_t lo = clip.frames.front().first, hi = clip.frames.back().first + clip.frames.back().second;
+        if (hi - lo <= g_prefetch_bytes) {
+            alt = static_cast<uint8_t*>(jsp_host_alloc(clip.bytes.size() + 64));
+            if (alt) std::memcpy(alt, clip.bytes.data(), clip.bytes.size());
+        }
+    }
+    auto base = [&](int pass) -> const uint8_t* { return alt && (pass & 1) ? alt : clip.bytes.data(); };
     auto fetch = [&](int pass, size_t i0) {
         const size_t lo = clip.frames[i0].first;
         size_t j = i0, hi = lo;
@@ -226,7 +240,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
             hi = clip.frames[j].first + clip.frames[j].second;
             ++j;
         }
-        if (jsp_prefetch(dec, clip.bytes.data() + lo, hi - lo) != 0) std::fprintf(stderr, "jsp_prefetch: %s\n", jsp_last_error());
+        if (jsp_prefetch(dec, base(pass) + lo, hi - lo) != 0) std::fprintf(stderr, "jsp_prefetch: %s\n", jsp_last_error());
         ahead.push_back({pass, i0, j});
     };
     for (int rep = -warmup; rep < repeat && !failed && !timed_out; ++rep) {
@@ -250,7 +264,7 @@ long play_pipelined(const Clip& clip, int depth, int repeat, bool quiet, int war
                     else if (rep + 1 < repeat) fetch(b.pass + 1, 0);
                 }
             }
-            const uint8_t* src = clip.bytes.data() + clip.frames[i].first;
+            const uint8_t* src = base(rep) + clip.frames[i].first;
             const size_t len = clip.frames[i].second;
             const bool key = frame_is_key(clip, dec, i);
             int32_t* prev = jsp_previous_frame(dec);          // as of the last submitted frame

@@ -199,18 +199,25 @@ __device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFF
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
-__global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
-                                                            int band_rows, int nspans, int win_cap, int tile_fastest) {
+// Launch shape (round 5): the waves of a band's neighbouring spans share a WORKGROUP — up to eight waves side by side in the row, nothing between them but
+// the CU they run on: no barrier, no shared LDS, each wave its own slice of the workgroup's allocation.  A row's 7 680 bytes then leave one CU at about the
+// same time; the store shape alone takes 6.6 TB/s that way against 6.3 with the waves dealt out one per workgroup (profiles/r05_front_lab_band_workgroups.txt).
+constexpr int TILE_WAVES = 8;
+__global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
+                                                            int band_rows, int nspans, int win_cap, int span_groups, int lds_words_per_wave) {
     constexpr int PPL = 4, SPAN = 64 * PPL;
-    extern __shared__ __align__(16) uint32_t lds[];
-    const IFrameArgs fa = args[tile_fastest ? blockIdx.y : blockIdx.x];
+    extern __shared__ __align__(16) uint32_t lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    uint32_t* lds = lds_all + (size_t)wave * lds_words_per_wave;
+    const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
-    const int tile = tile_fastest ? blockIdx.x : blockIdx.y;
-    const int band = tile / nspans, span = tile - band * nspans;
+    const int band = (int)blockIdx.y / span_groups, span = ((int)blockIdx.y - band * span_groups) * TILE_WAVES + wave;
+    if (span >= nspans) return;
+    const int tile = band * nspans + span;
     const int yb = band * band_rows;
     if (yb >= Y) return;
     const int ye = yb + band_rows < Y ? yb + band_rows : Y;
-    const int lane = threadIdx.x;
+    const int lane = (int)threadIdx.x & 63;
     const int xs = span * SPAN;                       // first column of the span
     const int x0 = xs + lane * PPL;
     const bool active = x0 < X;                       // X % 4 == 0: an active lane owns 4 pixels
@@ -244,11 +251,10 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the word itself (colour / addend in
     // its low 24 bits), its low 7 bits per byte, and the two masks that pick the pixel's starting value — the pixel to the upper
     // left, the pixel above, or nothing (a constant).  A row that repeats the layout of the row above keeps all of it.
-    uint32_t d24[PPL] = {0, 0, 0, 0}, dlo[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
-    const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // the lanes below this one
+    uint32_t d24[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
     // window: rows [y, y + n) whose records fit in win_cap (at most 63 rows: a window's index entries live one per lane).  A
     // single row with more records than that (more than one run every other pixel) is scattered straight from global memory.
-    constexpr int WMAX = 5;                                    // win_cap <= 128 * WMAX - 2 (tile_plan): a lane fetches two records per load
+    constexpr int WMAX = 4;                                    // win_cap <= 128 * WMAX - 2 (tile_plan): a lane fetches two records per load
     // The window's loads are written as asm and waited for BY COUNT.  A wave's loads and stores share one in-order counter
     // (vmcnt): the compiler, seeing loads whose results are used after a loop of row stores, waits for vmcnt(0) — every window
     // then also waited for the acknowledgement of all its own row stores, 2-3 us a dozen times per tile.  Issued as asm the
@@ -261,16 +267,14 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
     // instead of 0.47 (profiles/r04_sp_tile_parts.txt), but the touch made it 0.49 - 0.51 through the builtin (the compiler then waits for
     // vmcnt(0) at the next LDS access) and still 0.47 - 0.49 issued as asm behind the window's loads (profiles/
     // r04_sp_tile_touch_ab.txt): what the cached build saves is the requests, not the wait for them.)
-    // ve / vl / vk: lane r = index entry / left pixel / kind counts of row (first + r); wb = the window's first record rounded down to an
+    // ve: lane r = index entry of row (first + r); wb = the window's first record rounded down to an
     // even one (two-record loads stay 8-byte aligned); wn2 = records from wb to the window's end
-    struct Window { uint32_t ve, vl, vk; uint32_t w0, wb; int n, wn2; bool direct; };
+    struct Window { uint32_t ve; uint32_t w0, wb; int n, wn2, from; bool direct; };   // (left pixels and kind counts are read again when the window begins: they need not travel a window ahead)
     auto plan_and_fetch = [&](int from) {
         Window w;
         const int k = from + lane;
         w.ve = idx[(k < ye ? k : ye) - yb];
-        const uint2 lk = left[(k < ye ? k : ye - 1) - yb];
-        w.vl = lk.x;
-        w.vk = lk.y;
+        w.from = from;
         w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ve) & OFF;
         w.wb = w.w0 & ~1u;
         const bool fits = lane >= 1 && k <= ye && (int)((w.ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
@@ -315,6 +319,13 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         // every wait also waited for the frame stores in front of it (loads and stores share the counter); a tile has a
         // dozen windows.  Now a window costs one wait for the stores behind its loads.
         const Window cw = nw;
+        uint32_t cw_vl, cw_vk;                                 // lane r = left pixel / kind counts of row (first + r)
+        {
+            const int k = cw.from + lane;
+            const uint2 lk = left[(k < ye ? k : ye - 1) - yb];
+            cw_vl = lk.x;
+            cw_vk = lk.y;
+        }
         settle_window(rows_since_fetch);
         {
             const int npairs = (cw.wn2 + 1) >> 1;
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
         uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, 1);
         {
             const int nfirst = (int)((e1 & OFF) - cw.w0);
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cw.vk, 0);
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cw_vk, 0);
             const uint32_t nc = c0 & 0xFFFFu, nca = nc + (c0 >> 16);
             if (cw.direct) {
                 for (int r = lane; r < nfirst; r += 64) scatter(load1_global(grecs + cw.w0 + r), r, nc, nca);
@@ -346,10 +357,10 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
             const bool more = r + 1 < cw.n;
             const uint32_t e2 = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2) : e1;   // (r + 2 <= n <= 63)
             const bool repeat = (e0 & kRowRepeats) != 0u;                  // (uniform) no records: the words of the row above stay
-            const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw.vl, r);
+            const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw_vl, r);
             const int n_next = (int)((e2 & OFF) - (e1 & OFF));             // records of the next row (0 past the window's last)
             const int next_at = (int)((e1 & OFF) - cw.wb);
-            const uint32_t cn = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.vk, r + 1) : 0u;   // the next row's kind counts
+            const uint32_t cn = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw_vk, r + 1) : 0u;   // the next row's kind counts
             const uint32_t nc = cn & 0xFFFFu, nca = nc + (cn >> 16);
             uint32_t nrec = 0;
             if (lane < n_next) nrec = win[next_at + lane];
@@ -365,14 +376,16 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
                 // the word in force at this lane's first pixel: the last one of the nearest lane to the left that has any (lane 0
                 // always has h[0]: a record starts every span; its own `below` is empty and whatever it fetches is not used)
                 const unsigned long long seen = __ballot(last != 0u);
-                const uint32_t below_lo = (uint32_t)seen & lt_lo, below_hi = (uint32_t)(seen >> 32) & lt_hi;
+                // the lanes BELOW this one that have a word: the set shifted up by (64 - lane), so that this lane's own bit and everything above fall out
+                // (lane 0: its result is not used; a shift by 64 leaves whatever it leaves)
+                const unsigned long long below = seen << ((64 - lane) & 63);
+                const uint32_t below_lo = (uint32_t)below, below_hi = (uint32_t)(below >> 32);
                 const uint32_t lead = min(ffbh(below_hi), ffbh(below_lo) + 32u);   // leading zeros of the 64-bit set (v_ffbh: all ones for 0, which loses the min)
-                uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(~lead << 2), (int)last);   // lane 63 - lead (the instruction looks at address bits 7:2 only)
+                uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1 - (int)lead) << 2, (int)last);   // the nearest lane below with a word: lane - 1 - lead (the instruction looks at address bits 7:2 only)
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) {
                     w = h[j] ? h[j] : w;
                     d24[j] = w;
-                    dlo[j] = w & 0x007F7F7Fu;
                     m_above[j] = (uint32_t)((int32_t)(w << 7) >> 31);   // kTileAbove
                     m_left[j] = (uint32_t)((int32_t)(w << 6) >> 31);    // kTileAboveLeft
                 }
@@ -383,7 +396,7 @@ __global__ __launch_bounds__(64) void sp_iframe_tile_kernel(const IFrameArgs* __
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
                 const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
-                q[j] = ((base & 0x007F7F7Fu) + dlo[j]) ^ ((base ^ d24[j]) & 0x00808080u);
+                q[j] = ((base & 0x007F7F7Fu) + (d24[j] & 0x007F7F7Fu)) ^ ((base ^ d24[j]) & 0x00808080u);   // (the word's low 7 bits per byte masked here, not kept: a register per pixel less)
             }
             if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));   // (nontemporal: same time, measured)
 #pragma unroll
@@ -867,7 +880,7 @@ TilePlan tile_plan(const Geometry& g, int band_rows) {
     const size_t budget = 4608 / 4;
     size_t cap = budget > fixed + 2 ? (budget - fixed - 2) & ~size_t(1) : 0;
     if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
-    if (cap > 638) cap = 638;                                  // the kernel fetches a window with five two-record loads per lane (640 records, one may be the pad in front)
+    if (cap > 510) cap = 510;                                  // the kernel fetches a window with four two-record loads per lane (512 records, one may be the pad in front)
     t.win_cap = (int)cap;
     t.lds = 4 * (fixed + cap + 2);
     return t;
@@ -877,10 +890,14 @@ void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframe
     if (nframes <= 0) return;
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
-    const char* e = std::getenv("JSP_SP_TILE_FASTEST");                 // lab: which index runs fastest in the launch order (read at every launch)
-    const int tile_fastest = e && std::atoi(e) != 0 && nframes <= 65535;   // (frames fastest: 0.616 of 8 TB/s, tiles fastest 0.573, same buffers; rotating the bands per frame: no change)
-    const dim3 grid = tile_fastest ? dim3(bands * t.nspans, nframes) : dim3(nframes, bands * t.nspans);
-    hipLaunchKernelGGL(sp_iframe_tile_kernel, grid, dim3(64), t.lds, stream, d_args, g.X, g.Y, t.rows, t.nspans, t.win_cap, tile_fastest);
+    const int groups = (t.nspans + TILE_WAVES - 1) / TILE_WAVES;   // workgroups per band: eight neighbouring spans each (1080p: one)
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    });
+    // frames fastest in the launch order (0.616 of 8 TB/s against 0.573 with tiles fastest, same buffers, round 3)
+    hipLaunchKernelGGL(sp_iframe_tile_kernel, dim3(nframes, bands * groups), dim3(64 * TILE_WAVES), t.lds * TILE_WAVES, stream, d_args, g.X, g.Y, t.rows, t.nspans,
+                       t.win_cap, groups, (int)(t.lds / 4));
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,
