@@ -143,34 +143,52 @@ JSP_LANE_FN Masks build_masks(const uint32_t (&w)[LS / 2 + 1], uint32_t nvalid) 
 }
 
 // blocks a special slot covers, << 4 (the tables keep the exit slot in their low 4 bits)
+// (`w`: the lane's words WHERE THEY LIE — LDS in the kernel —, read only here: special slots are one word in a few hundred, and the table pass need
+// not keep all LS / 2 + 1 words of the lane in registers for them)
 template <int LS>
-JSP_LANE_FN uint32_t special_count16(const uint32_t (&w)[LS / 2 + 1], const Masks& m, int s) {
+JSP_LANE_FN uint32_t special_count16(const uint32_t* w, const Masks& m, int s) {
     const uint32_t word = (w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu, n = word & 0x3FFu;
     const uint32_t cnt = n ? n : REST_OF_FRAME;
     return ((m.K >> s) & 1u) ? cnt << 4 : 0u;
 }
 
+// Left alone the compiler computes every step's two sign masks and its addend FIRST — 3 x 32 values alive at once — and the dependent chain afterwards: that
+// alone makes msv1_fused_kernel a 111-VGPR kernel (four workgroups per CU).  An empty volatile asm that "rewrites" a step's result and the three masks the next
+// step reads keeps every step to itself: 42 VGPRs (52 fenced every 8 steps), five workgroups per CU (LDS then bounds it) — and no faster: on a quiet box
+// all-8-colour 0.680 / 0.675 -> 0.667 / 0.669, all-solid 0.893 / 0.857 -> 0.858 / 0.827, M1 and inter frames the same, 8-bit +1.5 % (profiles/
+// r05_fused_lane_table_fence_ab.txt); on two noisy boxes nothing consistent (r05_fused_fence_variants_noisy_box*.txt).  What the hoisting buys in
+// instruction-level parallelism is worth what the fifth workgroup is.  JSP_LANE_FENCE_EVERY = steps between fences; 64 = none (the product).
+#ifndef JSP_LANE_FENCE_EVERY
+#define JSP_LANE_FENCE_EVERY 64
+#endif
+#if defined(JSP_LANES_HOST)
+#define JSP_LANE_SCHED_FENCE(v, a, b, c) do { } while (0)
+#else
+#define JSP_LANE_SCHED_FENCE(v, a, b, c) asm volatile("" : "+v"(v), "+v"(a), "+v"(b), "+v"(c))
+#endif
 // The 9-entry table of the lane: tab[e] = exit slot (0..8, relative to the next lane's first slot) | blocks << 4 of the
 // chain that enters at slot e.  `zw`: the OR of Z over the wave (any superset works: it only gates the special path).
 template <int BITS, int LS>
-JSP_LANE_FN void lane_table(const uint32_t (&w)[LS / 2 + 1], const Masks& m, uint32_t zw, uint32_t (&tab)[9]) {
+JSP_LANE_FN void lane_table(const uint32_t* w, const Masks& m, uint32_t zw, uint32_t (&tab)[9]) {
     constexpr int MID = BITS == 16 ? 2 : 1, LONG = BITS == 16 ? 8 : 4;     // window index of slot + 3 / + 9 (8-bit: + 2 / + 5)
     uint32_t dw[9];                                                         // dw[k] = value of slot s + 1 + k
+    uint32_t fM = m.M, fL = m.L, fZ = m.Z;                                  // (the masks the steps read, threaded through the fences)
 #pragma unroll
     for (int k = 0; k < 9; ++k) dw[k] = (uint32_t)k;
 #define JSP_LANE_STEP(S)                                                                                     \
     {                                                                                                        \
-        const uint32_t mm = sign_mask_c<S>(m.M), ml = sign_mask_c<S>(m.L);                                   \
+        const uint32_t mm = sign_mask_c<S>(fM), ml = sign_mask_c<S>(fL);                                     \
         uint32_t nx = (dw[MID] & mm) | (dw[0] & ~mm);                                                        \
         nx = (dw[LONG] & ml) | (nx & ~ml);                                                                   \
         uint32_t add = 16u;                                                                                  \
         if (zw & (1u << S)) {                                                                                \
-            const uint32_t mz = sign_mask_c<S>(m.Z);                                                         \
+            const uint32_t mz = sign_mask_c<S>(fZ);                                                          \
             add = (special_count16<LS>(w, m, S) & mz) | (16u & ~mz);                                         \
         }                                                                                                    \
         const uint32_t v = sat_add(nx, add);                                                                 \
         dw[8] = dw[7]; dw[7] = dw[6]; dw[6] = dw[5]; dw[5] = dw[4]; dw[4] = dw[3]; dw[3] = dw[2]; dw[2] = dw[1]; dw[1] = dw[0]; \
         dw[0] = v;                                                                                           \
+        if (((S) & (JSP_LANE_FENCE_EVERY - 1)) == 0) JSP_LANE_SCHED_FENCE(dw[0], fM, fL, fZ);                \
     }
     if (LS == 32) {
         JSP_LANE_STEP(31) JSP_LANE_STEP(30) JSP_LANE_STEP(29) JSP_LANE_STEP(28) JSP_LANE_STEP(27) JSP_LANE_STEP(26) JSP_LANE_STEP(25) JSP_LANE_STEP(24)

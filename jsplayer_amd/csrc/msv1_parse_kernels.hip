@@ -446,7 +446,7 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
     constexpr bool PREFIX = MODE == 0 || MODE == 4;
     constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TAB_W = PWG * 9 + 16, ENTER_W = PREFIX ? 4 : LOOKBACK_BATCH * 9 + 4;
     static_assert(TAB_W * 2 >= FSTAGE, "staging window must fit in the tables' space");
-    __shared__ __align__(16) uint32_t arena[BYTES_W + TAB_W + ENTER_W];
+    __shared__ __align__(16) uint32_t arena[BYTES_W + TAB_W + ENTER_W + JSP_FUSED_LDS_PAD];
     __shared__ uint32_t s_pal[BITS == 8 ? 256 : 1];
     __shared__ uint32_t s_entry, s_root[16], s_seg[PREFIX ? 1 : LOOKBACK_SEGS][9];
     __shared__ uint32_t s_grp[PWG / 64][7][16], s_wav[PWG / 64][16];   // (16 per row: a saturated value indexes entry 15, see msv1_lanes.h)
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
 #pragma unroll
         for (int i = 0; i < LS / 2 + 1; ++i) w[i] = mine_w[i];
         masks = lanes::build_masks<BITS, LS>(w, r.frame_end > p0 ? (r.frame_end - p0) >> 1 : 0u);
-        lanes::lane_table<BITS, LS>(w, masks, wave_or(masks.Z), tab);
+        lanes::lane_table<BITS, LS>(mine_w, masks, wave_or(masks.Z), tab);   // (special slots read their word from LDS: `w` is dead from here)
 #pragma unroll
         for (int e = 0; e < 9; ++e) tabs[tid * 9 + e] = tab[e];
     }

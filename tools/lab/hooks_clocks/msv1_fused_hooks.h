@@ -16,6 +16,9 @@
 #ifndef JSP_FUSED_WAVES
 #define JSP_FUSED_WAVES 4
 #endif
+#ifndef JSP_FUSED_LDS_PAD
+#define JSP_FUSED_LDS_PAD 0
+#endif
 #ifndef JSP_FUSED_WAVES_TABLES
 #define JSP_FUSED_WAVES_TABLES 4
 #endif
