@@ -279,6 +279,50 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     };
+    if (getenv("LAB_TSWEEP")) {   // round 5: how the fronts shape depends on the extent a workgroup writes (T blocks = T x 64 bytes), tile-major and frame-major, on a chunked pool and on one allocation
+        const int NC = F / 16 * 4;
+        std::vector<uint32_t*> chunk(NC);
+        for (int c = 0; c < NC; ++c) { CK(hipMalloc(&chunk[c], FRAME_BYTES * 16)); CK(hipMemset(chunk[c], 0, FRAME_BYTES * 16)); }
+        uint32_t* one;
+        CK(hipMalloc(&one, FRAME_BYTES * F));
+        CK(hipMemset(one, 0, FRAME_BYTES * F));
+        std::vector<uint32_t*> dealt, contiguous(F);
+        for (int slot = 0; slot < 16; ++slot) for (int c = 0; c < F / 16; ++c) dealt.push_back(chunk[c * 4] + (size_t)slot * X * Y);
+        for (int i = 0; i < F; ++i) contiguous[i] = one + (size_t)i * X * Y;
+        for (int which = 0; which < 2; ++which) {
+            const std::vector<uint32_t*>& fr = which ? contiguous : dealt;
+            CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * F, hipMemcpyHostToDevice));
+            printf("%s:", which ? "one allocation, frames back to back" : "16-frame chunks, every fourth, frames dealt");
+            for (int T : {256, 512, 1024, 2048, 4096, 8192, 32768}) for (int tm : {1, 0}) {
+                const int tpf = (NBLK + T - 1) / T;
+                auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * F), dim3(256), 0, 0, d_table, F, T, tpf, tm); };
+                launch();
+                CK(hipDeviceSynchronize());
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf(" T%d%s %4.0f |", T, tm ? "t" : "f", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+            }
+            printf(" GB/s (t = tile-major, f = frame-major)\n");
+        }
+        {
+            const size_t n16 = FRAME_BYTES * F / 16;
+            auto fill = [&] { hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (u32x4*)one, n16); };
+            fill();
+            CK(hipDeviceSynchronize());
+            float ms = 0;
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 3; ++i) fill();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("plain fill %4.0f GB/s\n", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+        }
+        return 0;
+    }
     if (argc > 2 && getenv("LAB_SUBSETS")) {   // round 5: is "fast" a property of WHICH frames are written together?  2F single-frame allocations (or chunks of LAB_CH frames), random F-subsets, per-frame scores
         const int CH = getenv("LAB_CH") ? atoi(getenv("LAB_CH")) : 1, OVER = atoi(argv[2]);      // OVER x F frames allocated
         const int NA = F * OVER / CH;                                                              // allocations
