@@ -239,6 +239,27 @@ __global__ __launch_bounds__(512) void band_wg_table_kernel(uint32_t* const* __r
     }
 }
 
+
+// the fronts shape with NONTEMPORAL row stores (what msv1_fused_kernel issues), and with plain stores but 8 KB per lane visit order reversed (rows 3..0)
+__global__ __launch_bounds__(256) void front_nt_kernel(uint32_t* const* __restrict__ frames, int nframes, int T, int tiles_per_frame, int nt) {
+    const int j = blockIdx.x / nframes, f = blockIdx.x - j * nframes;
+    uint32_t* dst = frames[f];
+    const int b0 = j * T;
+    for (int r = 0; r < T; r += 256) {
+        const int blk = b0 + r + (int)threadIdx.x;
+        if (blk < NBLK) {
+            const int by = blk / NBX, bx = blk - by * NBX;
+            uint32_t* p = dst + (size_t)by * 4 * X + bx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const u32x4 v = u32x4{(uint32_t)blk, 1u, 2u, (uint32_t)y};
+                if (nt) __builtin_nontemporal_store(v, (gu32x4*)(p + (size_t)y * X));
+                else *(gu32x4*)(p + (size_t)y * X) = v;
+            }
+        }
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -307,6 +328,19 @@ int main(int argc, char** argv) {
                 printf(" T%d%s %4.0f |", T, tm ? "t" : "f", (double)F * FRAME_BYTES * 3 / ms / 1e6);
             }
             printf(" GB/s (t = tile-major, f = frame-major)\n");
+            for (int nt : {0, 1}) {
+                const int T = 8192, tpf = (NBLK + T - 1) / T;
+                auto launch = [&] { hipLaunchKernelGGL(front_nt_kernel, dim3(tpf * F), dim3(256), 0, 0, d_table, F, T, tpf, nt); };
+                launch();
+                CK(hipDeviceSynchronize());
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("   T8192 tile-major, %s stores: %4.0f GB/s\n", nt ? "nontemporal" : "plain", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+            }
         }
         {
             const size_t n16 = FRAME_BYTES * F / 16;
