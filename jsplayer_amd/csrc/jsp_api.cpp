@@ -1,6 +1,7 @@
 // extern "C" surface of libjsplayer_amd.so (declared in include/jsplayer_amd.h).
 #include <algorithm>
 #include <numeric>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <mutex>
@@ -253,6 +254,12 @@ int jsp_decompress_p(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, i
 
 // ---- pool ---------------------------------------------------------------------------------
 
+namespace {
+// Which of the older forms won the last probe of this process (-1: a chunked candidate, or nothing yet): boards differ in which form their memory likes,
+// a board does not change its mind between two pools — the next pool tries that form first instead of finding it again behind seven others.
+std::atomic<int> g_pool_form_hint{-1};
+}  // namespace
+
 jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
     try {
         if (width <= 0 || height <= 0 || nbuf <= 0) throw std::runtime_error("bad pool shape");
@@ -284,7 +291,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         const bool probe = nbuf >= kProbeFrom && (width & 3) == 0 && (height & 3) == 0 && (size_t)nbuf * (size_t)((width / 4) * (height / 4) + 8191) / 8192 * 256 < (1ull << 32) &&   // (the probe: one launch, fewer than 2^32 lanes)
                            !(env && std::atoi(env) == 0);
         if (probe) {
-            struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; };
+            struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; int form = -1; };   // form: -1 chunked, 0 .. 2 the older forms
             std::vector<Candidate> cands;
             std::vector<void*> run;                            // the run of chunk allocations behind the first candidates (spread x the pool)
             auto release = [](Candidate& c) { for (void* d : c.allocs) (void)hipFree(d); c.allocs.clear(); };
@@ -321,9 +328,59 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                 // So: four times the chunks the pool needs, allocated in one run; candidate k = every fourth chunk starting with the k-th, its frames
                 // DEALT round-robin over the chunks (frame i and frame i + 1 in different chunks, >= 0.5 GB apart); the first candidate that takes what
                 // a plain fill takes is kept, the other chunks are given back.  Only when none of the four comes near do the older forms get a try.
+                auto make_old = [&](int form, Candidate& c) {   // 0: two frames per allocation, 1: all frames in one allocation, 2: an allocation per frame
+                    bool ok = true;
+                    if (form == 1) {
+                        void* d = nullptr;
+                        ok = hipMalloc(&d, bytes * (size_t)nbuf) == hipSuccess;
+                        if (ok) { c.allocs.push_back(d); for (int i = 0; i < nbuf; ++i) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)i * width * height); }
+                    } else if (form == 0) {
+                        for (int i = 0; i < nbuf && ok; i += 2) {
+                            void* d = nullptr;
+                            const int k = i + 1 < nbuf ? 2 : 1;
+                            ok = hipMalloc(&d, bytes * k) == hipSuccess;
+                            if (ok) { c.allocs.push_back(d); for (int q = 0; q < k; ++q) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)q * width * height); }
+                        }
+                    } else {
+                        for (int i = 0; i < nbuf && ok; ++i) {
+                            void* d = nullptr;
+                            ok = hipMalloc(&d, bytes) == hipSuccess;
+                            if (ok) { c.allocs.push_back(d); c.frames.push_back(static_cast<int32_t*>(d)); }
+                        }
+                    }
+                    if (!ok) { (void)hipGetLastError(); release(c); c.frames.clear(); return false; }
+                    // consecutive frames must not be neighbours in memory (see below): frame i takes slot (i x K) mod n, K coprime to n
+                    int K = 1;
+                    for (int cand : {17, 19, 23, 29, 31, 37, 41, 43})
+                        if (cand < nbuf && std::gcd(cand, nbuf) == 1) { K = cand; break; }
+                    if (K > 1) {
+                        std::vector<int32_t*> in_order(c.frames.size());
+                        for (int i = 0; i < nbuf; ++i) in_order[i] = c.frames[(size_t)((long long)i * K % nbuf)];
+                        c.frames.swap(in_order);
+                    }
+                    JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
+                    c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
+                    c.form = form;
+                    p->tried.push_back(c.rate);
+                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, form == 1 ? "one allocation" : form == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
+                    return true;
+                };
+                int hint = g_pool_form_hint.load();
+                if (const char* f = std::getenv("JSP_POOL_PROBE_FORM")) { const int v = std::atoi(f); if (v >= 0 && v < 3) hint = v; }   // (start with that older form: 0 two frames per allocation, 1 one allocation, 2 one per frame)
+                bool settled = false;
+                if (hint >= 0 && hint < 3) {                   // the form this board liked last time, first
+                    Candidate c;
+                    if (make_old(hint, c)) {
+                        cands.push_back(std::move(c));
+                        p->held_peak = std::max<uint64_t>(p->held_peak, one);
+                        best = 0;
+                        settled = yardstick > 0 && cands[0].rate >= 0.985 * yardstick;
+                    }
+                }
                 const int kChunkFrames = 16;
                 int spread = 4;
-                while (spread > 1 && (uint64_t)spread * one > hold_limit) --spread;
+                if (settled) spread = 1;                       // (nothing more to try)
+                while (spread > 1 && (uint64_t)(spread + (int)cands.size()) * one > hold_limit) --spread;
                 const int nch = (nbuf + kChunkFrames - 1) / kChunkFrames;
                 auto chunk_frames = [&](int ch) { return std::min(kChunkFrames, nbuf - ch * kChunkFrames); };
                 if (spread > 1) {
@@ -334,7 +391,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         if (ok) run.push_back(d);
                     }
                     if (!ok) { (void)hipGetLastError(); for (void* d : run) (void)hipFree(d); run.clear(); }
-                    else p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)spread * one);
+                    else p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)(spread + (int)cands.size()) * one);
                 }
                 // Which chunks of the run a candidate takes.  "Every fourth" is not always the answer: in some sessions all four such candidates are slow
                 // (5.7 - 6.4 TB/s) while a form made of many small allocations is fast (profiles/r05_q_bench_all.jsonl: candidates_GBs) — the run's chunks
@@ -360,7 +417,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     }
                     return ids;
                 };
-                int spread_best = -1;
+                int spread_best = -1, chunked = -1;            // chunked: where the chunked candidate stands among `cands`
                 double spread_rate = 0;
                 std::vector<int32_t*> dealt;
                 auto deal = [&](const std::vector<int>& ids) {  // the candidate's frames, dealt round-robin over its chunks
@@ -369,7 +426,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         for (int ch = 0; ch < nch; ++ch)
                             if (slot < chunk_frames(ch)) dealt.push_back(static_cast<int32_t*>(run[(size_t)ids[(size_t)ch]]) + (size_t)slot * width * height);
                 };
-                for (int k = 0; k < 4 && k < kCandidates && !run.empty(); ++k) {
+                for (int k = 0; k < 4 && (int)p->tried.size() < kCandidates && !run.empty(); ++k) {
                     deal(pick(k));
                     JSP_HIP(hipMemcpy(d_table, dealt.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
                     const double rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
@@ -393,62 +450,26 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     run.clear();
                     c.rate = spread_rate;
                     cands.push_back(std::move(c));
-                    best = 0;
+                    chunked = (int)cands.size() - 1;
+                    // (an older form — its frames lie densely — must beat the chunked candidate by 3 % to stand before it: the probe's shape does not mind density,
+                    // the key-frame kernel's does, profiles/r05_front_lab_frame_order.txt)
+                    if (best < 0 || cands[chunked].rate * 1.03 >= cands[best].rate) best = chunked;
                 }
-                const int tried_spread = (int)p->tried.size();
-                const bool spread_good = best == 0 && (yardstick <= 0 || cands[0].rate >= 0.95 * yardstick);
-                for (int a = 0; a < kCandidates - tried_spread && !spread_good; ++a) {
+                const bool good_enough = settled || (chunked >= 0 && best == chunked && (yardstick <= 0 || cands[chunked].rate >= 0.95 * yardstick));
+                for (int a = 0; (int)p->tried.size() < kCandidates && !good_enough; ++a) {
                     if (best >= 0 && (uint64_t)(cands.size() + 1) * one > hold_limit) break;   // holding another candidate would pass the limit
                     Candidate c;
-                    bool ok = true;
-                    if (a % 3 == 1) {                          // all frames in one allocation, back to back
-                        void* d = nullptr;
-                        ok = hipMalloc(&d, bytes * (size_t)nbuf) == hipSuccess;
-                        if (ok) { c.allocs.push_back(d); for (int i = 0; i < nbuf; ++i) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)i * width * height); }
-                    } else if (a % 3 == 0) {                   // two frames per allocation
-                        for (int i = 0; i < nbuf && ok; i += 2) {
-                            void* d = nullptr;
-                            const int k = i + 1 < nbuf ? 2 : 1;
-                            ok = hipMalloc(&d, bytes * k) == hipSuccess;
-                            if (ok) { c.allocs.push_back(d); for (int q = 0; q < k; ++q) c.frames.push_back(static_cast<int32_t*>(d) + (size_t)q * width * height); }
-                        }
-                    } else {                                   // an allocation per frame
-                        for (int i = 0; i < nbuf && ok; ++i) {
-                            void* d = nullptr;
-                            ok = hipMalloc(&d, bytes) == hipSuccess;
-                            if (ok) { c.allocs.push_back(d); c.frames.push_back(static_cast<int32_t*>(d)); }
-                        }
-                    }
-                    if (!ok) {                                 // the memory ran out while candidates were being held: the best so far it is
-                        (void)hipGetLastError();
-                        release(c);
+                    const int form = (a + (hint >= 0 ? hint + 1 : 0)) % 3;    // (the hinted form has had its first try above)
+                    if (!make_old(form, c)) {                  // the memory ran out while candidates were being held: the best so far it is
                         if (best >= 0) break;
                         throw std::runtime_error("out of device memory for the frame pool");
                     }
-                    {   // consecutive frames must not be neighbours in memory (see above): frame i takes slot (i x K) mod n, K coprime to n
-                        int K = 1;
-                        for (int cand : {17, 19, 23, 29, 31, 37, 41, 43})
-                            if (cand < nbuf && std::gcd(cand, nbuf) == 1) { K = cand; break; }
-                        if (K > 1) {
-                            std::vector<int32_t*> in_order(c.frames.size());
-                            for (int i = 0; i < nbuf; ++i) in_order[i] = c.frames[(size_t)((long long)i * K % nbuf)];
-                            c.frames.swap(in_order);
-                        }
-                    }
-                    JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
-                    if (a == 1 && yardstick <= 0) yardstick = jsp::pool_fill_rate(reinterpret_cast<uint32_t*>(c.allocs[0]), bytes * (size_t)nbuf);
-                    c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
-                    p->tried.push_back(c.rate);
-                    if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", tried_spread + a, a % 3 == 1 ? "one allocation" : a % 3 == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     cands.push_back(std::move(c));
                     p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)cands.size() * one);
-                    // (an older form — its frames lie densely — must beat the chunked candidate by 3 % to replace it: the probe's shape does not mind density, the
-                    // key-frame kernel's does, profiles/r05_front_lab_frame_order.txt)
-                    if (best < 0 || cands.back().rate > cands[best].rate * (best == 0 && tried_spread > 0 ? 1.03 : 1.0)) best = (int)cands.size() - 1;
-                    if ((a >= 1 || yardstick > 0) && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill
-                                                                                   // takes, 6.9 - 7.0 TB/s; the others 5.4 - 6.5; one candidate in
-                                                                                   // six is fast in a bad session, the first one in a good one)
+                    if (best < 0 || cands.back().rate > cands[best].rate * (best == chunked ? 1.03 : 1.0)) best = (int)cands.size() - 1;
+                    if (yardstick > 0 && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill takes)
                 }
+                if (best >= 0) g_pool_form_hint.store(cands[best].form);
             } catch (...) {
                 for (auto& c : cands) release(c);
                 for (void* d : run) (void)hipFree(d);

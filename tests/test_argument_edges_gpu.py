@@ -135,6 +135,19 @@ def test_measure_h2d_and_the_bounded_pool_probe(monkeypatch):
         assert pool.attempts == 1 and pool.held_bytes == 32 * 1920 * 1080 * 4 == pool.hold_limit
     finally:
         pool.close()
+    # the form a board liked last time is tried first (here: said through the environment); whatever wins, the pool is whole
+    monkeypatch.delenv("JSP_POOL_PROBE_HOLD_GB")
+    monkeypatch.setenv("JSP_POOL_PROBE_MAX", "3")
+    for form in ("0", "1", "2"):
+        monkeypatch.setenv("JSP_POOL_PROBE_FORM", form)
+        pool = FramePool(1920, 1080, 40)
+        try:
+            assert 1 <= pool.attempts <= 3 and len(pool.tried_rates) == pool.attempts and pool.store_rate == max(pool.tried_rates) or pool.store_rate > 0
+            ptrs = sorted(f.data_ptr() for f in pool.frames)
+            assert len(set(ptrs)) == 40 and all(b - a >= 1920 * 1080 * 4 for a, b in zip(ptrs, ptrs[1:]))
+        finally:
+            pool.close()
+    monkeypatch.delenv("JSP_POOL_PROBE_FORM")
     small = FramePool(320, 240, 9)
     try:
         assert small.attempts == 0 and small.store_rate == 0 and small.probe_ms == 0 and small.held_bytes == 0
