@@ -358,8 +358,13 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         for (int i = 0; i < nbuf; ++i) in_order[i] = c.frames[(size_t)((long long)i * K % nbuf)];
                         c.frames.swap(in_order);
                     }
-                    JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
-                    c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
+                    try {
+                        JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
+                        c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
+                    } catch (...) {
+                        release(c);                            // (not among `cands` yet: nobody else would give its memory back)
+                        throw;
+                    }
                     c.form = form;
                     p->tried.push_back(c.rate);
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, form == 1 ? "one allocation" : form == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
