@@ -101,7 +101,8 @@ const char* jsp_last_error(void);
  * reveals it).  The pool therefore allocates, in one run, four times the 16-frame chunks it needs, takes every fourth (candidate k: chunks k, k + 4, ...)
  * and DEALS its frames round-robin over them — buffer i and buffer i + 1 never lie in the same chunk —, measures the candidate with the kernels' store
  * shape (a few milliseconds), keeps the first that takes what a plain fill takes and gives the other chunks back; only when none of the four comes
- * near do the older forms (one allocation, two frames per allocation, one per frame — frames taken in a strided order) get a try.  Decode consecutive
+ * near do the older forms (one allocation, two frames per allocation, one per frame — frames taken in a strided order) get a try; boards differ in
+ * which form their memory likes, so the form that won the last probe of the process is tried first by the next pool.  Decode consecutive
  * frames into consecutive buffers of the pool and they are far apart.  JSP_POOL_PROBE=0 in the environment: one allocation per frame, first come — what
  * smaller pools (a player's num_buffers + 1) always get.  The probe's appetite is bounded (jsp_pool_probe_info; while it chooses it holds four times
  * the pool, or what JSP_POOL_PROBE_HOLD_GB / a quarter of the free memory allows). */
