@@ -260,6 +260,35 @@ __global__ __launch_bounds__(256) void front_nt_kernel(uint32_t* const* __restri
     }
 }
 
+
+// fresh workgroups, one BLOCK ROW each (480 blocks = 4 rows x 7 680 contiguous bytes), frame-major or row-major over the frames (what a descriptor-fed
+// block kernel with one workgroup per block row would store)
+__global__ __launch_bounds__(512) void blockrow_kernel(uint32_t* const* __restrict__ frames, int nframes, int row_major) {
+    int f, by;
+    if (row_major) { by = blockIdx.x / nframes; f = blockIdx.x - by * nframes; } else { f = blockIdx.x / (Y / 4); by = blockIdx.x - f * (Y / 4); }
+    const int bx = threadIdx.x;
+    if (bx >= NBX) return;
+    uint32_t* p = frames[f] + (size_t)by * 4 * X + bx * 4;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) *(gu32x4*)(p + (size_t)y * X) = u32x4{(uint32_t)bx, 1u, 2u, (uint32_t)y};
+}
+// fronts with workgroups of WG lanes (64 ... 1024): T blocks per workgroup, tile-major
+__global__ __launch_bounds__(1024) void front_wg_kernel(uint32_t* const* __restrict__ frames, int nframes, int T) {
+    const int WG = blockDim.x;
+    const int j = blockIdx.x / nframes, f = blockIdx.x - j * nframes;
+    uint32_t* dst = frames[f];
+    const int b0 = j * T;
+    for (int r = 0; r < T; r += WG) {
+        const int blk = b0 + r + (int)threadIdx.x;
+        if (blk < NBLK) {
+            const int by = blk / NBX, bx = blk - by * NBX;
+            uint32_t* p = dst + (size_t)by * 4 * X + bx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) *(gu32x4*)(p + (size_t)y * X) = u32x4{(uint32_t)blk, 1u, 2u, (uint32_t)y};
+        }
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -341,6 +370,34 @@ int main(int argc, char** argv) {
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 printf("   T8192 tile-major, %s stores: %4.0f GB/s\n", nt ? "nontemporal" : "plain", (double)F * FRAME_BYTES * 3 / ms / 1e6);
             }
+            printf("   workgroups of 64 / 128 / 512 / 1024 lanes (T8192 tile-major):");
+            for (int wg : {64, 128, 512, 1024}) {
+                const int T = 8192, tpf = (NBLK + T - 1) / T;
+                auto launch = [&] { hipLaunchKernelGGL(front_wg_kernel, dim3(tpf * F), dim3(wg), 0, 0, d_table, F, T); };
+                launch();
+                CK(hipDeviceSynchronize());
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf(" %4.0f", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+            }
+            printf(" | one workgroup per block row, frame-major / row-major:");
+            for (int rm : {0, 1}) {
+                auto launch = [&] { hipLaunchKernelGGL(blockrow_kernel, dim3(F * (Y / 4)), dim3(512), 0, 0, d_table, F, rm); };
+                launch();
+                CK(hipDeviceSynchronize());
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf(" %4.0f", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+            }
+            printf(" GB/s\n");
         }
         {
             const size_t n16 = FRAME_BYTES * F / 16;
