@@ -289,6 +289,14 @@ __global__ __launch_bounds__(1024) void front_wg_kernel(uint32_t* const* __restr
     }
 }
 
+
+// the same bytes as blockrow_kernel (one block row = 30 720 contiguous bytes per fresh workgroup, frame-major) written LINEARLY: lane t takes the 16-byte chunks t, t + 512, ...
+__global__ __launch_bounds__(512) void blockrow_linear_kernel(uint32_t* const* __restrict__ frames, int nframes) {
+    const int f = blockIdx.x / (Y / 4), by = blockIdx.x - f * (Y / 4);
+    u32x4* p = (u32x4*)(frames[f] + (size_t)by * 4 * X);
+    for (int c = threadIdx.x; c < X; c += 512) *(gu32x4*)(p + c) = u32x4{(uint32_t)c, 1u, 2u, 3u};   // X / 4 chunks per row x 4 rows = X chunks
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -396,6 +404,18 @@ int main(int argc, char** argv) {
                 CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 printf(" %4.0f", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+            }
+            {
+                auto launch = [&] { hipLaunchKernelGGL(blockrow_linear_kernel, dim3(F * (Y / 4)), dim3(512), 0, 0, d_table, F); };
+                launch();
+                CK(hipDeviceSynchronize());
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf(" | the block row's 30 KB written linearly: %4.0f", (double)F * FRAME_BYTES * 3 / ms / 1e6);
             }
             printf(" GB/s\n");
         }
