@@ -297,6 +297,16 @@ __global__ __launch_bounds__(512) void blockrow_linear_kernel(uint32_t* const* _
     for (int c = threadIdx.x; c < X; c += 512) *(gu32x4*)(p + c) = u32x4{(uint32_t)c, 1u, 2u, 3u};   // X / 4 chunks per row x 4 rows = X chunks
 }
 
+
+// plain linear fills of one allocation by workgroup extent: a workgroup of L lanes writes L x SPL consecutive 16-byte chunks (chunk = first + k x L + lane), workgroups in address order
+__global__ __launch_bounds__(1024) void linear_fill_kernel(u32x4* __restrict__ dst, size_t n, int spl) {
+    const size_t first = (size_t)blockIdx.x * blockDim.x * spl;
+    for (int k = 0; k < spl; ++k) {
+        const size_t i = first + (size_t)k * blockDim.x + threadIdx.x;
+        if (i < n) *(gu32x4*)(dst + i) = u32x4{(uint32_t)i, 1u, 2u, 3u};
+    }
+}
+
 // translation probe: every lane reads 4 bytes from a page of its own, pages picked by a multiplicative hash over the whole buffer;
 // `page` = distance between candidate addresses.  Bound by address translation when the mapping's fragments are small.
 __global__ __launch_bounds__(256) void page_probe_kernel(const uint32_t* __restrict__ buf, size_t npages, size_t page_words, int rounds, uint32_t* __restrict__ sink) {
@@ -431,6 +441,22 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
             printf("plain fill %4.0f GB/s\n", (double)F * FRAME_BYTES * 3 / ms / 1e6);
+            printf("linear fills of the one allocation, lanes x stores per lane (KB per workgroup):");
+            for (int L : {64, 256, 512, 1024}) for (int spl : {1, 2, 4, 8, 16}) {
+                const size_t per = (size_t)L * spl;
+                const unsigned grid = (unsigned)((n16 + per - 1) / per);
+                auto go = [&] { hipLaunchKernelGGL(linear_fill_kernel, dim3(grid), dim3(L), 0, 0, (u32x4*)one, n16, spl); };
+                go();
+                CK(hipDeviceSynchronize());
+                float ms2 = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) go();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms2, e0, e1));
+                printf(" %dx%d(%zuK) %4.0f |", L, spl, per * 16 / 1024, (double)F * FRAME_BYTES * 3 / ms2 / 1e6);
+            }
+            printf(" GB/s\n");
         }
         return 0;
     }
