@@ -41,13 +41,21 @@ struct IRun {
 // Tile layout (sp_iframe_tile_kernel): 4 bytes per record — bits 31..24 the column of the run's first pixel inside its 256-column span,
 // bits 23..0 the colour / addend.  The kind travels beside it: a row's records are stored sorted by kind (constants, "above",
 // "above-left") and the row's counts — n_const | n_above << 16 — sit next to its left pixel (FrameOut::left).  In the kernel a
-// scattered record becomes the word `value | kTileHead | kind bit`: kTileHead tells "a run starts here" from "nothing", and each of
-// the two (exclusive) predictor bits is a sign-extending bit-field extract away from being a lane mask.
-constexpr uint32_t kTileAbove = 1u << 24;       // the pixel starts from the pixel above (RUN_ABOVE)
-constexpr uint32_t kTileAboveLeft = 1u << 25;   // ... from the pixel above and one to the left (RUN_ABOVE_LEFT), kTileAbove clear
+// scattered record becomes the word `value | kTileHead | kind nibble << 24`: kTileHead tells "a run starts here" from "nothing", and the
+// nibble is what ONE multiply-add turns into the byte selector of the v_perm_b32 that picks the pixel's starting value out of
+// {pixel above-left, pixel above}: selector = nibble * 0x010101 + 0x0C020100 — bytes 0..2 of the pixel above (nibble 0), bytes 4..6 = the
+// pixel above-left (nibble 4), or 0xFF 0xFF 0xFF (nibble 13: selectors >= 13 read as 0xFF), byte 3 always zero (selector 12).  A constant
+// therefore starts from 0xFFFFFF, and its record carries the colour PLUS ONE in every byte (mod 256): 0xFF + (c + 1) = c.  All three kinds
+// are then "start value + record value, byte by byte", which is three SDWA byte adds.
 constexpr uint32_t kTileHead = 0x80000000u;
+constexpr uint32_t kTileAbove = 0x0u << 24;       // the pixel starts from the pixel above (RUN_ABOVE)
+constexpr uint32_t kTileAboveLeft = 0x4u << 24;   // ... from the pixel above and one to the left (RUN_ABOVE_LEFT)
+constexpr uint32_t kTileConst = 0xDu << 24;       // ... from 0xFFFFFF (RUN_CONST; the record holds colour + 0x010101 byte-wise)
+constexpr uint32_t kTileSelMul = 0x00010101u, kTileSelAdd = 0x0C020100u;
 inline uint32_t tile_record32(const IRun& r, uint32_t span_row_origin) {   // span_row_origin: linear index of (row, first column of the span)
-    return ((r.start - span_row_origin) << 24) | (r.word & 0x00FFFFFFu);
+    uint32_t v = r.word & 0x00FFFFFFu;
+    if ((r.word >> 24) == RUN_CONST) v = ((v & 0x007F7F7Fu) + 0x00010101u) ^ (v & 0x00808080u);   // + 1 in every byte, no carry across bytes
+    return ((r.start - span_row_origin) << 24) | v;
 }
 
 // ---- P-frame descriptors --------------------------------------------------------------------
@@ -225,6 +233,7 @@ int choose_band_rows(const Geometry& g, int nframes);
 bool iframe_tiles_ok(const Geometry& g);
 int iframe_tile_span(const Geometry& g);   // columns per tile (256 or 512): what set_iframe_layout must be given
 void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream);
+int iframe_tile_max_band_rows();        // the tallest band one wave's LDS slice can index (taller frames must be cut into bands)
 // band_rows <= 0 or >= Y: one band per frame
 void launch_iframes(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream);
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,

@@ -489,7 +489,7 @@ struct SpCodec : jsp_codec, DstColumns {
         for (const auto& f : frames) nkey += f.key ? 1 : 0;
         int band_rows = opt_band_rows >= 0 ? opt_band_rows : choose_band_rows(g, nkey);   // one cut for the whole batch
         const bool tiles = iframe_tiles_ok(st->geo);   // key frames as independent tiles (needs aligned buffers)
-        if (tiles && g.Y > 4096 && (band_rows <= 0 || band_rows > 4096)) band_rows = 4096;   // a tile's row index lives in LDS
+        if (tiles && g.Y > iframe_tile_max_band_rows() && (band_rows <= 0 || band_rows > iframe_tile_max_band_rows())) band_rows = iframe_tile_max_band_rows();   // a tile's row index and left pixels live in LDS, 12 bytes per row of the band (tile_plan, sp_kernels.hip: bands taller than ~550 rows share a workgroup among fewer waves)
         host.set_iframe_layout(band_rows, tiles ? iframe_tile_span(st->geo) : 0);
         // the key-frame compare by the host stage: only where this decoder also decoded the frame before — the stream's own decoder
         // taking one frame at a time (a group of pictures on a decoder of its own does not hold the picture before its key frame)

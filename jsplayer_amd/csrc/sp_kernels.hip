@@ -176,10 +176,6 @@ __global__ __launch_bounds__(IWG) void sp_iframe_rows_search_kernel(const IFrame
     }
 }
 
-__device__ __forceinline__ uint32_t lane_to_the_left(uint32_t v) {   // lane i gets lane i-1's value (lane 0: undefined)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-
 // Tile path: one WAVE per tile = a band of rows x a span of 256 columns (4 pixels per lane).  The host stage hands every
 // tile what crosses its borders — the row above the band (seeds) and, per row, the pixel left of the span's
 // first pixel one row up (`left`) — orders the run records tile by tile and never lets one cross a span, so
@@ -187,13 +183,20 @@ __device__ __forceinline__ uint32_t lane_to_the_left(uint32_t v) {   // lane i g
 // loop is one wave's private instruction stream: row above in registers, run words scattered through an LDS row
 // of the span, branch-free predictor.
 //
-// The kernel is bound by the instructions it issues (profiles/archive/r03_sp_iframes_tile_sq_counters.txt: a wave64 VALU
-// instruction holds its SIMD for four cycles and the row loop ran to ~110 of them per row), so everything that is the
-// same for all 64 lanes lives on the scalar unit: a window's index entries and left pixels sit one per lane in two
-// registers and each row takes its own with v_readlane (no LDS read, no address arithmetic); a record arrives as 4 bytes
-// {column inside the span, 24-bit colour / addend} (tile_record32, sp.h: half of round 4's 8-byte {offset, word} pairs), its kind is its
-// place among the row's records (sorted by kind, two scalar counts per row), and one ds_write puts `value | kTileHead | kind bit` at the
-// column; the word's two predictor bits are exclusive (kTileAbove / kTileAboveLeft), each a v_bfe_i32 away from being a lane mask.
+// The kernel is bound by the instructions it issues (a wave64 VALU instruction holds its SIMD for four cycles; traffic is 1.003 x the bytes
+// moved), so the row loop is written instruction by instruction (round 6; ~45 -> ~25 VALU on a row that repeats the layout of the row above,
+// ~75 -> ~50 on one that does not, a third of the scalar branches):
+//   * everything that is the same for all 64 lanes lives on the scalar unit: a window's index entries, left pixels and kind counts sit one per
+//     lane in three registers and each row takes its own with v_readlane — unconditionally: the entries past the window's last row are copies
+//     of its end, so "no next row" is "a next row with no records";
+//   * a record arrives as 4 bytes {column inside the span, 24-bit value} (tile_record32, sp.h), its kind is its place among the row's records
+//     (sorted by kind, two scalar counts per row), and one ds_write puts `value | kTileHead | kind nibble` at the column;
+//   * a pixel is `start value + record value`, byte by byte, for ALL kinds: ONE v_perm_b32 picks the start value out of {pixel above-left,
+//     pixel above} with a per-pixel byte selector (bytes of the one, of the other, or 0xFF for a constant — whose record carries colour + 1),
+//     three SDWA byte adds put the record's bytes on top (v_add_u32_sdwa ... dst_unused:UNUSED_PRESERVE: byte 3 stays the selector's zero):
+//     4 VALU per pixel where the mask-and-carry form took 7, and the selector is one register where the two lane masks were two;
+//   * the row is computed IN PLACE, pixel 3 first (pixel j needs the old pixel j - 1): no copy of the finished row into the "row above";
+//   * the row store takes a scalar base that advances by the pitch and a per-lane offset that never changes.
 __device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFFFFFFF for 0
     uint32_t r;
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
@@ -202,16 +205,18 @@ __device__ __forceinline__ uint32_t ffbh(uint32_t v) {   // leading zeros; 0xFFF
 // Launch shape (round 5): the waves of a band's neighbouring spans share a WORKGROUP — up to eight waves side by side in the row, nothing between them but
 // the CU they run on: no barrier, no shared LDS, each wave its own slice of the workgroup's allocation.  A row's 7 680 bytes then leave one CU at about the
 // same time; the store shape alone takes 6.6 TB/s that way against 6.3 with the waves dealt out one per workgroup (profiles/r05_front_lab_band_workgroups.txt).
-constexpr int TILE_WAVES = 8;
+// (1920 columns are 7.5 spans: the eighth wave of a 1080p workgroup runs with half its lanes masked, 6 % of the launch's issue slots.  Giving that wave the half spans
+// of two bands would need two window states on the scalar unit — every scalar of the row loop twice — and is not done.)
+constexpr int TILE_WAVES = 8;                         // at most; tall bands get fewer (tile_plan: the workgroup's LDS is waves x a tile's index)
 __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(const IFrameArgs* __restrict__ args, int X, int Y,
-                                                            int band_rows, int nspans, int win_cap, int span_groups, int lds_words_per_wave) {
+                                                            int band_rows, int nspans, int win_cap, int span_groups, int lds_words_per_wave, int waves_per_group) {
     constexpr int PPL = 4, SPAN = 64 * PPL;
     extern __shared__ __align__(16) uint32_t lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint32_t* lds = lds_all + (size_t)wave * lds_words_per_wave;
     const IFrameArgs fa = args[blockIdx.x];
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(fa.dst);
-    const int band = (int)blockIdx.y / span_groups, span = ((int)blockIdx.y - band * span_groups) * TILE_WAVES + wave;
+    const int band = (int)blockIdx.y / span_groups, span = ((int)blockIdx.y - band * span_groups) * waves_per_group + wave;
     if (span >= nspans) return;
     const int tile = band * nspans + span;
     const int yb = band * band_rows;
@@ -226,21 +231,21 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(cons
             for (int y = yb; y < ye; ++y) store4_global(dst + (size_t)y * X + x0, make_uint4(fa.colour, fa.colour, fa.colour, fa.colour));
         return;
     }
-    uint32_t* head = lds;                             // SPAN words, at LDS address 0 of the wave's allocation: 4 x a record's column is its address
+    uint32_t* head = lds;                             // SPAN words: 4 x a record's column is its byte offset
     uint32_t* idx = lds + SPAN;                       // band_rows + 1 offsets (relative to the frame's records)
     uint2* left = reinterpret_cast<uint2*>(idx + ((band_rows + 1 + 3) & ~3));   // band_rows pairs {left pixel, kind counts}
-    uint32_t* win = reinterpret_cast<uint32_t*>(left + ((band_rows + 1) & ~1));   // win_cap + 2 records (8-byte aligned)
+    uint32_t* win = reinterpret_cast<uint32_t*>(left + ((band_rows + 1) & ~1));   // win_cap + 2 records (8-byte aligned) + 64 words that may be read, never used
     const uint32_t* gidx = fa.tile_idx + (size_t)tile * (band_rows + 1);
     const uint2* gleft = reinterpret_cast<const uint2*>(fa.left) + (size_t)tile * band_rows;
     for (int k = lane; k <= band_rows; k += 64) idx[k] = load1_global(gidx + k);
     for (int k = lane; k < band_rows; k += 64) left[k] = load2_global(gleft + k);
     *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
-    uint32_t p[PPL] = {0, 0, 0, 0};                   // this lane's pixels of the row above
+    u32x4 pv = {0, 0, 0, 0};                          // this lane's pixels of the row above; after the row's arithmetic, of the row (the row loop's asm names its registers)
     if (yb > 0 && active) {
         const uint32_t* sd = fa.seeds + (size_t)(band - 1) * ((size_t)X + 1) + 1 + x0;
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) p[j] = load1_global(sd + j);
+        pv.x = load1_global(sd); pv.y = load1_global(sd + 1); pv.z = load1_global(sd + 2); pv.w = load1_global(sd + 3);
     }
+    const unsigned long long active_lanes = __ballot(active);
     // everything fetched so far must have landed before the row loop: a vmcnt wait inside it would also wait for
     // the frame stores (loads and stores share the counter)
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt/lgkmcnt untouched
@@ -248,12 +253,11 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(cons
 
     const uint32_t* __restrict__ grecs = reinterpret_cast<const uint32_t*>(fa.runs);   // 4-byte records (sp.h: tile_record32), 8-byte aligned per frame
     constexpr uint32_t OFF = ~kRowRepeats;            // an index entry = record offset | kRowRepeats ("same words as the row above")
-    // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the word itself (colour / addend in
-    // its low 24 bits), its low 7 bits per byte, and the two masks that pick the pixel's starting value — the pixel to the upper
-    // left, the pixel above, or nothing (a constant).  A row that repeats the layout of the row above keeps all of it.
-    uint32_t d24[PPL] = {0, 0, 0, 0}, m_left[PPL] = {0, 0, 0, 0}, m_above[PPL] = {0, 0, 0, 0};
-    // window: rows [y, y + n) whose records fit in win_cap (at most 63 rows: a window's index entries live one per lane).  A
-    // single row with more records than that (more than one run every other pixel) is scattered straight from global memory.
+    // What a pixel's run word says, unpacked once per CHANGE of layout (not once per row): the word itself (its low three bytes are what is
+    // added) and the byte selector of its starting value.  A row that repeats the layout of the row above keeps both.
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, sel0 = 0x0C0C0C0Cu, sel1 = 0x0C0C0C0Cu, sel2 = 0x0C0C0C0Cu, sel3 = 0x0C0C0C0Cu;
+    // window: rows [y, y + n) whose records fit in win_cap (at most 62 rows: a window's index entries live one per lane, and a row reads the entry
+    // two past its own).  A single row with more records than that (more than one run every other pixel) is scattered straight from global memory.
     constexpr int WMAX = 4;                                    // win_cap <= 128 * WMAX - 2 (tile_plan): a lane fetches two records per load
     // The window's loads are written as asm and waited for BY COUNT.  A wave's loads and stores share one in-order counter
     // (vmcnt): the compiler, seeing loads whose results are used after a loop of row stores, waits for vmcnt(0) — every window
@@ -267,23 +271,25 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(cons
     // instead of 0.47 (profiles/r04_sp_tile_parts.txt), but the touch made it 0.49 - 0.51 through the builtin (the compiler then waits for
     // vmcnt(0) at the next LDS access) and still 0.47 - 0.49 issued as asm behind the window's loads (profiles/
     // r04_sp_tile_touch_ab.txt): what the cached build saves is the requests, not the wait for them.)
-    // ve: lane r = index entry of row (first + r); wb = the window's first record rounded down to an
-    // even one (two-record loads stay 8-byte aligned); wn2 = records from wb to the window's end
+    // ve: lane r = index entry of row (first + r), lanes past n = the entry of lane n (the window's end); wb = the window's first record rounded
+    // down to an even one (two-record loads stay 8-byte aligned); wn2 = records from wb to the window's end
     struct Window { uint32_t ve; uint32_t w0, wb; int n, wn2, from; bool direct; };   // (left pixels and kind counts are read again when the window begins: they need not travel a window ahead)
     auto plan_and_fetch = [&](int from) {
         Window w;
         const int k = from + lane;
-        w.ve = idx[(k < ye ? k : ye) - yb];
+        const uint32_t ve = idx[(k < ye ? k : ye) - yb];
         w.from = from;
-        w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ve) & OFF;
+        w.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ve) & OFF;
         w.wb = w.w0 & ~1u;
-        const bool fits = lane >= 1 && k <= ye && (int)((w.ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
-        const unsigned long long m = __ballot(fits) >> 1;
-        int n = __builtin_ctzll(~m);                           // (bit 63 of ~m is always set: at most 63 rows)
+        const bool fits = lane >= 1 && k <= ye && (int)((ve & OFF) - w.w0) <= win_cap;   // entry r fits: rows first .. first + r - 1 do
+        const unsigned long long m = (__ballot(fits) >> 1) & 0x3FFFFFFFFFFFFFFFull;          // (62 rows at most)
+        int n = __builtin_ctzll(~m);
         w.direct = n == 0;                                     // the first row alone is too much for the window
         if (n == 0) n = 1;
         w.n = n;
-        w.wn2 = w.direct ? 0 : (int)(((uint32_t)__builtin_amdgcn_readlane((int)w.ve, n) & OFF) - w.wb);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)ve, n);
+        w.ve = lane > n ? end : ve;
+        w.wn2 = w.direct ? 0 : (int)((end & OFF) - w.wb);
         const int npairs = (w.wn2 + 1) >> 1;
 #pragma unroll
         for (int q = 0; q < WMAX; ++q) {
@@ -307,9 +313,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(cons
     // a record -> the word the row's resolver reads.  The kind is the record's place among the row's records: the first `nc` are
     // constants, the next up to `nca` start from the pixel above, the rest from the pixel above and to the left (scalar counts)
     auto scatter = [&](uint32_t rec, int k, uint32_t nc, uint32_t nca) {
-        const uint32_t kind = (uint32_t)k < nc ? kTileHead : ((uint32_t)k < nca ? (kTileHead | kTileAbove) : (kTileHead | kTileAboveLeft));
+        const uint32_t kind = (uint32_t)k < nc ? (kTileHead | kTileConst) : ((uint32_t)k < nca ? (kTileHead | kTileAbove) : (kTileHead | kTileAboveLeft));
         *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(head) + ((rec >> 22) & 0x3FCu)) = (rec & 0x00FFFFFFu) | kind;
     };
+    // the row store: a scalar base that walks down the band + this lane's 16 bytes of the row
+    typedef __attribute__((address_space(1))) char gchar;
+    const uint32_t voff = (uint32_t)x0 * 4u;
     Window nw = plan_and_fetch(yb);
     int rows_since_fetch = 0;                                  // row stores issued after the loads in flight
     int y = yb;
@@ -353,28 +362,26 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(cons
                 for (int r = lane; r < nfirst; r += 64) scatter(win[at + r], r, nc, nca);
             }
         }
+        gchar* rowp = (gchar*)(dst + (size_t)y * X);           // (uniform: a scalar pair)
         for (int r = 0; r < cw.n; ++r, ++y) {
-            const bool more = r + 1 < cw.n;
-            const uint32_t e2 = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2) : e1;   // (r + 2 <= n <= 63)
+            const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)cw.ve, r + 2);   // (r + 2 <= n + 1 <= 63; past the window's end: the end again)
             const bool repeat = (e0 & kRowRepeats) != 0u;                  // (uniform) no records: the words of the row above stay
             const uint32_t eg = (uint32_t)__builtin_amdgcn_readlane((int)cw_vl, r);
             const int n_next = (int)((e2 & OFF) - (e1 & OFF));             // records of the next row (0 past the window's last)
             const int next_at = (int)((e1 & OFF) - cw.wb);
-            const uint32_t cn = more ? (uint32_t)__builtin_amdgcn_readlane((int)cw_vk, r + 1) : 0u;   // the next row's kind counts
-            const uint32_t nc = cn & 0xFFFFu, nca = nc + (cn >> 16);
-            uint32_t nrec = 0;
-            if (lane < n_next) nrec = win[next_at + lane];
-            uint32_t u0 = lane_to_the_left(p[PPL - 1]);
-            u0 = lane == 0 ? eg : u0;
+            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cw_vk, r + 1);   // the next row's kind counts (not used when it has no records)
+            const uint32_t nrec = win[next_at + lane];                     // (every lane reads: past the row's records whatever is there, within the wave's slice)
+            // the pixel left of this lane's first, one row up: the last pixel of the lane to the left; lane 0 keeps the window's word
+            const uint32_t u0 = (uint32_t)__builtin_amdgcn_update_dpp((int)eg, (int)pv.w, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
             if (!repeat) {
                 const uint4 hv = *reinterpret_cast<const uint4*>(head + lane * PPL);
                 *reinterpret_cast<uint4*>(head + lane * PPL) = make_uint4(0, 0, 0, 0);
-                const uint32_t h[PPL] = {hv.x, hv.y, hv.z, hv.w};
-                uint32_t last = h[0];
-#pragma unroll
-                for (int j = 1; j < PPL; ++j) last = h[j] ? h[j] : last;
+                uint32_t last = hv.x;
+                last = hv.y ? hv.y : last;
+                last = hv.z ? hv.z : last;
+                last = hv.w ? hv.w : last;
                 // the word in force at this lane's first pixel: the last one of the nearest lane to the left that has any (lane 0
-                // always has h[0]: a record starts every span; its own `below` is empty and whatever it fetches is not used)
+                // always has its own first: a record starts every span; its `below` is empty and whatever it fetches is not used)
                 const unsigned long long seen = __ballot(last != 0u);
                 // the lanes BELOW this one that have a word: the set shifted up by (64 - lane), so that this lane's own bit and everything above fall out
                 // (lane 0: its result is not used; a shift by 64 leaves whatever it leaves)
@@ -382,31 +389,47 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 8) void sp_iframe_tile_kernel(cons
                 const uint32_t below_lo = (uint32_t)below, below_hi = (uint32_t)(below >> 32);
                 const uint32_t lead = min(ffbh(below_hi), ffbh(below_lo) + 32u);   // leading zeros of the 64-bit set (v_ffbh: all ones for 0, which loses the min)
                 uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1 - (int)lead) << 2, (int)last);   // the nearest lane below with a word: lane - 1 - lead (the instruction looks at address bits 7:2 only)
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) {
-                    w = h[j] ? h[j] : w;
-                    d24[j] = w;
-                    m_above[j] = (uint32_t)((int32_t)(w << 7) >> 31);   // kTileAbove
-                    m_left[j] = (uint32_t)((int32_t)(w << 6) >> 31);    // kTileAboveLeft
-                }
+                w = hv.x ? hv.x : w; d0 = w; sel0 = ((w >> 24) & 0xFu) * kTileSelMul + kTileSelAdd;
+                w = hv.y ? hv.y : w; d1 = w; sel1 = ((w >> 24) & 0xFu) * kTileSelMul + kTileSelAdd;
+                w = hv.z ? hv.z : w; d2 = w; sel2 = ((w >> 24) & 0xFu) * kTileSelMul + kTileSelAdd;
+                w = hv.w ? hv.w : w; d3 = w; sel3 = ((w >> 24) & 0xFu) * kTileSelMul + kTileSelAdd;
             }
-            // (Rows that repeat a layout in which nothing moves — constants, "above" with a zero addend — are the row above again; skipping their
-            // arithmetic under a wave-uniform test was 1 % SLOWER, 0.487 against 0.482 ms per 256 frames: profiles/r05_sp_tile_static_rows_ab.txt.
-            // The kernel does not wait for its VALU.)
-            // pixel = start value + addend, byte by byte (bytes 0..2; byte 3 stays 0): the low 7 bits of every byte
-            // are added in one go (no carry can cross a byte), bit 7 of each byte is put right with an exclusive or
-            uint32_t q[PPL];
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) {
-                const uint32_t base = ((j ? p[j - 1] : u0) & m_left[j]) | (p[j] & m_above[j]);
-                q[j] = ((base & 0x007F7F7Fu) + (d24[j] & 0x007F7F7Fu)) ^ ((base ^ d24[j]) & 0x00808080u);   // (the word's low 7 bits per byte masked here, not kept: a register per pixel less)
+            // pixel = start value + the word's low three bytes, byte by byte, in place and from the right (pixel j's start may be the OLD pixel j - 1).
+            // v_perm_b32 D, S0, S1, sel: selector 0..3 = bytes of S1 (the pixel above), 4..7 = bytes of S0 (above-left), 12 = 0x00, >= 13 = 0xFF.
+            // A partial (SDWA) write must not be read by the very next VALU instruction: the four pixels' chains are interleaved.  The row lives in
+            // v[60:63] by name (inline asm cannot name the parts of a register tuple, and the row store wants the four pixels side by side).
+#define JSP_ADD_BYTE(n) \
+            "v_add_u32_sdwa v63, v63, %4 dst_sel:BYTE_" #n " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #n " src1_sel:BYTE_" #n "\n\t" \
+            "v_add_u32_sdwa v62, v62, %3 dst_sel:BYTE_" #n " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #n " src1_sel:BYTE_" #n "\n\t" \
+            "v_add_u32_sdwa v61, v61, %2 dst_sel:BYTE_" #n " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #n " src1_sel:BYTE_" #n "\n\t" \
+            "v_add_u32_sdwa v60, v60, %1 dst_sel:BYTE_" #n " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #n " src1_sel:BYTE_" #n "\n\t"
+            asm("v_perm_b32 v63, v62, v63, %8\n\t"
+                "v_perm_b32 v62, v61, v62, %7\n\t"
+                "v_perm_b32 v61, v60, v61, %6\n\t"
+                "v_perm_b32 v60, %9, v60, %5\n\t"
+                JSP_ADD_BYTE(0) JSP_ADD_BYTE(1) JSP_ADD_BYTE(2)
+                "s_nop 0"
+                : "+{v[60:63]}"(pv)
+                : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(sel0), "v"(sel1), "v"(sel2), "v"(sel3), "v"(u0));
+#undef JSP_ADD_BYTE
+            // the row store, lanes past the frame's right edge switched off for its duration (no branch); the two instructions behind it are the wait
+            // states a 16-byte store's data registers need before anything may write them.  (Not counted by the compiler: settle_window counts.)
+            {
+                unsigned long long keep;
+                asm volatile("s_and_saveexec_b64 %0, %4\n\t"
+                             "global_store_dwordx4 %1, %2, %3\n\t"
+                             "s_mov_b64 exec, %0\n\t"
+                             "s_nop 0"
+                             : "=&s"(keep) : "v"(voff), "v"(pv), "s"(rowp), "s"(active_lanes) : "scc");   // (s_and_saveexec writes SCC)
             }
-            if (active) store4_global(dst + (size_t)y * X + x0, make_uint4(q[0], q[1], q[2], q[3]));   // (nontemporal: same time, measured)
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) p[j] = q[j];
+            rowp += (size_t)X * 4;
             ++rows_since_fetch;                                // (one row store per row, issued by every wave with an active lane)
-            if (lane < n_next) scatter(nrec, lane, nc, nca);
-            for (int k = lane + 64; k < n_next; k += 64) scatter(win[next_at + k], k, nc, nca);   // rows with more records than lanes
+            if (n_next > 0) {                                  // (uniform) the next row brings records: put them into the head row
+                const uint32_t nc = cn & 0xFFFFu, nca = nc + (cn >> 16);
+                if (lane < n_next) scatter(nrec, lane, nc, nca);
+                if (n_next > 64)
+                    for (int k = lane + 64; k < n_next; k += 64) scatter(win[next_at + k], k, nc, nca);   // rows with more records than lanes
+            }
             __builtin_amdgcn_wave_barrier();
             e0 = e1;
             e1 = e2;
@@ -872,35 +895,42 @@ bool iframe_tiles_ok(const Geometry& g) { return (g.X & 3) == 0 && g.aligned16; 
 // each with a longer serial row step)
 int iframe_tile_span(const Geometry&) { return 256; }   // (8 pixels per lane, 512-column spans: 0.71 vs 0.54 ms, profiles/archive/r03_fused_notes.txt)
 namespace {
-struct TilePlan { int rows, span, nspans, win_cap; size_t lds; };
+constexpr size_t kTileGroupLds = 64 * 1024;            // what a workgroup of tile waves may take (hipFuncAttributeMaxDynamicSharedMemorySize below)
+struct TilePlan { int rows, span, nspans, win_cap, waves; size_t lds; };
 TilePlan tile_plan(const Geometry& g, int band_rows) {
     TilePlan t;
     t.rows = rows_in_band(g, band_rows);
     t.span = iframe_tile_span(g);
     t.nspans = (g.X + t.span - 1) / t.span;
-    // per wave: head row + row index + {left pixel, kind counts} per row + record window (4-byte records); ~4.5 KB keeps 32 waves on a CU
-    const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + 2 * (((size_t)t.rows + 1) & ~size_t(1));
+    // per wave: head row + row index + {left pixel, kind counts} per row + record window (4-byte records) + 64 words a row's unconditional read of "the next
+    // row's records" may run into; ~4.5 KB keeps 32 waves on a CU
+    const size_t fixed = (size_t)t.span + (((size_t)t.rows + 1 + 3) & ~size_t(3)) + 2 * (((size_t)t.rows + 1) & ~size_t(1)) + 64;
     const size_t budget = 4608 / 4;
     size_t cap = budget > fixed + 2 ? (budget - fixed - 2) & ~size_t(1) : 0;
     if (cap < 128) cap = 128;                                  // (a row with more records is scattered from global memory)
     if (cap > 510) cap = 510;                                  // the kernel fetches a window with four two-record loads per lane (512 records, one may be the pad in front)
     t.win_cap = (int)cap;
-    t.lds = 4 * (fixed + cap + 2);
+    t.lds = 4 * ((fixed + cap + 2 + 3) & ~size_t(3));          // (a multiple of 16 bytes: every wave's head row is read and cleared 16 bytes per lane)
+    // A tile's index and left pixels grow with the band (12 bytes per row): a workgroup takes as many neighbouring spans as fit its LDS — eight up to ~550 rows,
+    // four at 1080 (one band per frame), one at 4096, the tallest band there is (sp_codec.cpp cuts taller frames).
+    size_t waves = kTileGroupLds / t.lds;
+    t.waves = (int)(waves < 1 ? 1 : (waves > (size_t)TILE_WAVES ? (size_t)TILE_WAVES : waves));
     return t;
 }
 }  // namespace
+int iframe_tile_max_band_rows() { return 4096; }
 void launch_iframe_tiles(const Geometry& g, const IFrameArgs* d_args, int nframes, int band_rows, hipStream_t stream) {
     if (nframes <= 0) return;
     const TilePlan t = tile_plan(g, band_rows);
     const int bands = (g.Y + t.rows - 1) / t.rows;
-    const int groups = (t.nspans + TILE_WAVES - 1) / TILE_WAVES;   // workgroups per band: eight neighbouring spans each (1080p: one)
+    const int groups = (t.nspans + t.waves - 1) / t.waves;     // workgroups per band: up to eight neighbouring spans each (1080p: one)
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_iframe_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileGroupLds);
     });
     // frames fastest in the launch order (0.616 of 8 TB/s against 0.573 with tiles fastest, same buffers, round 3)
-    hipLaunchKernelGGL(sp_iframe_tile_kernel, dim3(nframes, bands * groups), dim3(64 * TILE_WAVES), t.lds * TILE_WAVES, stream, d_args, g.X, g.Y, t.rows, t.nspans,
-                       t.win_cap, groups, (int)(t.lds / 4));
+    hipLaunchKernelGGL(sp_iframe_tile_kernel, dim3(nframes, bands * groups), dim3(64 * t.waves), t.lds * t.waves, stream, d_args, g.X, g.Y, t.rows, t.nspans,
+                       t.win_cap, groups, (int)(t.lds / 4), t.waves);
 }
 
 void launch_pframe(const Geometry& g, int32_t* dst, const int32_t* prev, const PBlock* d_blocks,

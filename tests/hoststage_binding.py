@@ -14,7 +14,7 @@ _PATH = os.path.join(HERE, "hoststage", "libhoststage.so")
 _lib = None
 
 RUN_CONST, RUN_ABOVE, RUN_ABOVE_LEFT = 0, 1, 3
-TILE_ABOVE_LEFT = 2   # tile layout: bits 24 / 25 of a record's word are exclusive (kTileAbove / kTileAboveLeft)
+TILE_ABOVE_LEFT = 2   # the model's own label for the third kind of a tile row (its place among the row's records tells a record's kind)
 PB_SUBRECT, PB_MOTION, PB_DATA = 1, 2, 4
 KIND_NONE, KIND_FLAT, KIND_INTRA, KIND_INTER = 0, 1, 2, 3
 
@@ -222,8 +222,11 @@ def expand_iframe_tiles(desc, X, Y):
                 lft = np.empty(xe - xs, np.uint32)
                 lft[1:] = up[:-1]
                 lft[0] = left[t * rows_per + r, 0]
-                v = np.where(kind == RUN_ABOVE, _add_bytes(up, val), val)
-                v = np.where(kind == TILE_ABOVE_LEFT, lft, v).astype(np.uint32)
+                # every kind is "start value + record value, byte by byte": the pixel above, the pixel above-left (value 0), or 0xFFFFFF for a
+                # constant, whose record carries the colour plus one in every byte (sp.h: tile_record32)
+                start = np.where(kind == RUN_ABOVE, up, np.where(kind == TILE_ABOVE_LEFT, lft, np.uint32(0xFFFFFF)))
+                assert np.all(val[kind == TILE_ABOVE_LEFT] == 0)
+                v = _add_bytes(start, val).astype(np.uint32)
                 out[y, xs:xe] = v
                 up = v
     assert covered[:int(idx[-1]) & 0x7FFFFFFF].all()

@@ -117,11 +117,31 @@ def test_noise_key_frame_rows_with_more_runs_than_the_tile_window():
     drive_pair(w, h, 24, chunks, keys, frames, band_rows=7)
 
 
+def test_noise_key_frame_in_one_tall_band_takes_the_direct_scatter():
+    """One band of 300 rows: the tile's row index and left pixels leave its LDS slice a window of 128 records, a noisy
+    256-column row has up to 256 — every such row is scattered straight from global memory (the `direct` branch), the
+    quiet rows in between go through 128-record windows; and a workgroup of such tall tiles has fewer than eight waves."""
+    w, h = 1024, 300
+    chunks, keys, frames = sg.sp_clip(993, w, h, 2, version=4, key_every=1, noise=0.97)
+    drive_pair(w, h, 24, chunks, keys, frames, band_rows=0)
+    chunks, keys, frames = sg.sp_clip(994, w, h, 2, version=4, key_every=1, noise=0.3)
+    drive_pair(w, h, 24, chunks, keys, frames, band_rows=0)
+
+
+def test_frames_taller_than_a_tiles_index_are_cut_into_bands():
+    """4 200 rows: more than one wave's LDS slice can index (4 096), so 'one band per frame' is cut at 4 096; a workgroup is one wave."""
+    w, h = 64, 4200
+    chunks, keys, frames = sg.sp_clip(995, w, h, 2, version=4, key_every=1)
+    drive_pair(w, h, 24, chunks, keys, frames, band_rows=0)
+    drive_pair(w, h, 24, chunks, keys, frames)
+
+
 def test_key_frame_bands_1080p_batch():
-    """A batch of 1080p key frames in one launch, banded automatically and with an odd band height."""
+    """A batch of 1080p key frames in one launch, banded automatically, with an odd band height, in bands too tall for eight
+    waves to share a workgroup's LDS (600 rows) and as one band per frame (1 080 rows: four waves per workgroup)."""
     w, h = 1920, 1080
     chunks, keys, frames = sg.sp_clip(991, w, h, 3, version=4, key_every=1)
-    for rows in ("auto", "37"):
+    for rows in ("auto", "37", "600", "0"):
         gpu = ScreenPressor(w, h, 24)
         gpu.Preinit(36)
         gpu.set_option("sp_band_rows", rows)
