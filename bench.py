@@ -130,6 +130,52 @@ def _spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _init_collectives(rank: int, world: int, local_rank: int, want_rccl: bool, why_not: str = ""):
+    """Set up the process group of an N-rank run and say what carries its collectives.  RCCL (backend "nccl") first, checked with one
+    all-reduce whose answer is known; if any rank cannot set it up or gets a wrong sum, EVERY rank tears it down and the same processes go on
+    over gloo with host tensors (the --ranks-share-device code path) — no re-exec, no restart of a process that has touched its GPU — so a node
+    on which RCCL does not come up still ends with a line, flagged.  The ranks agree on the verdict through the rendezvous store, not through
+    the group under test.  Returns (device the collectives' tensors live on, what the line's "collectives" says).
+    JSP_BENCH_FORCE_RCCL_FAILURE=all (tests) makes the RCCL attempt fail on every rank; =<k> only on rank k."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    store, _, _ = next(iter(dist.rendezvous("env://", rank=rank, world_size=world)))
+    store.set_timeout(datetime.timedelta(seconds=600))
+    if not want_rccl:
+        dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world)
+        return "cpu", f"gloo ({why_not})"
+    reason = None
+    try:
+        forced = os.environ.get("JSP_BENCH_FORCE_RCCL_FAILURE")
+        if forced is not None and (forced == "all" or forced == str(rank)):
+            raise RuntimeError("forced by JSP_BENCH_FORCE_RCCL_FAILURE")
+        dist.init_process_group("nccl", store=dist.PrefixStore("rccl", store), rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
+        probe = torch.full((2,), float(rank + 1), dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        want = world * (world + 1) / 2.0
+        if probe.tolist() != [want, want]:
+            raise RuntimeError(f"all-reduce over RCCL returned {probe.tolist()}, not {want}")
+    except Exception as e:                                    # noqa: BLE001 — whatever RCCL / torch raise here, the run goes on over gloo
+        reason = f"{type(e).__name__}: {str(e).splitlines()[0][:160] if str(e) else ''}"
+    store.set(f"rccl_verdict_{rank}", reason or "ok")
+    verdicts = [store.get(f"rccl_verdict_{r}").decode() for r in range(world)]
+    bad = [(r, v) for r, v in enumerate(verdicts) if v != "ok"]
+    if not bad:
+        return "cuda", "rccl"
+    if dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:                                     # noqa: BLE001
+            pass
+    dist.init_process_group("gloo", store=dist.PrefixStore("gloo_after_rccl", store), rank=rank, world_size=world)
+    r0, v0 = bad[0]
+    return "cpu", f"gloo (rccl failed on {len(bad)} of {world} ranks; rank {r0}: {v0})"
+
+
 class Job:
     """What every leg needs to know about the run: ranks, the stream everything is queued on, the bracket."""
 
@@ -510,9 +556,10 @@ def main():
     from jsplayer_amd.sharding import gather_per_rank, reduce_counters
     if args.dry_run:
         # the multi-rank plumbing without a GPU: every rank "owns" its stream's frames, nothing is decoded
+        collectives = "none (one process)"
         if distributed:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo")
+            # (without a GPU the RCCL attempt cannot succeed: with --gpus N the dry run is a rehearsal of the fall-back itself, unless told to skip it)
+            _, collectives = _init_collectives(rank, world, local_rank, want_rccl=not args.ranks_share_device, why_not="ranks share a device")
             dist.barrier()
 
         def counters(name):
@@ -524,7 +571,7 @@ def main():
         rest = [counters(w) for w in also]
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-                              "dry_run": True, "config": {"workload": args.workload, "streams": args.gpus}, "total_frames": head["total_frames"],
+                              "dry_run": True, "collectives": collectives, "config": {"workload": args.workload, "streams": args.gpus}, "total_frames": head["total_frames"],
                               "total_pixels": head["total_pixels"], "per_rank_frames": head["per_rank_frames"], "also": rest}), flush=True)
         if distributed:
             dist.barrier()
@@ -536,17 +583,14 @@ def main():
     if share:
         local_rank = 0                        # every rank on the one device there is
     torch.cuda.set_device(local_rank)
+    coll_device, collectives = "cuda", "none (one process)"
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        coll_device, collectives = _init_collectives(rank, world, local_rank, want_rccl=not share, why_not="ranks share a device")
 
     # a dedicated (non-null) stream: kernels and the timing events are queued on the same one
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    job = Job(args, rank, local_rank, world, distributed, stream, coll_device="cpu" if share else "cuda")
+    job = Job(args, rank, local_rank, world, distributed, stream, coll_device=coll_device)
     t_all = time.perf_counter()
 
     name = args.workload
@@ -569,6 +613,7 @@ def main():
             "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
+            "collectives": collectives,       # what carried the counter reduce: "rccl", or gloo and why
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
