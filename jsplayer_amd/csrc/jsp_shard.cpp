@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <stdexcept>
@@ -33,10 +34,16 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string tried;
     Rccl() {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        // JSP_RCCL_LIB: the library to load instead of the usual names (an install that keeps it elsewhere; tests point it at nothing)
+        const char* named = std::getenv("JSP_RCCL_LIB");
+        const std::vector<const char*> names = named && *named ? std::vector<const char*>{named}
+                                                                : std::vector<const char*>{"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* name : names) {
             so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (so) break;
+            tried += (tried.empty() ? "" : ", ") + std::string(name);
         }
         if (!so) return;
         auto sym = [&](const char* n) { return dlsym(so, n); };
@@ -63,7 +70,7 @@ std::string& shard_error() {
 // receives the sums; device 0's copy is handed back, all copies must agree.
 bool reduce_over_rccl(const int* devices, int ndev, const uint64_t* per_device, uint64_t* total) {
     Rccl& r = rccl();
-    if (!r.ok) { shard_error() = "librccl not loadable"; return false; }
+    if (!r.ok) { shard_error() = r.so ? "librccl lacks an entry point the counter reduce needs" : "librccl not loadable (tried " + r.tried + ")"; return false; }
     std::vector<ncclComm_t> comms(ndev, nullptr);
     std::vector<hipStream_t> streams(ndev, nullptr);
     std::vector<uint64_t*> bufs(ndev, nullptr);
@@ -139,9 +146,14 @@ int jsp_reduce_counters(const int* devices, int ndev, const uint64_t* per_device
         folded[2 * k] += per_device[2 * i];
         folded[2 * k + 1] += per_device[2 * i + 1];
     }
-    const int have = jsp_device_count();
+    // (JSP_SHARD_ASSUME_DEVICES: tests of the fall-back on a box without that many devices — the RCCL attempt then fails where it fails)
+    const char* assume = std::getenv("JSP_SHARD_ASSUME_DEVICES");
+    const int have = assume && *assume ? std::atoi(assume) : jsp_device_count();
     bool usable = have > 0;
-    for (int d : distinct) usable = usable && d >= 0 && d < have;
+    shard_error().clear();
+    if (!usable) shard_error() = "no HIP device visible: counters summed on the host";
+    for (int d : distinct)
+        if (usable && (d < 0 || d >= have)) { usable = false; shard_error() = "device ordinal " + std::to_string(d) + " is not one of the " + std::to_string(have) + " visible: counters summed on the host"; }
     uint64_t reduced[2] = {0, 0};
     if (usable && reduce_over_rccl(distinct.data(), (int)distinct.size(), folded.data(), reduced)) {
         if (reduced[0] != sum[0] || reduced[1] != sum[1]) return JSP_ERROR_OCCURED;   // (a collective that loses counts is an error, not a fallback)

@@ -151,11 +151,14 @@ public:
     void set_key_compare_row(int row) { key_compare_row_ = row; }
     int pinned_version() const { return version_; }            // 0: no coded key frame has chosen the entropy coder yet
     bool pin_version(int version) { return ec_ ? version_ == version : init_entropy(version); }
-    void adopt_settings(const HostDecoder& o) {                 // Preinit and key-frame layout of the stream's decoder
-        insignificant_blocks_ = o.insignificant_blocks_;
-        band_rows_ = o.band_rows_;
-        span_px_ = o.span_px_;
+    struct Settings { int insignificant_blocks = 0, band_rows = 0, span_px = 0; };   // Preinit and key-frame layout: what a group's own decoder takes over from the stream's
+    Settings settings() const { return {insignificant_blocks_, band_rows_, span_px_}; }
+    void adopt_settings(const Settings& s) {
+        insignificant_blocks_ = s.insignificant_blocks;
+        band_rows_ = s.band_rows;
+        span_px_ = s.span_px;
     }
+    void adopt_settings(const HostDecoder& o) { adopt_settings(o.settings()); }
 
 private:
     void note_key_compare(FrameOut& out, bool had_prev) const;

@@ -298,6 +298,9 @@ struct SpCodec : jsp_codec, DstColumns {
         const HostFrame hf{j.frame.src, j.frame.n, j.frame.key};
         std::shared_ptr<Group> cur = groups.empty() ? nullptr : groups.back();
         if (!cur) {                                 // first frame since the last drain: predictions start from the codec's state
+            // (and the stream's settings are noted HERE, on the caller's thread with nothing in flight: from now on a worker may be inside `host` —
+            // the first group decodes on it and sets its key-frame layout there — and this thread must not read it.  ThreadSanitizer, round 6.)
+            settings_at_submit = host.settings();
             stream_version = host.pinned_version();
             seen_key = host.has_prev() || stream_version != 0;
             pred_prev_dev = prev_dev;
@@ -328,7 +331,7 @@ struct SpCodec : jsp_codec, DstColumns {
             if (!spare.empty()) { fresh = std::move(spare.back()); spare.pop_back(); }
             if (fresh && fresh->pinned_version() != 0 && fresh->pinned_version() != stream_version) fresh.reset();   // it served another coder
             if (!fresh) fresh = std::make_unique<HostDecoder>(g.X, g.Y, g.bpp);
-            fresh->adopt_settings(host_settings());
+            fresh->adopt_settings(settings_at_submit);
             new_group = fresh->pin_version(stream_version);
             if (!new_group) spare.push_back(std::move(fresh));
         }
@@ -364,7 +367,7 @@ struct SpCodec : jsp_codec, DstColumns {
         }
         cv_work.notify_all();
     }
-    const HostDecoder& host_settings() const { return host; }   // Preinit and key-frame layout: only ever changed with nothing in flight
+    HostDecoder::Settings settings_at_submit;   // the stream decoder's Preinit / key-frame layout as they stood when the first frame since the last drain was submitted
 
     void worker_wait(jsp_async_job& j) override {
         std::unique_lock<std::mutex> lk(mu);

@@ -678,9 +678,6 @@ struct G2Chunk {
     PGroupFrame gf[G2_CF];
     uint32_t lit_at[G2_CF * G2_BLOCKS];       // where in `lits` the rectangle of (frame, block) starts
     uint32_t lits[G2_LW];
-    // per worker wave: bit 4 f set = some block of the workgroup changes one of the wave's rows in frame f of the chunk (round 6): a wave whose
-    // bit is clear stores the rows it holds and never looks at the frame's records
-    unsigned long long touched[4];
     int nf, next;
     int pad[2];                               // (sizeof a multiple of 16: the second chunk's tables stay 16-byte aligned for the LDS-DMAs)
 };
@@ -733,17 +730,11 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // 2. where each changed rectangle's literals go, and how many frames fit: two items per lane, exclusive scan
             uint32_t need[2] = {0, 0}, from[2] = {0, 0};    // literal words of the lane's two items, and where they start in `payload`
-            uint32_t rows_hit = 0;                          // bit w: one of the lane's two items changes a row worker wave w holds (rows 2w, 2w+1, 2w+8, 2w+9 of the block row)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int item = lane * 2 + h;
                 if (item < nf_try * G2_BLOCKS && (item & 7) < nb_here) {
                     const PBlock pb = ck.pb[item];
-                    if (pb.flags != 0) {
-#pragma unroll
-                        for (int w = 0; w < 4; ++w)
-                            if ((pb.y1 < 2 * w + 2 && pb.y2 > 2 * w) || (pb.y1 < 2 * w + 10 && pb.y2 > 2 * w + 8)) rows_hit |= 1u << w;
-                    }
                     if (pb.flags & PB_DATA) {
                         // (rounded up to 16 bytes: the host stage starts every rectangle's literals on a 16-byte boundary of the table — so does
                         // its place in `lits` — and the fetch below moves 16 bytes per lane; what it reads past a rectangle's end is table too)
@@ -784,14 +775,6 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
                         if (i + lane * 4 < n) __builtin_amdgcn_global_load_lds((g2_gvoid*)(src + i + lane * 4), (g2_lvoid*)&ck.lits[at + i], 16, 0, 0);
                 }
             }
-            // a frame's eight items sit in four neighbouring lanes: fold them onto the first (bit 4 f)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                unsigned long long m = __ballot((rows_hit >> w) & 1u);
-                m |= m >> 1;
-                m |= m >> 2;
-                if (lane == 0) ck.touched[w] = m;
-            }
             if (lane == 0) { ck.nf = nf; ck.next = f0 + nf; }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (lane == 0) *s_ready = (uint32_t)(c + 1);
@@ -813,16 +796,10 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
     const bool col = bx < nbx && x0 < X;
     const bool mine_a = col && ya < Y, mine_b = col && yb2 < Y;
     const size_t ia = (size_t)ya * X + x0, ib = (size_t)yb2 * X + x0;
-    u32x4 pa = {0, 0, 0, 0}, pb4 = {0, 0, 0, 0};             // the lane's two rows of four pixels, carried from frame to frame
-    if (mine_a) { const uint4 q = *reinterpret_cast<const uint4*>(prev + ia); pa = u32x4{q.x, q.y, q.z, q.w}; }
-    if (mine_b) { const uint4 q = *reinterpret_cast<const uint4*>(prev + ib); pb4 = u32x4{q.x, q.y, q.z, q.w}; }
-    // the previous-frame pixels are settled before any store is issued (the builtin, not asm: the compiler's own wait bookkeeping must see it, or it
-    // waits for "the loads before the loop" at the first use of the pixels INSIDE the loop — vmcnt(0) in front of every frame's stores)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    // The frame's two row stores: the frame's buffer as a scalar base, the lane's two places in it as offsets that never change, the lanes past the frame's
-    // edges switched off for the store's duration — no address arithmetic, no branch.  (Frames of at most 4 GB: 32-bit offsets.)
-    const unsigned long long lanes_a = __ballot(mine_a), lanes_b = __ballot(mine_b);
-    const uint32_t off_a = (uint32_t)(ia * 4), off_b = (uint32_t)(ib * 4);
+    uint32_t pa[4] = {0, 0, 0, 0}, pb4[4] = {0, 0, 0, 0};
+    if (mine_a) { const uint4 q = *reinterpret_cast<const uint4*>(prev + ia); pa[0] = q.x; pa[1] = q.y; pa[2] = q.z; pa[3] = q.w; }
+    if (mine_b) { const uint4 q = *reinterpret_cast<const uint4*>(prev + ib); pb4[0] = q.x; pb4[1] = q.y; pb4[2] = q.z; pb4[3] = q.w; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the previous-frame pixels are settled before any store is issued
     for (int c = 0;; ++c) {
         int spin = 0;
         for (; *s_ready < (uint32_t)(c + 1) && spin < G2_SPIN; ++spin) __builtin_amdgcn_s_sleep(1);
@@ -830,19 +807,18 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const G2Chunk& ck = chunks[c & 1];
         const int nf = ck.nf, next = ck.next;
-        // the chunk's destinations one per lane (a frame takes its own with two v_readlane), and which of its frames touch this wave's rows at all:
-        // on the others — half of all workgroup-frames of screen content, 92 % of whose blocks do not change — the wave reads no record
-        const unsigned long long touched = ck.touched[wave];
-        const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)touched), t_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(touched >> 32));
-        const unsigned long long tm = ((unsigned long long)t_hi << 32) | t_lo;
-        const unsigned long long dlane = reinterpret_cast<unsigned long long>(ck.gf[lane & (G2_CF - 1)].dst);
-        const int d_lo = (int)(uint32_t)dlane, d_hi = (int)(uint32_t)(dlane >> 32);
-        // (Asking for frame f + 1's record and destination before frame f's rows go out — the loop software-pipelined — changes nothing:
-        // 0.950 against 0.956 ms per 598 frames, profiles/r05_sp_group_pipelined_ab.txt; the simple loop stays.)
-        for (int f = 0; f < nf; ++f) {
-            if ((tm >> (4 * f)) & 1ull) {
+        if (col) {
+            // (Asking for frame f + 1's record and destination before frame f's rows go out — the loop software-pipelined — changes nothing:
+            // 0.950 against 0.956 ms per 598 frames, profiles/r05_sp_group_pipelined_ab.txt; the simple loop stays.)
+            // (Round 6, measured and NOT kept: a per-wave "this frame touches none of my rows" bit from the loader, so that such frames — half of all
+            // workgroup-frames — cost two stores and no record read, and the two row stores issued with a scalar base and constant lane offsets.  Each
+            // bit-exact, each SLOWER in one process on the same frames: 0.9323 ms as it is | mask alone 0.9388 | scalar-base stores alone 0.9455 | both
+            // 0.9587; the same with an s_sleep 8 per frame 0.9443 (profiles/r06_sp_group_touched_mask_variants.txt).  The fewer instructions stand between
+            // a wave's stores the worse the memory side takes them; the records' reads pace the walk.)
+            for (int f = 0; f < nf; ++f) {
                 const PBlock pb = ck.pb[f * G2_BLOCKS + kb];
-                if (col && pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
+                uint32_t* out = reinterpret_cast<uint32_t*>(ck.gf[f].dst);
+                if (pb.flags != 0 && cx0 < pb.x2 && cx0 + 4 > pb.x1) {
                     const int w = pb.x2 - pb.x1;
                     const uint32_t* lit0 = ck.lits + ck.lit_at[f * G2_BLOCKS + kb] - pb.x1;
                     if (r >= pb.y1 && r < pb.y2) {
@@ -856,17 +832,9 @@ __global__ __launch_bounds__(G2_WG) void sp_pframe_group_kernel(const PGroupFram
                         for (int j = 0; j < 4; ++j) { const int rx = cx0 + j; if (rx >= pb.x1 && rx < pb.x2) pb4[j] = lit[rx]; }
                     }
                 }
+                if (mine_a) store4_global(out + ia, make_uint4(pa[0], pa[1], pa[2], pa[3]));
+                if (mine_b) store4_global(out + ib, make_uint4(pb4[0], pb4[1], pb4[2], pb4[3]));
             }
-            const unsigned long long out = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(d_hi, f) << 32) | (uint32_t)__builtin_amdgcn_readlane(d_lo, f);
-            unsigned long long keep;
-            asm volatile("s_mov_b64 %0, exec\n\t"
-                         "s_and_b64 exec, %0, %6\n\t"
-                         "global_store_dwordx4 %1, %3, %5\n\t"
-                         "s_and_b64 exec, %0, %7\n\t"
-                         "global_store_dwordx4 %2, %4, %5\n\t"
-                         "s_mov_b64 exec, %0\n\t"
-                         "s_nop 0"
-                         : "=&s"(keep) : "v"(off_a), "v"(off_b), "v"(pa), "v"(pb4), "s"(out), "s"(lanes_a), "s"(lanes_b) : "scc");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) s_done[wave] = (uint32_t)(c + 1);

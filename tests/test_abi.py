@@ -64,3 +64,20 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle/" not in text and "liboracle" not in text and "oracle_binding" not in text, \
                     f"{f} refers to the oracle"
+
+
+def test_threaded_host_layers_are_clean_under_thread_sanitizer(tmp_path):
+    """tools/tsan_cpu.sh: jsp_api.cpp, msv1_codec.cpp, sp_codec.cpp, jsp_shard.cpp and the host stages built with -fsanitize=thread against
+    the stub HIP runtime under tests/tsan/ and driven on 26 host threads (asynchronous submit / wait out of phase, drains, prefetch ranges
+    given up mid-flight, staged batches, pools created and destroyed side by side).  Round 6's first run found a race — the caller's thread
+    reading the stream decoder's settings while the first group's worker wrote its key-frame layout into the same decoder (sp_codec.cpp,
+    `settings_at_submit`)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JSP_TSAN_DIR=str(tmp_path))
+    res = subprocess.run([os.path.join(root, "tools", "tsan_cpu.sh"), "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, env=env)
+    out = res.stdout.decode()
+    assert res.returncode == 0 and "tsan clean" in out, out[-3000:]

@@ -7,6 +7,7 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/front_lab.hip -o tools/front_lab.bin && tools/front_lab.bin [frames]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
@@ -347,6 +348,122 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     };
+    if (getenv("LAB_VMM")) {   // round 6: the pool built from hipMemCreate handles mapped into one VA range — holds exactly the pool; does an arrangement of the handles match the dealt hipMalloc pool?
+        // three store shapes per arrangement: the 512 write fronts (what jsp_pool_create probes with), band-walking waves (the ScreenPressor key-frame kernel's), frame-walking workgroups (the group kernels')
+        auto rates = [&](const char* what, const std::vector<uint32_t*>& fr, double setup_ms, double held_x) {
+            CK(hipMemcpy(d_table, fr.data(), sizeof(uint32_t*) * F, hipMemcpyHostToDevice));
+            const int T = 8192, tpf = (NBLK + T - 1) / T;
+            auto time3 = [&](auto&& launch) {
+                launch();
+                CK(hipDeviceSynchronize());
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    float ms = 0;
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 3; ++i) launch();
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    best = ms / 3 < best ? ms / 3 : best;
+                }
+                return (double)F * FRAME_BYTES / best / 1e6;
+            };
+            const double fronts = time3([&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * F), dim3(256), 0, 0, d_table, F, T, tpf, 1); });
+            const int B = 90, bands = (Y + B - 1) / B;
+            const double band = time3([&] { hipLaunchKernelGGL(band_wg_table_kernel, dim3(F * bands), dim3(512), 0, 0, d_table, F, B, bands, 8, 0); });
+            const double walk = time3([&] { hipLaunchKernelGGL(group_table_kernel, dim3((X + 127) / 128, (Y + 15) / 16), dim3(256), 0, 0, d_table, F); });
+            printf("%-86s fronts %5.0f | bands %5.0f | walkers %5.0f GB/s | set up in %7.1f ms, holds %.2f x the pool\n", what, fronts, band, walk, setup_ms, held_x);
+            fflush(stdout);
+        };
+        auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
+        const int CHF = 16, NCH = F / CHF;
+        {   // what jsp_pool_create does: 4 x NCH hipMalloc chunks of 16 frames, every fourth kept, frames dealt
+            const double t0 = now_ms();
+            std::vector<uint32_t*> chunk(NCH * 4);
+            for (auto& c : chunk) CK(hipMalloc(&c, FRAME_BYTES * CHF));
+            std::vector<uint32_t*> fr(F);
+            for (int i = 0; i < F; ++i) fr[i] = chunk[(i % NCH) * 4] + (size_t)(i / NCH) * X * Y;
+            const double t1 = now_ms();
+            rates("hipMalloc chunks of 16 frames, 4 x as many as needed, every fourth, frames dealt", fr, t1 - t0, 4.0);
+            for (int i = 0; i < F; ++i) fr[i] = chunk[i / CHF] + (size_t)(i % CHF) * X * Y;
+            rates("  the same chunks, the first quarter of them, frames in order (neighbours)", fr, 0, 4.0);
+            for (auto c : chunk) CK(hipFree(c));
+        }
+        {   // one hipMalloc
+            const double t0 = now_ms();
+            uint32_t* one;
+            CK(hipMalloc(&one, FRAME_BYTES * F));
+            std::vector<uint32_t*> fr(F);
+            for (int i = 0; i < F; ++i) fr[i] = one + (size_t)i * X * Y;
+            rates("one hipMalloc, frames back to back", fr, now_ms() - t0, 1.0);
+            for (int i = 0; i < F; ++i) fr[i] = one + (size_t)((i * 17) % F) * X * Y;
+            rates("  the same, frame i in slot 17 i mod F", fr, 0, 1.0);
+            CK(hipFree(one));
+        }
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) { printf("no virtual memory management here\n"); return 0; }
+        size_t gran_rec = 0;
+        (void)hipMemGetAllocationGranularity(&gran_rec, &prop, hipMemAllocationGranularityRecommended);
+        printf("allocation granularity: minimum %zu KB, recommended %zu KB\n", gran >> 10, gran_rec >> 10);
+        // a frame takes PIECES handles of HB bytes (its stride in the VA range is rounded up to that: + 1.1 % for 2 MB handles)
+        for (size_t HB : {(size_t)2 << 20, (size_t)8 << 20, (size_t)128 << 20}) {
+            if (HB % gran) continue;
+            const size_t per_frame = HB >= FRAME_BYTES ? 1 : (FRAME_BYTES + HB - 1) / HB;     // handles per frame (HB < frame) ...
+            const size_t frames_per = HB >= FRAME_BYTES ? HB / ((FRAME_BYTES + (2u << 20) - 1) / (2u << 20) * (2u << 20)) : 1;   // ... or frames per handle, each on a 2 MB boundary
+            const size_t stride = HB >= FRAME_BYTES ? HB / frames_per : per_frame * HB;       // bytes from one frame to the next in VA
+            const size_t nh = HB >= FRAME_BYTES ? ((size_t)F + frames_per - 1) / frames_per : (size_t)F * per_frame;
+            const size_t total = nh * HB;
+            // arrangement: which handle (in creation order) backs VA slot s
+            for (int arr = 0; arr < 4; ++arr) {
+                if (HB >= FRAME_BYTES && arr == 3) continue;
+                if (HB > ((size_t)8 << 20) && arr >= 2) continue;
+                const double t0 = now_ms();
+                void* va = nullptr;
+                if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { printf("reserve failed\n"); break; }
+                std::vector<hipMemGenericAllocationHandle_t> handles(nh);
+                bool ok = true;
+                for (size_t h = 0; h < nh && ok; ++h) ok = hipMemCreate(&handles[h], HB, &prop, 0) == hipSuccess;
+                const double t_create = now_ms();
+                // VA slot s (HB bytes) <- handle order[s]
+                std::vector<size_t> order(nh);
+                const size_t units = HB >= FRAME_BYTES ? nh : (size_t)F;                       // what is dealt: handles, or frames (groups of per_frame handles)
+                const size_t grp = HB >= FRAME_BYTES ? 1 : per_frame;
+                const size_t nchunks = units / 16 ? units / 16 : 1;
+                for (size_t u = 0; u < units; ++u) {
+                    size_t src = u;                                                             // arr 0: in creation order
+                    if (arr == 1 || arr == 3) src = (u % nchunks) * (units / nchunks) + u / nchunks;   // arr 1: dealt — unit u lies in "chunk" u mod nchunks of the creation order
+                    if (arr == 2) src = (u * 17) % units;                                       // arr 2: strided
+                    for (size_t k = 0; k < grp; ++k)
+                        order[u * grp + k] = arr == 3 ? k * units + src                         // arr 3: dealt, and a frame's own pieces in different quarters of the creation order
+                                                      : src * grp + k;
+                }
+                for (size_t sidx = 0; sidx < nh && ok; ++sidx) ok = hipMemMap((char*)va + sidx * HB, HB, 0, handles[order[sidx]], 0) == hipSuccess;
+                hipMemAccessDesc acc{};
+                acc.location = prop.location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                ok = ok && hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+                const double t1 = now_ms();
+                if (ok) {
+                    std::vector<uint32_t*> fr(F);
+                    for (int i = 0; i < F; ++i) fr[i] = (uint32_t*)((char*)va + (size_t)i * stride);
+                    char what[160];
+                    static const char* names[] = {"in creation order", "frames dealt over 16-frame stretches of the creation order", "strided (x 17)", "dealt, a frame's own pieces a quarter of the pool apart"};
+                    std::snprintf(what, sizeof what, "handles of %3zu MB (%zu created in %.1f ms), %s", HB >> 20, nh, t_create - t0, names[arr]);
+                    rates(what, fr, t1 - t0, (double)total / ((double)F * FRAME_BYTES));
+                } else printf("mapping handles of %zu MB failed (%s)\n", HB >> 20, hipGetErrorString(hipGetLastError()));
+                const double t2 = now_ms();
+                (void)hipMemUnmap(va, total);
+                for (auto h : handles) (void)hipMemRelease(h);
+                (void)hipMemAddressFree(va, total);
+                printf("      (torn down in %.1f ms)\n", now_ms() - t2);
+            }
+        }
+        return 0;
+    }
     if (getenv("LAB_TSWEEP")) {   // round 5: how the fronts shape depends on the extent a workgroup writes (T blocks = T x 64 bytes), tile-major and frame-major, on a chunked pool and on one allocation
         const int NC = F / 16 * 4;
         std::vector<uint32_t*> chunk(NC);

@@ -4,7 +4,7 @@ changes).  Both libraries are loaded side by side: the package under .lab_prev i
 other relatively).  Digests of the frames each side leaves are compared with the golden ones once (after a 0xEE scrub).
 
     .lab_prev:  git archive <commit> jsplayer_amd include bench.py tests oracle | tar -x -C .lab_prev; make -C .lab_prev/jsplayer_amd/csrc
-    usage:      python tools/lab/two_libs.py <workload> [rounds=4] [steps=20]
+    usage:      [LAB_SIDES="tag ..."] python tools/lab/two_libs.py <workload> [rounds=4] [steps=20]      (tags: tools/lab/mk_variant.sh)
 """
 import importlib.util
 import os
@@ -19,22 +19,28 @@ from jsplayer_amd import workloads as wl  # noqa: E402
 from jsplayer_amd.codec import FramePool  # noqa: E402
 
 
-def load_prev():
-    d = os.path.join(ROOT, ".lab_prev", "jsplayer_amd")
-    spec = importlib.util.spec_from_file_location("jsplayer_amd_prev", os.path.join(d, "__init__.py"), submodule_search_locations=[d])
+def load_side(tag):
+    """The package under .lab_<tag>/ imported as jsplayer_amd_<tag> (with its own libjsplayer_amd.so); returns its workloads module."""
+    d = os.path.join(ROOT, ".lab_" + tag, "jsplayer_amd")
+    name = "jsplayer_amd_" + tag
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, "__init__.py"), submodule_search_locations=[d])
     mod = importlib.util.module_from_spec(spec)
-    sys.modules["jsplayer_amd_prev"] = mod
+    sys.modules[name] = mod
     spec.loader.exec_module(mod)
-    import jsplayer_amd_prev.workloads as pw
-    return pw
+    return importlib.import_module(name + ".workloads")
+
+
+def load_prev():
+    return load_side("prev")
 
 
 def main():
     name = sys.argv[1]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-    pw = load_prev()
-    sides = {"prev": pw, "new": wl}
+    sides = {"prev": load_prev(), "new": wl}
+    for tag in os.environ.get("LAB_SIDES", "").split():       # further variants: LAB_SIDES="nomask oldstore" -> .lab_nomask/, .lab_oldstore/
+        sides[tag] = load_side(tag)
     spec = wl.WORKLOADS[name]
     inter = spec.get("mode") == "inter"
     clips = wl.build_clips(name, 0)
@@ -95,8 +101,8 @@ def main():
             run(side, steps)
             dt = (time.perf_counter() - t0) / steps
             best[side] = min(best[side], dt)
-            print(f"round {r} {side:4s}: {dt * 1e3:.4f} ms per step  {moved / dt / 8e12:.4f} of 8 TB/s", flush=True)
-    print(f"best: prev {best['prev'] * 1e3:.4f} ms, new {best['new'] * 1e3:.4f} ms, new/prev {best['new'] / best['prev']:.4f}", flush=True)
+            print(f"round {r} {side:8s}: {dt * 1e3:.4f} ms per step  {moved / dt / 8e12:.4f} of 8 TB/s", flush=True)
+    print("best: " + ", ".join(f"{s} {best[s] * 1e3:.4f} ms ({best[s] / best['prev']:.4f} of prev)" for s in sides), flush=True)
     del info
 
 
