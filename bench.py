@@ -276,7 +276,12 @@ def resident_leg(job: Job, name: str, nfr_override=None, nclips=None):
         try:
             ent = json.load(open(tpath))["per_step"].get(name)
             if ent and ent["kernels"] == kernels and ent["frames_per_step"] == nfr:
-                traffic, traffic_source = ent["hbm_bytes"], ent["source"]
+                # ... and only while the kernels' SOURCES are the ones the passes were taken from (round 6: until then a name match was enough,
+                # and four entries outlived changes to the kernel they describe)
+                if ent.get("kernel_sources") == wl.kernel_source_digest(kernels):
+                    traffic, traffic_source = ent["hbm_bytes"], ent["source"]
+                else:
+                    traffic_source = f"stale: the kernel sources changed since {ent['source']} was taken"
         except Exception:
             pass
     write_share = sum(i["pixels"] for i in infos) * 4 / max(counted, 1)      # the frames written, of all bytes counted
@@ -497,9 +502,9 @@ def measured_ceilings(job: Job):
 
 
 def _with_ceilings(roofline, write_share, live, recorded):
-    """reference_fill / frac_of_reference_fill / recorded_fill for one workload's roofline object.  A yardstick, NOT a ceiling: a plain
-    one-store-per-lane fill of this box's memory, measured in this run — kernels whose stores come in friendlier bursts (all-solid
-    MSVideo1 frames) have been seen 3 % above it.  The roofline fraction proper is `frac`, of the 8 TB/s peak."""
+    """reference_fill / recorded_fill for one workload's roofline object.  A yardstick, NOT a ceiling: a plain one-store-per-lane fill of
+    this box's memory, measured in this run — kernels whose stores come in friendlier bursts (all-solid MSVideo1 frames) have been seen
+    3 % above it, so it is printed as a rate and no fraction of it is formed (round 6).  The roofline fraction is `frac`, of the 8 TB/s peak."""
     rec = None
     if recorded:
         try:
@@ -510,7 +515,6 @@ def _with_ceilings(roofline, write_share, live, recorded):
     ceiling = live or rec
     out = dict(roofline)
     out["reference_fill"] = ceiling
-    out["frac_of_reference_fill"] = round(roofline["achieved"] / ceiling["value"], 4) if ceiling else None
     out["recorded_fill"] = rec
     return out
 
@@ -618,7 +622,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "verified": head["verified"],
-            "verified_how": "after the timed region every destination frame is overwritten with 0xEE bytes, one more untimed step of the same "
+            "verified_how": None if args.no_verify else
+                            "after the timed region every destination frame is overwritten with 0xEE bytes, one more untimed step of the same "
                             "launches runs, and every frame it leaves in HBM is hashed against the CPU oracle's digest (tests/golden/bench_digests.json)",
             "lookback_fallbacks": head["lookback_fallbacks"],
             "config": {

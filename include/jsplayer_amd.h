@@ -133,6 +133,8 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       table with the on-GPU parse kernels (raw frame bytes are all the device needs; a replay of a
  *       staged batch re-runs the parse); frames the parse flags as special fall back to the host
  *       parser one by one, so results are identical either way.
+ *   ("sp_group_chunk" and "msv1_parse_pieces", launch plans of round 4 that measured slower and were removed in round 5, are still accepted and do
+ *   nothing — results never depended on them; their environment twins JSP_SP_GROUP_CHUNK / JSP_MSV1_PARSE_PIECES are no longer read.)
  *   "sp_band_rows" = "auto" (default) | "0" | "<n>" : ScreenPressor only.  Key frames are rebuilt by one
  *       workgroup per band of n rows (0 = the whole frame is one band; auto = sized so a batch fills
  *       the GPU); the host stage hands each band the row above it.  Results do not depend on it.

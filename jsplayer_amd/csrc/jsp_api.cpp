@@ -257,7 +257,11 @@ int jsp_decompress_p(jsp_codec* c, const uint8_t* src, size_t n, int32_t* dst, i
 namespace {
 // Which of the older forms won the last probe of this process (-1: a chunked candidate, or nothing yet): boards differ in which form their memory likes,
 // a board does not change its mind between two pools — the next pool tries that form first instead of finding it again behind seven others.
-std::atomic<int> g_pool_form_hint{-1};
+// (Per device: a process that shards streams over several GPUs, jsp_shard.cpp, has as many boards as devices.)
+constexpr int kHintDevices = 64;
+std::atomic<int> g_pool_form_hint[kHintDevices];
+struct HintInit { HintInit() { for (auto& h : g_pool_form_hint) h.store(-1); } } g_hint_init;
+std::atomic<int>& pool_form_hint(int device) { return g_pool_form_hint[device >= 0 && device < kHintDevices ? device : 0]; }
 }  // namespace
 
 jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
@@ -370,7 +374,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, form == 1 ? "one allocation" : form == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     return true;
                 };
-                int hint = g_pool_form_hint.load();
+                int hint = pool_form_hint(device_id).load();
                 if (const char* f = std::getenv("JSP_POOL_PROBE_FORM")) { const int v = std::atoi(f); if (v >= 0 && v < 3) hint = v; }   // (start with that older form: 0 two frames per allocation, 1 one allocation, 2 one per frame)
                 bool settled = false;
                 if (hint >= 0 && hint < 3) {                   // the form this board liked last time, first
@@ -385,8 +389,10 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                 const int kChunkFrames = 16;
                 int spread = 4;
                 if (settled) spread = 1;                       // (nothing more to try)
-                while (spread > 1 && (uint64_t)(spread + (int)cands.size()) * one > hold_limit) --spread;
                 const int nch = (nbuf + kChunkFrames - 1) / kChunkFrames;
+                // (what a run of s x the pool really holds: whole chunks, so up to 15 frames more per s than s pools)
+                auto run_bytes = [&](int s) { return (uint64_t)nch * (uint64_t)s * (uint64_t)kChunkFrames * (uint64_t)bytes; };
+                while (spread > 1 && run_bytes(spread) + (uint64_t)cands.size() * one > hold_limit) --spread;
                 auto chunk_frames = [&](int ch) { return std::min(kChunkFrames, nbuf - ch * kChunkFrames); };
                 if (spread > 1) {
                     bool ok = true;
@@ -396,7 +402,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         if (ok) run.push_back(d);
                     }
                     if (!ok) { (void)hipGetLastError(); for (void* d : run) (void)hipFree(d); run.clear(); }
-                    else p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)(spread + (int)cands.size()) * one);
+                    else p->held_peak = std::max<uint64_t>(p->held_peak, run_bytes(spread) + (uint64_t)cands.size() * one);
                 }
                 // Which chunks of the run a candidate takes.  "Every fourth" is not always the answer: in some sessions all four such candidates are slow
                 // (5.7 - 6.4 TB/s) while a form made of many small allocations is fast (profiles/r05_q_bench_all.jsonl: candidates_GBs) — the run's chunks
@@ -459,6 +465,9 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     // (an older form — its frames lie densely — must beat the chunked candidate by 3 % to stand before it: the probe's shape does not mind density,
                     // the key-frame kernel's does, profiles/r05_front_lab_frame_order.txt)
                     if (best < 0 || cands[chunked].rate * 1.03 >= cands[best].rate) best = chunked;
+                } else if (!run.empty()) {                     // no chunked candidate was measured (JSP_POOL_PROBE_MAX used up by the hinted form): the run goes back whole
+                    for (void* d : run) (void)hipFree(d);
+                    run.clear();
                 }
                 const bool good_enough = settled || (chunked >= 0 && best == chunked && (yardstick <= 0 || cands[chunked].rate >= 0.95 * yardstick));
                 for (int a = 0; (int)p->tried.size() < kCandidates && !good_enough; ++a) {
@@ -474,7 +483,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (best < 0 || cands.back().rate > cands[best].rate * (best == chunked ? 1.03 : 1.0)) best = (int)cands.size() - 1;
                     if (yardstick > 0 && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill takes)
                 }
-                if (best >= 0) g_pool_form_hint.store(cands[best].form);
+                if (best >= 0) pool_form_hint(device_id).store(cands[best].form);
             } catch (...) {
                 for (auto& c : cands) release(c);
                 for (void* d : run) (void)hipFree(d);
@@ -482,6 +491,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                 throw;
             }
             (void)hipFree(d_table);
+            if (best < 0) throw std::runtime_error("out of device memory for the frame pool");   // (no candidate could be made at all)
             for (int i = 0; i < (int)cands.size(); ++i) if (i != best) release(cands[i]);
             p->attempts = (int)p->tried.size();
             p->store_rate = cands[best].rate;
@@ -591,6 +601,8 @@ int jsp_set_option(jsp_codec* c, const char* key, const char* value) {
         c->async_depth = (int)v;
         return 0;
     }
+    // retired launch-plan options (measured slower, removed in round 5): results never depended on them, so a caller that still sets them is not refused
+    if (std::strcmp(key, "sp_group_chunk") == 0 || std::strcmp(key, "msv1_parse_pieces") == 0) return 0;
     return guarded([&] {
         c->activate();
         return c->set_option(key, value);

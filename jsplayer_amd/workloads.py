@@ -123,6 +123,33 @@ def digest(frame) -> str:
     return hashlib.sha256(data).hexdigest()[:16]
 
 
+_KERNEL_SOURCES = (      # kernel name prefix -> the files under csrc/ its code comes from
+    ("msv1_fused", ("msv1_parse_kernels.hip", "msv1_lanes.h", "msv1_decode.h", "msv1_fused_hooks.h", "msv1.h")),
+    ("msv1_parse", ("msv1_parse_kernels.hip", "msv1_lanes.h", "msv1.h")),
+    ("msv1_blocks", ("msv1_kernels.hip", "msv1_decode.h", "msv1.h")),
+    ("sp_", ("sp_kernels.hip", "sp.h")),
+)
+
+
+def kernel_source_digest(kernels: str) -> str:
+    """A digest of the source files behind the kernels a workload names ("a + b | c"): what a recorded measurement of those kernels
+    (profiles/traffic_by_workload.json) is tied to — bench.py quotes a PMC traffic figure only while the kernels' sources are the ones it was
+    taken from.  (Content, not commits: the GPU box has no .git.)"""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    files = set()
+    for part in kernels.replace("|", "+").split("+"):
+        name = part.strip()
+        for prefix, srcs in _KERNEL_SOURCES:
+            if name.startswith(prefix):
+                files.update(srcs)
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(f.encode())
+        with open(os.path.join(here, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bench_digests.json")
 
 

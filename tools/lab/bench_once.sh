@@ -7,5 +7,5 @@ echo "wall $((SECONDS - s)) s"
 python - "$O/${T}_bench.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]; df = d["config"]["destination_frames"]; e = d.get("e2e", {})
-print(d["value"], r["frac"], r["frac_of_measured"], df.get("allocations_tried"), df.get("probe_GBs"), e.get("value"), e.get("all_threads", {}).get("value"), e.get("batch_api", {}).get("value"))
+print(d["value"], r["frac"], (r.get("reference_fill") or {}).get("value"), df.get("allocations_tried"), df.get("probe_GBs"), e.get("value"), e.get("all_threads", {}).get("value"), e.get("batch_api", {}).get("value"))
 PY

@@ -55,6 +55,9 @@ def summarise(fetch_dir, write_dir, bench_json, out_path):
                                 "read_bytes_per_launch": f_b, "write_bytes_per_launch": w_b}
         rd += f_b * per_step
         wr += w_b * per_step
+    sys.path.insert(0, ROOT)
+    from jsplayer_amd.workloads import kernel_source_digest
+    out["kernel_sources"] = kernel_source_digest(b["roofline"]["kernel"])      # (of the tree that ran: this script runs in the same gpurun call)
     out.update({"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
                 "algorithmic_bytes_per_step": b["roofline"]["algorithmic_bytes_per_step"],
                 "moved_bytes_per_step": b["roofline"]["moved_bytes_per_step"]})
@@ -68,13 +71,14 @@ def install(src, dst):
     json.dump(doc, open(dst_abs, "w"), indent=1)
     reg_path = os.path.join(ROOT, "profiles", "traffic_by_workload.json")
     reg = {"note": "HBM bytes per bench step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_summary.py); bench.py "
-                   "copies an entry into roofline.traffic only while its kernel list and frames_per_step still match", "per_step": {}}
+                   "copies an entry into roofline.traffic only while its kernel list, frames_per_step and the digest of the kernels' source files (workloads.kernel_source_digest) still match", "per_step": {}}
     if os.path.exists(reg_path):
         old = json.load(open(reg_path))
         if "per_step" in old:
             reg = old
     reg["per_step"][doc["workload"]] = {"kernels": doc["kernels"], "frames_per_step": doc["frames_per_step"],
-                                        "hbm_bytes": doc["hbm_bytes"], "source": os.path.relpath(dst_abs, ROOT)}
+                                        "hbm_bytes": doc["hbm_bytes"], "source": os.path.relpath(dst_abs, ROOT),
+                                        "kernel_sources": doc.get("kernel_sources")}
     json.dump(reg, open(reg_path, "w"), indent=1)
     print("registered", doc["workload"], "->", os.path.relpath(dst_abs, ROOT))
 
