@@ -261,7 +261,7 @@ namespace {
 constexpr int kHintDevices = 64;
 std::atomic<int> g_pool_form_hint[kHintDevices];
 struct HintInit { HintInit() { for (auto& h : g_pool_form_hint) h.store(-1); } } g_hint_init;
-std::atomic<int>& pool_form_hint(int device) { return g_pool_form_hint[device >= 0 && device < kHintDevices ? device : 0]; }
+std::atomic<int>* pool_form_hint(int device) { return &g_pool_form_hint[device >= 0 && device < kHintDevices ? device : 0]; }
 }  // namespace
 
 jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
@@ -374,7 +374,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, form == 1 ? "one allocation" : form == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     return true;
                 };
-                int hint = pool_form_hint(device_id).load();
+                int hint = pool_form_hint(device_id)->load();
                 if (const char* f = std::getenv("JSP_POOL_PROBE_FORM")) { const int v = std::atoi(f); if (v >= 0 && v < 3) hint = v; }   // (start with that older form: 0 two frames per allocation, 1 one allocation, 2 one per frame)
                 bool settled = false;
                 if (hint >= 0 && hint < 3) {                   // the form this board liked last time, first
@@ -483,7 +483,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (best < 0 || cands.back().rate > cands[best].rate * (best == chunked ? 1.03 : 1.0)) best = (int)cands.size() - 1;
                     if (yardstick > 0 && cands[best].rate >= 0.985 * yardstick) break;   // as good as it gets (the fast kind takes what a plain fill takes)
                 }
-                if (best >= 0) pool_form_hint(device_id).store(cands[best].form);
+                if (best >= 0) pool_form_hint(device_id)->store(cands[best].form);
             } catch (...) {
                 for (auto& c : cands) release(c);
                 for (void* d : run) (void)hipFree(d);
