@@ -74,11 +74,76 @@ void jsp_staged::finish_results() noexcept {
         if (significant[i] < 0) significant[i] = words[i] ? 1 : 0;
 }
 
+namespace jsp {
+// Device memory put together by hand: one address range, backed by physical allocations (hipMemCreate) mapped into it.  What hipMalloc gives for
+// a multi-gigabyte request and what it gives for a run of smaller ones differ, board by board, in what the decode kernels' store shapes get from them
+// (5.6 - 7.0 TB/s); memory made this way took 6.8 - 7.0 TB/s from all three shapes in every arrangement on every board it was tried on
+// (profiles/r06_vmm_pool_board*.txt), holds exactly the pool and is set up in under a millisecond.
+struct MappedRange {
+    void* va = nullptr;
+    size_t bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    bool empty() const { return va == nullptr; }
+    void release() {
+        if (va) {
+            (void)hipMemUnmap(va, bytes);
+            for (auto h : handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(va, bytes);
+            (void)hipGetLastError();
+        }
+        va = nullptr; bytes = 0; handles.clear();
+    }
+    // `nbuf` frames of `frame_bytes`, sixteen to a physical allocation, DEALT over the allocations (frame i and i + 1 never share one).  False (and nothing
+    // held) when the device or the runtime does not do this.
+    bool make(int device, size_t frame_bytes, int nbuf, std::vector<int32_t*>& frames) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) { (void)hipGetLastError(); return false; }
+        constexpr int kPer = 16;
+        const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
+        const size_t stride = (frame_bytes + gran - 1) / gran * gran;
+        const size_t handle_bytes = (stride * kPer + align - 1) / align * align;
+        const size_t nh = ((size_t)nbuf + kPer - 1) / kPer;
+        bytes = nh * handle_bytes;
+        if (hipMemAddressReserve(&va, bytes, align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); va = nullptr; bytes = 0; return false; }
+        bool ok = true;
+        for (size_t h = 0; h < nh && ok; ++h) {
+            hipMemGenericAllocationHandle_t handle;
+            ok = hipMemCreate(&handle, handle_bytes, &prop, 0) == hipSuccess;
+            if (ok) {
+                handles.push_back(handle);
+                ok = hipMemMap(static_cast<char*>(va) + h * handle_bytes, handle_bytes, 0, handle, 0) == hipSuccess;
+            }
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = ok && hipMemSetAccess(va, bytes, &acc, 1) == hipSuccess;
+        // (the rest of the library — and the caller's torch — must see these addresses as device memory)
+        hipPointerAttribute_t at{};
+        ok = ok && hipPointerGetAttributes(&at, va) == hipSuccess && at.type == hipMemoryTypeDevice;
+        if (!ok) {
+            (void)hipGetLastError();
+            // (ranges of handles that were never mapped: unmapping the whole range may complain, which is all it does)
+            release();
+            return false;
+        }
+        frames.clear();
+        for (int i = 0; i < nbuf; ++i)
+            frames.push_back(reinterpret_cast<int32_t*>(static_cast<char*>(va) + ((size_t)i % nh) * handle_bytes + ((size_t)i / nh) * stride));
+        return true;
+    }
+};
+}  // namespace jsp
 struct jsp_pool {
     int device = 0;
     int X = 0, Y = 0;
     std::vector<int32_t*> bufs;
     std::vector<void*> allocs;     // what to free: one allocation per frame, or one for all of them (bufs point into it)
+    jsp::MappedRange mapped;       // ... or one address range over physical allocations of the pool's own making (the first form tried)
     double store_rate = 0;         // GB/s the chosen slab took from the probe (0: not probed)
     int attempts = 0;              // allocations tried
     double fill_rate = 0;          // GB/s of a plain fill over the first candidate: what the probe is held against
@@ -295,10 +360,10 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
         const bool probe = nbuf >= kProbeFrom && (width & 3) == 0 && (height & 3) == 0 && (size_t)nbuf * (size_t)((width / 4) * (height / 4) + 8191) / 8192 * 256 < (1ull << 32) &&   // (the probe: one launch, fewer than 2^32 lanes)
                            !(env && std::atoi(env) == 0);
         if (probe) {
-            struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; int form = -1; };   // form: -1 chunked, 0 .. 2 the older forms
+            struct Candidate { std::vector<void*> allocs; std::vector<int32_t*> frames; double rate = 0; int form = -1; jsp::MappedRange mapped; };   // form: -1 chunked or mapped, 0 .. 2 the older forms
             std::vector<Candidate> cands;
             std::vector<void*> run;                            // the run of chunk allocations behind the first candidates (spread x the pool)
-            auto release = [](Candidate& c) { for (void* d : c.allocs) (void)hipFree(d); c.allocs.clear(); };
+            auto release = [](Candidate& c) { for (void* d : c.allocs) (void)hipFree(d); c.allocs.clear(); c.mapped.release(); };
             uint32_t** d_table = nullptr;
             int best = -1;
             double yardstick = 0;
@@ -374,16 +439,39 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, form == 1 ? "one allocation" : form == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     return true;
                 };
+                // Round 6: the pool made by hand first (MappedRange above).  It holds the pool and nothing else, costs a millisecond to set up and one probe launch;
+                // when it takes what a plain fill takes — it did on every board of profiles/r06_vmm_pool_board*.txt — nothing else is allocated at all
+                // (until round 5 the first candidate held four times the pool for as long as the probe ran: 27 GB and a third of a second per pool in the
+                // driver's run).  JSP_POOL_PROBE_MAPPED=0: skip it (lab).
+                bool settled = false;
+                {
+                    const char* m = std::getenv("JSP_POOL_PROBE_MAPPED");
+                    Candidate c;
+                    if (!(m && std::atoi(m) == 0) && c.mapped.make(device_id, bytes, nbuf, c.frames)) {
+                        try {
+                            JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
+                            c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
+                        } catch (...) {
+                            release(c);
+                            throw;
+                        }
+                        p->tried.push_back(c.rate);
+                        if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate 0 (one address range over %zu physical allocations of 16 frames, frames dealt): %.0f GB/s (plain fill %.0f)\n", c.mapped.handles.size(), c.rate, yardstick);
+                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)c.mapped.bytes);
+                        cands.push_back(std::move(c));
+                        best = 0;
+                        settled = yardstick > 0 && cands[0].rate >= 0.985 * yardstick;
+                    }
+                }
                 int hint = pool_form_hint(device_id)->load();
                 if (const char* f = std::getenv("JSP_POOL_PROBE_FORM")) { const int v = std::atoi(f); if (v >= 0 && v < 3) hint = v; }   // (start with that older form: 0 two frames per allocation, 1 one allocation, 2 one per frame)
-                bool settled = false;
-                if (hint >= 0 && hint < 3) {                   // the form this board liked last time, first
+                if (!settled && hint >= 0 && hint < 3) {      // the form this board liked last time, next
                     Candidate c;
                     if (make_old(hint, c)) {
                         cands.push_back(std::move(c));
-                        p->held_peak = std::max<uint64_t>(p->held_peak, one);
-                        best = 0;
-                        settled = yardstick > 0 && cands[0].rate >= 0.985 * yardstick;
+                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)cands.size() * one);
+                        if (best < 0 || cands.back().rate > cands[best].rate) best = (int)cands.size() - 1;
+                        settled = yardstick > 0 && cands[best].rate >= 0.985 * yardstick;
                     }
                 }
                 const int kChunkFrames = 16;
@@ -497,6 +585,8 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
             p->store_rate = cands[best].rate;
             p->fill_rate = yardstick;
             p->allocs = cands[best].allocs;
+            p->mapped = std::move(cands[best].mapped);
+            cands[best].mapped = jsp::MappedRange{};
             p->bufs = cands[best].frames;
             for (int32_t* f : p->bufs) JSP_HIP(hipMemset(f, 0, bytes));
             p->probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - probe_t0).count();
@@ -523,6 +613,7 @@ void jsp_pool_destroy(jsp_pool* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void* d : p->allocs) (void)hipFree(d);
+    p->mapped.release();
     delete p;
 }
 double jsp_pool_store_rate(jsp_pool* p, int* attempts) {

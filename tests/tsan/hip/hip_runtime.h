@@ -55,5 +55,24 @@ hipError_t hipEventSynchronize(hipEvent_t);
 hipError_t hipEventQuery(hipEvent_t);
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t*, const void*);
 
+// virtual memory management (the frame pool's first form): the reserved range IS the memory, handles are tokens
+struct StubHandle;
+typedef StubHandle* hipMemGenericAllocationHandle_t;
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAllocationGranularity_flags { hipMemAllocationGranularityMinimum = 0, hipMemAllocationGranularityRecommended = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation { hipMemLocationType type; int id; };
+struct hipMemAllocationProp { hipMemAllocationType type; int requestedHandleType; hipMemLocation location; void* win32HandleMetaData; struct { unsigned char compressionType, gpuDirectRDMACapable; unsigned short usage; } allocFlags; };
+struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
+hipError_t hipMemGetAllocationGranularity(size_t*, const hipMemAllocationProp*, hipMemAllocationGranularity_flags);
+hipError_t hipMemAddressReserve(void**, size_t, size_t alignment, void* addr, unsigned long long flags);
+hipError_t hipMemAddressFree(void*, size_t);
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t*, size_t, const hipMemAllocationProp*, unsigned long long flags);
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t);
+hipError_t hipMemMap(void*, size_t, size_t offset, hipMemGenericAllocationHandle_t, unsigned long long flags);
+hipError_t hipMemUnmap(void*, size_t);
+hipError_t hipMemSetAccess(void*, size_t, const hipMemAccessDesc*, size_t count);
+
 // what the kernel stubs call: "a kernel was queued on this stream"
 void stub_stream_work(hipStream_t stream);

@@ -49,6 +49,16 @@ hipError_t release(void* p) {
 
 void stub_stream_work(hipStream_t stream) { queued(stream); }
 
+struct StubHandle { size_t bytes; };
+hipError_t hipMemGetAllocationGranularity(size_t* g, const hipMemAllocationProp*, hipMemAllocationGranularity_flags) { *g = 4096; return hipSuccess; }
+hipError_t hipMemAddressReserve(void** p, size_t n, size_t, void*, unsigned long long) { return alloc(p, n, hipMemoryTypeDevice); }
+hipError_t hipMemAddressFree(void* p, size_t) { return release(p); }
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t* h, size_t n, const hipMemAllocationProp*, unsigned long long) { *h = new StubHandle{n}; return hipSuccess; }
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { delete h; return hipSuccess; }
+hipError_t hipMemMap(void*, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return hipSuccess; }
+hipError_t hipMemUnmap(void*, size_t) { return hipSuccess; }
+hipError_t hipMemSetAccess(void*, size_t, const hipMemAccessDesc*, size_t) { return hipSuccess; }
+
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "stub HIP error"; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }

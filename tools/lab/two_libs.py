@@ -40,7 +40,9 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     sides = {"prev": load_prev(), "new": wl}
     for tag in os.environ.get("LAB_SIDES", "").split():       # further variants: LAB_SIDES="nomask oldstore" -> .lab_nomask/, .lab_oldstore/
-        sides[tag] = load_side(tag)
+        # "prev#2" / "new#2": the SAME library staged a second time (codecs, tables and all of its own) — what two stagings of one kernel differ by
+        base = tag.split("#")[0]
+        sides[tag] = sides[base] if base in sides else load_side(base)
     spec = wl.WORKLOADS[name]
     inter = spec.get("mode") == "inter"
     clips = wl.build_clips(name, 0)
@@ -94,8 +96,10 @@ def main():
     for side in sides:
         run(side, 3)
     best = {s: 1e9 for s in sides}
+    order = list(sides)
     for r in range(rounds):
-        for side in sides:
+        order = order[1:] + order[:1]                          # (every side gets every place in the round)
+        for side in order:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             run(side, steps)
