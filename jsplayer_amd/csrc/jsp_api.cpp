@@ -460,7 +460,9 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)c.mapped.bytes);
                         cands.push_back(std::move(c));
                         best = 0;
-                        settled = yardstick > 0 && cands[0].rate >= 0.985 * yardstick;
+                        // (within 3 % of the plain fill: on the boards of profiles/r06_vmm_pool_board*.txt this form took 6.75 - 6.99 TB/s where the best
+                        // hipMalloc arrangement of the board took 6.42 - 7.03)
+                        settled = yardstick > 0 && cands[0].rate >= 0.97 * yardstick;
                     }
                 }
                 int hint = pool_form_hint(device_id)->load();

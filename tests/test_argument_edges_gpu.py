@@ -126,13 +126,15 @@ def test_measure_h2d_and_the_bounded_pool_probe(monkeypatch):
     pool = FramePool(1920, 1080, 32)
     try:
         assert 1 <= pool.attempts <= 2 and pool.store_rate > 100.0
-        assert pool.probe_ms > 0 and 32 * 1920 * 1080 * 4 <= pool.held_bytes <= 4 * 32 * 1920 * 1080 * 4 and pool.held_bytes <= pool.hold_limit   # (the first candidate: four times the pool's chunks, every fourth kept)
+        assert pool.probe_ms > 0 and 32 * 1920 * 1080 * 4 <= pool.held_bytes <= 5.1 * 32 * 1920 * 1080 * 4 and pool.held_bytes <= pool.hold_limit   # (at most: the mapped form and a run of four times the pool's chunks)
     finally:
         pool.close()
     monkeypatch.setenv("JSP_POOL_PROBE_HOLD_GB", "0.1")          # less than one candidate: the pool itself is still allowed, nothing beside it
     pool = FramePool(1920, 1080, 32)
     try:
-        assert pool.attempts == 1 and pool.held_bytes == 32 * 1920 * 1080 * 4 == pool.hold_limit
+        # (the first form is an address range over physical allocations of 16 frames each, rounded up to 2 MB: the pool and a per cent)
+        one = 32 * 1920 * 1080 * 4
+        assert pool.attempts == 1 and one == pool.hold_limit and one <= pool.held_bytes <= one * 1.02
     finally:
         pool.close()
     # the form a board liked last time is tried first (here: said through the environment); whatever wins, the pool is whole
