@@ -93,16 +93,16 @@ struct MappedRange {
         }
         va = nullptr; bytes = 0; handles.clear();
     }
-    // `nbuf` frames of `frame_bytes`, sixteen to a physical allocation, DEALT over the allocations (frame i and i + 1 never share one).  False (and nothing
-    // held) when the device or the runtime does not do this.
-    bool make(int device, size_t frame_bytes, int nbuf, std::vector<int32_t*>& frames) {
+    // `nbuf` frames of `frame_bytes`, `per` to a physical allocation; `dealt`: frame i and i + 1 never share one (frame i lies in allocation i mod n),
+    // else the frames lie in order.  False (and nothing held) when the device or the runtime does not do this.
+    bool make(int device, size_t frame_bytes, int nbuf, std::vector<int32_t*>& frames, int per = 16, bool dealt = true) {
         hipMemAllocationProp prop{};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
         prop.location.id = device;
         size_t gran = 0;
         if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) { (void)hipGetLastError(); return false; }
-        constexpr int kPer = 16;
+        const int kPer = per < 1 ? 1 : per;
         const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
         const size_t stride = (frame_bytes + gran - 1) / gran * gran;
         const size_t handle_bytes = (stride * kPer + align - 1) / align * align;
@@ -132,8 +132,10 @@ struct MappedRange {
             return false;
         }
         frames.clear();
-        for (int i = 0; i < nbuf; ++i)
-            frames.push_back(reinterpret_cast<int32_t*>(static_cast<char*>(va) + ((size_t)i % nh) * handle_bytes + ((size_t)i / nh) * stride));
+        for (int i = 0; i < nbuf; ++i) {
+            const size_t h = dealt ? (size_t)i % nh : (size_t)i / (size_t)kPer, slot = dealt ? (size_t)i / nh : (size_t)i % (size_t)kPer;
+            frames.push_back(reinterpret_cast<int32_t*>(static_cast<char*>(va) + h * handle_bytes + slot * stride));
+        }
         return true;
     }
 };
@@ -439,15 +441,29 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, form == 1 ? "one allocation" : form == 0 ? "two frames per allocation" : "one allocation per frame", c.rate, yardstick);
                     return true;
                 };
-                // Round 6: the pool made by hand first (MappedRange above).  It holds the pool and nothing else, costs a millisecond to set up and one probe launch;
-                // when it takes what a plain fill takes — it did on every board of profiles/r06_vmm_pool_board*.txt — nothing else is allocated at all
-                // (until round 5 the first candidate held four times the pool for as long as the probe ran: 27 GB and a third of a second per pool in the
-                // driver's run).  JSP_POOL_PROBE_MAPPED=0: skip it (lab).
+                // Round 6: the pool made by hand first (MappedRange above), in up to three arrangements: sixteen frames per physical allocation and the frames
+                // dealt over them; an allocation per frame; sixteen per allocation, frames in order.  Each holds the pool and nothing else, costs a few
+                // milliseconds to set up and one probe launch; the best so far stays held while the next is measured (twice the pool, briefly, and only when
+                // the first was not good enough).  The first that comes within 3 % of a plain fill is kept — on the boards of profiles/r06_vmm_pool_board*.txt
+                // this form took 6.75 - 6.99 TB/s from all three store shapes where the best hipMalloc arrangement of the board took 6.42 - 7.03.  And when none
+                // does (a board in its slow state: profiles/r06_h_bench_default_slow_board.json, every one of sixteen candidates of every kind at 5.2 - 5.8) the
+                // best of the three is kept all the same: the hipMalloc forms cost half a second and a pool's worth of memory EACH to try (16 candidates, 2.2 s
+                // and 55 GB held per pool in that run) and were not better there.  They are still tried when this form cannot be made at all, or on request
+                // (JSP_POOL_PROBE_THOROUGH=1).  JSP_POOL_PROBE_MAPPED=0: skip the mapped forms (lab).
                 bool settled = false;
                 {
                     const char* m = std::getenv("JSP_POOL_PROBE_MAPPED");
-                    Candidate c;
-                    if (!(m && std::atoi(m) == 0) && c.mapped.make(device_id, bytes, nbuf, c.frames)) {
+                    const char* th = std::getenv("JSP_POOL_PROBE_THOROUGH");
+                    const bool thorough = th && std::atoi(th) != 0;
+                    struct Form { int per; bool dealt; const char* what; };
+                    static const Form forms[] = {{16, true, "16 frames per physical allocation, frames dealt"}, {1, true, "a physical allocation per frame"}, {16, false, "16 frames per physical allocation, frames in order"}};
+                    int best_form = -1;
+                    double best_rate = 0;
+                    Candidate held;
+                    for (int k = 0; k < 3 && !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {
+                        Candidate c;
+                        if (best_form >= 0 && (uint64_t)held.mapped.bytes + one > hold_limit) break;   // (the best so far stays held while the next is measured: twice the pool, briefly)
+                        if (!c.mapped.make(device_id, bytes, nbuf, c.frames, forms[k].per, forms[k].dealt)) break;
                         try {
                             JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
                             c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
@@ -456,13 +472,18 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                             throw;
                         }
                         p->tried.push_back(c.rate);
-                        if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate 0 (one address range over %zu physical allocations of 16 frames, frames dealt): %.0f GB/s (plain fill %.0f)\n", c.mapped.handles.size(), c.rate, yardstick);
-                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)c.mapped.bytes);
-                        cands.push_back(std::move(c));
+                        if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (one address range over %zu physical allocations: %s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, c.mapped.handles.size(), forms[k].what, c.rate, yardstick);
+                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)c.mapped.bytes + (uint64_t)held.mapped.bytes);
+                        const bool good = yardstick > 0 && c.rate >= 0.97 * yardstick;
+                        if (c.rate > best_rate) { best_rate = c.rate; best_form = k; release(held); held = std::move(c); c.mapped = jsp::MappedRange{}; }
+                        else release(c);
+                        if (good) break;
+                    }
+                    if (best_form >= 0) {
+                        cands.push_back(std::move(held));
+                        held.mapped = jsp::MappedRange{};
                         best = 0;
-                        // (within 3 % of the plain fill: on the boards of profiles/r06_vmm_pool_board*.txt this form took 6.75 - 6.99 TB/s where the best
-                        // hipMalloc arrangement of the board took 6.42 - 7.03)
-                        settled = yardstick > 0 && cands[0].rate >= 0.97 * yardstick;
+                        settled = !thorough || (yardstick > 0 && best_rate >= 0.97 * yardstick);
                     }
                 }
                 int hint = pool_form_hint(device_id)->load();
