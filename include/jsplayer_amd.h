@@ -133,6 +133,10 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       table with the on-GPU parse kernels (raw frame bytes are all the device needs; a replay of a
  *       staged batch re-runs the parse); frames the parse flags as special fall back to the host
  *       parser one by one, so results are identical either way.
+ *   "msv1_parse_ahead" = "on" (default) | "off" : MSVideo1 only, replays of a staged batch of inter frames (jsp_staged_decode called again on the
+ *       same batch).  Such a replay is a table-writing parse launch and the reconstruction launches that read the tables; "on" queues the NEXT
+ *       replay's parse on a second stream of the codec, into a second set of tables, beside this replay's reconstruction (jsp_sync waits for both
+ *       streams).  Costs a second table set (4 bytes per block and frame).  Results do not depend on it.
  *   ("sp_group_chunk" and "msv1_parse_pieces", launch plans of round 4 that measured slower and were removed in round 5, are still accepted and do
  *   nothing — results never depended on them; their environment twins JSP_SP_GROUP_CHUNK / JSP_MSV1_PARSE_PIECES are no longer read.)
  *   "sp_band_rows" = "auto" (default) | "0" | "<n>" : ScreenPressor only.  Key frames are rebuilt by one

@@ -70,6 +70,7 @@ struct jsp_codec {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // a second stream of the codec's own (made on first use): work that runs BESIDE the launches on `stream` — jsp_sync waits for both
 
     // Caller-visible previous frame (identity) and where its pixels live in HBM.
     int32_t* prev_caller = nullptr;

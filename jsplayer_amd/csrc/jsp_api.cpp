@@ -37,6 +37,7 @@ jsp_codec::~jsp_codec() {
         if (j.done) (void)hipEventDestroy(j.done);
     }
     scratch.reset();
+    if (side_stream) { (void)hipStreamSynchronize(side_stream); (void)hipStreamDestroy(side_stream); }
     if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
@@ -922,6 +923,7 @@ int jsp_sync(jsp_codec* c) {
         c->activate();
         c->worker_drain();
         JSP_HIP(hipStreamSynchronize(c->stream));
+        if (c->side_stream) JSP_HIP(hipStreamSynchronize(c->side_stream));   // (what was queued beside the launches counts as the caller's work too)
         return 0;
     });
 }

@@ -53,6 +53,36 @@ struct Msv1Staged : jsp_staged {
     // (Round 4 also wrote the replay's tables in PIECES of frames on a second stream, beside the launches that read the piece before — option
     // "msv1_parse_pieces": bit-exact and 12 - 50 % slower in every split, profiles/r04_msv1_parse_pieces.txt; removed in round 5, commit history has it.)
 
+    // Replays of an inter-frame batch (round 6, option "msv1_parse_ahead", default on): the table-writing parse of the NEXT replay runs on the codec's
+    // second stream beside this replay's temporal launch, into the OTHER of two table sets — the parse reads nothing but the stream bytes, so only the
+    // tables' readers and writers have to be kept apart (events below).  Every replay still costs one parse launch and its reconstruction launches; what
+    // changes is that the parse (0.15 - 0.19 ms of a 1.02 ms step at 512 x 1080p) no longer stands in front of the launch that needs it.
+    hipStream_t side = nullptr;        // the codec's second stream; null: everything in line on the caller's stream
+    DeviceBuffer d_desc2;              // the second table set (allocated by the first replay that runs ahead)
+    hipEvent_t ev_fork = nullptr, ev_tables = nullptr;   // "the stream has reached this replay's reconstruction launches" / "the tables written ahead are complete"
+    int cur_set = 0;                   // which set this replay's launches read
+    bool ahead_valid = false;          // the tables of cur_set were written ahead (on `side`) and ev_tables says when
+    uint32_t* desc_set(int i) { return static_cast<uint32_t*>(i ? d_desc2.p : d_desc.p); }
+    void launch_table_parse(uint32_t* tables, hipStream_t on) {
+        for (uint32_t i : scrub)
+            JSP_HIP(hipMemsetAsync(tables + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE, sizeof(uint32_t) * (size_t)geo.nblocks, on));
+        // (the tile records carry the frames' table addresses: the second set is `table_shift` words further on)
+        msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(tables == d_desc.p ? d_recs_emit.p : d_recs_emit2.p), d_palette,
+                          static_cast<unsigned long long*>(d_agg_emit.p), next_epoch(epoch), 0, ntiles_emit, static_cast<uint32_t*>(d_sync.p), on,
+                          nullptr, 0, 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles_emit, nullptr, /*small_tiles=*/true);   // (`want`: where a lab build's phase clocks go)
+    }
+    DeviceBuffer d_recs_emit2;         // the table-writing form's tile records with the second set's addresses
+    void quiesce_side() {              // nothing of this batch is left running beside the stream (before its buffers are reused or freed)
+        if (side) (void)hipStreamSynchronize(side);
+        ahead_valid = false;
+        cur_set = 0;
+    }
+    ~Msv1Staged() override {
+        if (side) (void)hipStreamSynchronize(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_tables) (void)hipEventDestroy(ev_tables);
+    }
+
     void launch_parse(hipStream_t stream) {
         msv1_launch_parse(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1ParseFrame*>(d_pframes.p),
                           nframes, static_cast<const uint32_t*>(d_tile_frame.p), ntiles, max_tiles,
@@ -67,14 +97,32 @@ struct Msv1Staged : jsp_staged {
         // A replay re-executes the whole device pipeline: with the on-GPU parse that includes the
         // parse kernels, so a staged batch can be timed from raw stream bytes.  (The first decode
         // uses the tables the staging pass left behind.)
-        if (gpu_parse && decoded && needs_desc)   // one launch: the fused kernel's parse, writing block tables instead of pixels
-        {
-            for (uint32_t i : scrub)
-                JSP_HIP(hipMemsetAsync(static_cast<uint32_t*>(d_desc.p) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE,
-                                       sizeof(uint32_t) * (size_t)geo.nblocks, stream));
-            msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(d_recs_emit.p), d_palette,
-                              static_cast<unsigned long long*>(d_agg_emit.p), next_epoch(epoch), 0, ntiles_emit, static_cast<uint32_t*>(d_sync.p), stream,
-                              nullptr, 0, 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles_emit, nullptr, /*small_tiles=*/true);   // (`want`: where a lab build's phase clocks go)
+        const bool replay = gpu_parse && decoded && needs_desc;    // one launch: the fused kernel's parse, writing block tables instead of pixels
+        const bool run_ahead = side != nullptr && gpu_parse && needs_desc && ntiles_emit > 0;
+        if (replay) {
+            if (run_ahead && ahead_valid) JSP_HIP(hipStreamWaitEvent(stream, ev_tables, 0));   // written beside the replay before this one
+            else launch_table_parse(desc_set(cur_set), stream);
+        }
+        const uint32_t* tables = desc_set(cur_set);
+        if (run_ahead && decoded) {
+            // the next replay's tables, into the other set, beside the launches below: the other set's last readers (the replay before this one) and the
+            // last table-writing launch (it shares the published tile words and the fault word) are all in front of `ev_fork` on the stream
+            const size_t table_bytes = sizeof(uint32_t) * (size_t)std::max(geo.nblocks, 1) * (size_t)nframes;
+            if (!d_desc2.p) {
+                d_desc2.reserve(table_bytes);
+                JSP_HIP(hipMemcpyAsync(d_desc2.p, d_desc.p, table_bytes, hipMemcpyDeviceToDevice, stream));   // (tables the replay never rewrites — host-parsed frames — are in both)
+                std::vector<Msv1TileRec> recs2((size_t)ntiles_emit);
+                std::memcpy(recs2.data(), h_recs_emit.p, sizeof(Msv1TileRec) * recs2.size());
+                for (auto& r : recs2) r.dst = reinterpret_cast<int32_t*>(static_cast<uint32_t*>(d_desc2.p) + (reinterpret_cast<uint32_t*>(r.dst) - static_cast<uint32_t*>(d_desc.p)));
+                d_recs_emit2.reserve(sizeof(Msv1TileRec) * recs2.size());
+                JSP_HIP(hipMemcpy(d_recs_emit2.p, recs2.data(), sizeof(Msv1TileRec) * recs2.size(), hipMemcpyHostToDevice));
+                if (!ev_fork) JSP_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                if (!ev_tables) JSP_HIP(hipEventCreateWithFlags(&ev_tables, hipEventDisableTiming));
+            }
+            JSP_HIP(hipEventRecord(ev_fork, stream));
+            JSP_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+            launch_table_parse(desc_set(cur_set ^ 1), side);
+            JSP_HIP(hipEventRecord(ev_tables, side));
         }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
         const auto* frames = static_cast<const Msv1FrameArgs*>(d_frames.p);
@@ -87,12 +135,9 @@ struct Msv1Staged : jsp_staged {
                                   static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), tile0, (int)(last.first_tile + last.ntiles - tile0),
                                   static_cast<uint32_t*>(d_sync.p), stream, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);
             } else if (g.temporal) {
-                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p),
-                                            static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count, d_palette, stream);
+                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p), tables, frames + g.first, g.count, d_palette, stream);
             } else {
-                msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p),
-                                   static_cast<const uint32_t*>(d_desc.p), frames + g.first, g.count,
-                                   d_palette, vec_ok, stream);
+                msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p), tables, frames + g.first, g.count, d_palette, vec_ok, stream);
             }
             if (g.edge_compare) msv1_launch_edge_compare(geo, frames + g.first, g.count, stream);
         }
@@ -103,6 +148,7 @@ struct Msv1Staged : jsp_staged {
         if (any_fused || needs_desc)
             JSP_HIP(hipMemcpyAsync(h_fault.p, d_sync.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         ++clock_launches;
+        if (run_ahead && decoded) { cur_set ^= 1; ahead_valid = true; }   // the next replay reads what was just started beside this one
         decoded = true;
     }
     int clock_launches = 0;                                    // (read by the lab build's phase clocks only: msv1_fused_hooks.h)
@@ -130,6 +176,7 @@ struct Msv1Staged : jsp_staged {
             note_kernel("msv1_parse_tiles (look-back fallback)");
             *static_cast<uint32_t*>(h_fault.p) = 0;
             hipStream_t stream = last_stream;
+            quiesce_side();                            // (a table-writing launch may be running beside the stream: it shares the fault word, and its tables are not to be trusted either)
             JSP_HIP(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(uint32_t) + 64, stream));
             launch_parse(stream);
             if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
@@ -360,6 +407,7 @@ struct Msv1Codec : jsp_codec {
     // Several frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until enough frames are submitted behind it
     // — half of what may be in flight ("async_depth"), at most 1 + MSV1_MAX_RIDERS — and they go out together (Msv1AsyncStaged::decode_with);
     // or with whatever is held, as soon as anybody waits for one of them or anything else needs the stream.
+    bool opt_parse_ahead = [] { const char* e = std::getenv("JSP_MSV1_PARSE_AHEAD"); return !(e && e[0] == '0'); }();
     bool opt_async_pairs = [] { const char* e = std::getenv("JSP_MSV1_ASYNC_PAIRS"); return !(e && e[0] == '0'); }();
     std::vector<jsp_async_job*> held;
     long long paired_frames = 0;      // jsp_counter("paired_frames"): frames that shared a launch with others
@@ -462,6 +510,11 @@ struct Msv1Codec : jsp_codec {
             if (std::strcmp(value, "on") != 0 && std::strcmp(value, "off") != 0) return JSP_ERROR_OCCURED;
             launch_held();
             opt_async_pairs = std::strcmp(value, "on") == 0;
+            return 0;
+        }
+        if (std::strcmp(key, "msv1_parse_ahead") == 0) {    // replays of an inter-frame batch: the next replay's table-writing parse beside this replay's launches (on), or in front of them (off)
+            if (std::strcmp(value, "on") != 0 && std::strcmp(value, "off") != 0) return JSP_ERROR_OCCURED;
+            opt_parse_ahead = std::strcmp(value, "on") == 0;
             return 0;
         }
         if (std::strcmp(key, "msv1_scrub_tables") == 0) {   // tests: a replay must rebuild every block table it reads
@@ -694,6 +747,13 @@ struct Msv1Codec : jsp_codec {
         std::unique_ptr<Msv1Staged> guard(reuse ? nullptr : st);
         const int nf = (int)frames.size();
         const size_t nblk = (size_t)std::max(geo.nblocks, 1);
+        st->quiesce_side();                            // (a reused batch: nothing of its last replay still runs beside the stream)
+        st->d_desc2.release();
+        st->side = nullptr;
+        if (opt_parse_ahead) {
+            if (!side_stream) JSP_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            st->side = side_stream;
+        }
         st->geo = geo;
         st->nframes = nf;
         st->decoded = false;

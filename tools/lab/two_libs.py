@@ -61,6 +61,9 @@ def main():
         items = []
         for clip, dsts, first in zip(clips, dsts_all, firsts):
             codec = mod.make_codec(name, clip.palette, device=0)
+            for kv in os.environ.get("LAB_OPT_" + side.replace("#", "_"), "").split(","):      # LAB_OPT_new_2="msv1_parse_ahead=off": options of that side's codecs
+                if "=" in kv:
+                    codec.set_option(*kv.split("=", 1))
             frames, keys = clip.frames, clip.keys
             if inter:
                 assert codec.DecompressI(frames[0], first) == 0
