@@ -380,15 +380,16 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
             p->hold_limit = hold_limit;
             try {
                 JSP_HIP(hipMalloc(reinterpret_cast<void**>(&d_table), sizeof(uint32_t*) * (size_t)nbuf));
-                // the yardstick: what a plain fill takes from this device right now (a slab of its own, given back at once)
-                {
+                // the yardstick: what a plain fill takes from this device right now.  Measured on the first mapped candidate's own memory below (a 2 GB slab
+                // of its own, as until round 6, costs a quarter of a second in hipMalloc alone on most boards); the slab only when no mapped form can be made.
+                auto slab_yardstick = [&] {
                     void* slab = nullptr;
                     const size_t slab_bytes = (size_t)std::min<uint64_t>(one, 2ull << 30);
                     if (hipMalloc(&slab, slab_bytes) == hipSuccess) {
                         yardstick = jsp::pool_fill_rate(static_cast<uint32_t*>(slab), slab_bytes);
                         (void)hipFree(slab);
                     } else (void)hipGetLastError();
-                }
+                };
                 // Round 5 (tools/front_lab.hip; profiles/r05_front_lab_chunks.txt, r05_front_lab_spread.txt, r05_front_lab_spread_shapes.txt,
                 // r05_front_lab_frame_order.txt).  Two things make a pool slow, and neither is visible to any query:
                 //  (1) frames lying NEXT TO each other.  Chunks of 64 frames of slow and of fast pools, put together into one pool, take 7.1 TB/s
@@ -457,7 +458,9 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     const char* th = std::getenv("JSP_POOL_PROBE_THOROUGH");
                     const bool thorough = th && std::atoi(th) != 0;
                     struct Form { int per; bool dealt; const char* what; };
-                    static const Form forms[] = {{16, true, "16 frames per physical allocation, frames dealt"}, {1, true, "a physical allocation per frame"}, {16, false, "16 frames per physical allocation, frames in order"}};
+                    // (the order: on the one board of five where the three differed, an allocation per frame took 7.2 TB/s and sixteen per allocation 6.3 - 6.5,
+                    // profiles/r06_j_bench_default.json)
+                    static const Form forms[] = {{1, true, "a physical allocation per frame"}, {16, true, "16 frames per physical allocation, frames dealt"}, {16, false, "16 frames per physical allocation, frames in order"}};
                     int best_form = -1;
                     double best_rate = 0;
                     Candidate held;
@@ -466,6 +469,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         if (best_form >= 0 && (uint64_t)held.mapped.bytes + one > hold_limit) break;   // (the best so far stays held while the next is measured: twice the pool, briefly)
                         if (!c.mapped.make(device_id, bytes, nbuf, c.frames, forms[k].per, forms[k].dealt)) break;
                         try {
+                            if (yardstick <= 0) yardstick = jsp::pool_fill_rate(static_cast<uint32_t*>(c.mapped.va), (size_t)std::min<uint64_t>((uint64_t)c.mapped.bytes, 2ull << 30));
                             JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
                             c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
                         } catch (...) {
@@ -480,6 +484,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         else release(c);
                         if (good) break;
                     }
+                    if (best_form < 0) slab_yardstick();        // (no mapped form could be made: the older forms are held against a slab's fill)
                     if (best_form >= 0) {
                         cands.push_back(std::move(held));
                         held.mapped = jsp::MappedRange{};
