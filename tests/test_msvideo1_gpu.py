@@ -289,6 +289,63 @@ def test_replay_rebuilds_its_block_tables_with_buffers_repeating_inside_the_grou
     st.close()
 
 
+@pytest.mark.parametrize("ahead", ["on", "off"])
+def test_replays_back_to_back_with_the_next_parse_running_beside_them(ahead):
+    """Option msv1_parse_ahead: a replay of an inter-frame batch queues the NEXT replay's table-writing parse on the codec's second stream,
+    into the other of two table sets, beside its own temporal launch.  Replays queued back to back with no wait between them, tables poisoned
+    before every parse, a look-back fault injected on a later replay (the parse running ahead shares the fault word: the batch is then redone
+    through the three-kernel parse and must still come out right), and the batch restaged afterwards: frames equal the oracle's every time,
+    on and off alike."""
+    if PARSE_MODE != "gpu":
+        pytest.skip("on-GPU parse only")
+    w, h, n = 320, 240, 70
+    frames, keys, pal = sg.msv1_clip(23, w, h, n, p_mix=sg.msv1_p_mix(0.7, 25.0), key_every=n + 1)
+    gpu = make_gpu(16, w, h, pal)
+    gpu.Preinit(36)
+    gpu.set_option("msv1_parse_ahead", ahead)
+    gpu.set_option("msv1_scrub_tables", "1")
+    nbuf = 4
+    dsts = [dev_buf(w * h, 3) for _ in range(nbuf)]
+    orc = OracleMSVideo1(16, w, h, pal)
+    orc.Preinit(36)
+    obufs = [np.full(w * h, 3, dtype=np.int32) for _ in range(nbuf)]
+    for i in range(n):
+        (orc.DecompressI if keys[i] else orc.DecompressP)(frames[i], obufs[i % nbuf])
+    st = gpu.stage_batch(frames, [dsts[i % nbuf] for i in range(n)], is_key=keys)
+    assert "msv1_blocks_temporal_kernel" in st.kernels()
+
+    def check(tag):
+        gpu.sync()
+        assert st.results()[0] == [0] * n, tag
+        for k in range(nbuf):
+            assert np.array_equal(obufs[k], to_np(dsts[k])), (tag, k)
+
+    st.decode()
+    check("first decode")
+    for burst in (1, 4, 7):                                    # replays with nothing between them: only the events order parse and reconstruction
+        for d in dsts:
+            d.fill_(3)
+        for _ in range(burst):
+            st.decode()
+        check(f"burst of {burst}")
+    assert gpu.counter("lookback_fallbacks") == 0
+    gpu.set_option("msv1_inject_fault", "1")                   # takes effect at the next staging: restage, replay, fault at the check
+    st = gpu.stage_batch(frames, [dsts[i % nbuf] for i in range(n)], is_key=keys, reuse=st)   # (jsp_restage_batch: the parse that ran ahead of the last replay is waited for first)
+    for d in dsts:
+        d.fill_(3)
+    st.decode()
+    st.decode()
+    check("fault on a replay")
+    assert gpu.counter("lookback_fallbacks") == 1 and "look-back fallback" in st.kernels()
+    gpu.set_option("msv1_inject_fault", "0")
+    for d in dsts:
+        d.fill_(3)
+    st.decode()
+    st.decode()
+    check("after the fall-back")
+    st.close()
+
+
 @pytest.mark.parametrize("bits", [16, 8])
 def test_look_back_fault_falls_back_to_the_descriptor_kernels(bits):
     """A tile that gives up waiting for its predecessor (GPU shared with other work, profiler serialisation) is a matter of
