@@ -82,17 +82,17 @@ namespace jsp {
 // (profiles/r06_vmm_pool_board*.txt), holds exactly the pool and is set up in under a millisecond.
 struct MappedRange {
     void* va = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, handle_bytes = 0, mapped = 0;      // (mapped: how many of `handles` are mapped, in order from the range's start)
     std::vector<hipMemGenericAllocationHandle_t> handles;
     bool empty() const { return va == nullptr; }
     void release() {
         if (va) {
-            (void)hipMemUnmap(va, bytes);
+            for (size_t h = 0; h < mapped; ++h) (void)hipMemUnmap(static_cast<char*>(va) + h * handle_bytes, handle_bytes);   // piece by piece: a range only partly mapped (a failed make) unmaps what it has
             for (auto h : handles) (void)hipMemRelease(h);
             (void)hipMemAddressFree(va, bytes);
             (void)hipGetLastError();
         }
-        va = nullptr; bytes = 0; handles.clear();
+        va = nullptr; bytes = handle_bytes = mapped = 0; handles.clear();
     }
     // `nbuf` frames of `frame_bytes`, `per` to a physical allocation; `dealt`: frame i and i + 1 never share one (frame i lies in allocation i mod n),
     // else the frames lie in order.  False (and nothing held) when the device or the runtime does not do this.
@@ -106,10 +106,10 @@ struct MappedRange {
         const int kPer = per < 1 ? 1 : per;
         const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
         const size_t stride = (frame_bytes + gran - 1) / gran * gran;
-        const size_t handle_bytes = (stride * kPer + align - 1) / align * align;
+        handle_bytes = (stride * kPer + align - 1) / align * align;
         const size_t nh = ((size_t)nbuf + kPer - 1) / kPer;
         bytes = nh * handle_bytes;
-        if (hipMemAddressReserve(&va, bytes, align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); va = nullptr; bytes = 0; return false; }
+        if (hipMemAddressReserve(&va, bytes, align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); va = nullptr; bytes = handle_bytes = 0; return false; }
         bool ok = true;
         for (size_t h = 0; h < nh && ok; ++h) {
             hipMemGenericAllocationHandle_t handle;
@@ -117,6 +117,7 @@ struct MappedRange {
             if (ok) {
                 handles.push_back(handle);
                 ok = hipMemMap(static_cast<char*>(va) + h * handle_bytes, handle_bytes, 0, handle, 0) == hipSuccess;
+                if (ok) ++mapped;
             }
         }
         hipMemAccessDesc acc{};
@@ -128,7 +129,6 @@ struct MappedRange {
         ok = ok && hipPointerGetAttributes(&at, va) == hipSuccess && at.type == hipMemoryTypeDevice;
         if (!ok) {
             (void)hipGetLastError();
-            // (ranges of handles that were never mapped: unmapping the whole range may complain, which is all it does)
             release();
             return false;
         }

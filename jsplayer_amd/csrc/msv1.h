@@ -13,6 +13,13 @@ namespace jsp {
 // byte offset of the block's code word inside the batch's stream buffer, or one of:
 constexpr uint32_t MSV1_DESC_SKIP = 0xFFFFFFFFu;       // copy the block from the previous frame
 constexpr uint32_t MSV1_DESC_UNTOUCHED = 0xFFFFFFFEu;  // leave dst as it is (end marker / abort)
+// The COMPACT block table (round 6: what the replays of an inter-frame batch write and read): 2 bytes per block — the code's offset in the stream buffer
+// modulo 32 768, or a sentinel with bit 15 set — plus ONE 32-bit base per group of 256 blocks: the offset of some code of that group.  A group's codes lie
+// within 256 x 18 bytes of each other, so base and the 15 bits give the offset back (msv1_tab16_offset); any code of the group may serve as its base, which
+// is what lets two tiles that share a group each write one without agreeing on it.  Half the table bytes, written and read.
+constexpr uint32_t MSV1_TAB16_SKIP = 0xFFFEu, MSV1_TAB16_UNTOUCHED = 0xFFFFu;
+inline int msv1_tab16_pitch(int nblocks) { return (nblocks + 7) & ~7; }          // entries per frame row (rows start on 16-byte boundaries)
+inline int msv1_tab16_groups(int nblocks) { return (nblocks + 255) / 256; }
 
 // Per-frame launch record, read by every workgroup of that frame (grid.y = frame).
 struct Msv1FrameArgs {
@@ -123,6 +130,7 @@ constexpr uint32_t MSV1_VERDICT_GO = 1u, MSV1_VERDICT_VETO = 2u;
 constexpr uint32_t MSV1_LAB_DEAF = 0x80000000u;   // in `bad_mask` (tests): mode 3 tiles never see all reports in — the verdict is the time-out's
 // mode 4 (batch form): nothing is rebuilt; every tile writes its blocks' entries of the frame's descriptor table (the record's
 // `dst` points at it) — the on-GPU descriptor parse in ONE launch, for the batches whose frames depend on each other.
+// mode 5: the same, writing the COMPACT table (above): the record's `dst` points at the frame's 2-byte entries, its `prev` at the frame's group bases.
 // mode 3 (one frame per launch, at most MSV1_MERGED_MAX_TILES tiles): scout and decode in ONE launch — every tile parses
 // and reports, waits until all `ntiles` reports are in (`want` = the value of d_info->arrived / finished once this launch is
 // through), and only then writes, or does not.  All tiles share `*one_rec` (k = the tile's index); the last workgroup copies
@@ -172,7 +180,10 @@ void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const 
 // 16-byte aligned buffers, and frames that write all of their blocks or none).
 void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
                                  const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
-                                 hipStream_t stream);
+                                 hipStream_t stream, const uint16_t* d_tab16 = nullptr, const uint32_t* d_bases = nullptr);   // d_tab16 != null: the compact table instead of d_desc
+// The compact form of `count` frames' 4-byte tables (frames listed in d_list): for the frames of a batch whose tables the replays do not rewrite.
+void msv1_launch_tables_compact(const Msv1Geometry& geo, const uint32_t* d_desc, uint16_t* d_tab16, uint32_t* d_bases, const uint32_t* d_list, int count,
+                                hipStream_t stream);
 // Stage-2 compare over the pixels no block covers (X&3 / Y&3 remainders), MSVideo1.hx:197-203.
 void msv1_launch_edge_compare(const Msv1Geometry& geo, const Msv1FrameArgs* d_frames, int nframes,
                               hipStream_t stream);

@@ -58,20 +58,68 @@ struct Msv1Staged : jsp_staged {
     // tables' readers and writers have to be kept apart (events below).  Every replay still costs one parse launch and its reconstruction launches; what
     // changes is that the parse (0.15 - 0.19 ms of a 1.02 ms step at 512 x 1080p) no longer stands in front of the launch that needs it.
     hipStream_t side = nullptr;        // the codec's second stream; null: everything in line on the caller's stream
-    DeviceBuffer d_desc2;              // the second table set (allocated by the first replay that runs ahead)
     hipEvent_t ev_fork = nullptr, ev_tables = nullptr;   // "the stream has reached this replay's reconstruction launches" / "the tables written ahead are complete"
     int cur_set = 0;                   // which set this replay's launches read
     bool ahead_valid = false;          // the tables of cur_set were written ahead (on `side`) and ev_tables says when
-    uint32_t* desc_set(int i) { return static_cast<uint32_t*>(i ? d_desc2.p : d_desc.p); }
-    void launch_table_parse(uint32_t* tables, hipStream_t on) {
-        for (uint32_t i : scrub)
-            JSP_HIP(hipMemsetAsync(tables + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE, sizeof(uint32_t) * (size_t)geo.nblocks, on));
-        // (the tile records carry the frames' table addresses: the second set is `table_shift` words further on)
-        msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(tables == d_desc.p ? d_recs_emit.p : d_recs_emit2.p), d_palette,
-                          static_cast<unsigned long long*>(d_agg_emit.p), next_epoch(epoch), 0, ntiles_emit, static_cast<uint32_t*>(d_sync.p), on,
-                          nullptr, 0, 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles_emit, nullptr, /*small_tiles=*/true);   // (`want`: where a lab build's phase clocks go)
+    // What a replay writes and reads (round 6): the COMPACT table where every launch that reads tables is a temporal launch (`compact_ok`, settled at
+    // staging) — 2 bytes per block and a base per 256 blocks instead of 4 bytes per block, msv1.h —, else 4-byte tables as ever.  Set 0 of the 4-byte kind is
+    // d_desc itself (what staging built: the first decode and the look-back fall-back always read that); every other set is made by the first replay that
+    // needs it.  Tables a replay does not rewrite (frames the host parser settled) are put into every set when it is made.
+    bool compact_ok = false;
+    struct TableSet { DeviceBuffer wide, tab16, bases, recs; bool made = false; } sets[2];
+    uint32_t* wide_tables(int i) { return static_cast<uint32_t*>(compact_ok || i == 0 ? d_desc.p : sets[i].wide.p); }
+    void make_set(int i, hipStream_t stream) {
+        TableSet& t = sets[i];
+        if (t.made) return;
+        const size_t nblk = (size_t)std::max(geo.nblocks, 1);
+        std::vector<Msv1TileRec> recs((size_t)ntiles_emit);
+        std::memcpy(recs.data(), h_recs_emit.p, sizeof(Msv1TileRec) * recs.size());
+        if (compact_ok) {
+            const size_t pitch = (size_t)msv1_tab16_pitch(geo.nblocks), ngr = (size_t)msv1_tab16_groups(geo.nblocks);
+            t.tab16.reserve(sizeof(uint16_t) * pitch * (size_t)nframes);
+            t.bases.reserve(sizeof(uint32_t) * ngr * (size_t)nframes);
+            JSP_HIP(hipMemsetAsync(t.tab16.p, 0xFF, sizeof(uint16_t) * pitch * (size_t)nframes, stream));   // (MSV1_TAB16_UNTOUCHED)
+            JSP_HIP(hipMemsetAsync(t.bases.p, 0, sizeof(uint32_t) * ngr * (size_t)nframes, stream));
+            std::vector<uint32_t> kept;                // frames whose tables the replays leave alone: converted from the 4-byte tables staging uploaded
+            const auto* pf = static_cast<const Msv1ParseFrame*>(h_pframes.p);
+            for (int f = 0; f < nframes; ++f) if (pf[f].host_parsed) kept.push_back((uint32_t)f);
+            if (!kept.empty()) {
+                d_kept.reserve(sizeof(uint32_t) * kept.size());
+                JSP_HIP(hipMemcpy(d_kept.p, kept.data(), sizeof(uint32_t) * kept.size(), hipMemcpyHostToDevice));
+                msv1_launch_tables_compact(geo, static_cast<const uint32_t*>(d_desc.p), static_cast<uint16_t*>(t.tab16.p), static_cast<uint32_t*>(t.bases.p),
+                                           static_cast<const uint32_t*>(d_kept.p), (int)kept.size(), stream);
+            }
+            for (auto& r : recs) {
+                const size_t f = (size_t)(reinterpret_cast<uint32_t*>(r.dst) - static_cast<uint32_t*>(d_desc.p)) / nblk;   // (staging pointed the record at the frame's 4-byte table)
+                r.dst = reinterpret_cast<int32_t*>(static_cast<uint16_t*>(t.tab16.p) + f * pitch);
+                r.prev = reinterpret_cast<const int32_t*>(static_cast<uint32_t*>(t.bases.p) + f * ngr);
+            }
+        } else if (i != 0) {
+            const size_t table_bytes = sizeof(uint32_t) * nblk * (size_t)nframes;
+            t.wide.reserve(table_bytes);
+            JSP_HIP(hipMemcpyAsync(t.wide.p, d_desc.p, table_bytes, hipMemcpyDeviceToDevice, stream));
+            for (auto& r : recs) r.dst = reinterpret_cast<int32_t*>(static_cast<uint32_t*>(t.wide.p) + (reinterpret_cast<uint32_t*>(r.dst) - static_cast<uint32_t*>(d_desc.p)));
+        }
+        if (compact_ok || i != 0) {
+            t.recs.reserve(sizeof(Msv1TileRec) * std::max<size_t>(recs.size(), 1));
+            JSP_HIP(hipMemcpy(t.recs.p, recs.data(), sizeof(Msv1TileRec) * recs.size(), hipMemcpyHostToDevice));
+        }
+        t.made = true;
     }
-    DeviceBuffer d_recs_emit2;         // the table-writing form's tile records with the second set's addresses
+    DeviceBuffer d_kept;
+    void launch_table_parse(int set, hipStream_t on) {
+        make_set(set, on);
+        const TableSet& t = sets[set];
+        const size_t pitch = (size_t)msv1_tab16_pitch(geo.nblocks);
+        for (uint32_t i : scrub) {
+            if (compact_ok) JSP_HIP(hipMemsetAsync(static_cast<uint16_t*>(t.tab16.p) + (size_t)i * pitch, 0xEE, sizeof(uint16_t) * (size_t)geo.nblocks, on));
+            else JSP_HIP(hipMemsetAsync(wide_tables(set) + (size_t)i * (size_t)std::max(geo.nblocks, 1), 0xEE, sizeof(uint32_t) * (size_t)geo.nblocks, on));
+        }
+        msv1_launch_fused(geo, static_cast<const uint8_t*>(d_stream.p), static_cast<const Msv1TileRec*>(t.recs.p ? t.recs.p : d_recs_emit.p), d_palette,
+                          static_cast<unsigned long long*>(d_agg_emit.p), next_epoch(epoch), 0, ntiles_emit, static_cast<uint32_t*>(d_sync.p), on,
+                          nullptr, 0, compact_ok ? 5 : 4, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles_emit, nullptr, /*small_tiles=*/true);   // (`want`: where a lab build's phase clocks go)
+    }
+    void drop_sets() { for (auto& t : sets) { t.wide.release(); t.tab16.release(); t.bases.release(); t.recs.release(); t.made = false; } }
     void quiesce_side() {              // nothing of this batch is left running beside the stream (before its buffers are reused or freed)
         if (side) (void)hipStreamSynchronize(side);
         ahead_valid = false;
@@ -101,27 +149,21 @@ struct Msv1Staged : jsp_staged {
         const bool run_ahead = side != nullptr && gpu_parse && needs_desc && ntiles_emit > 0;
         if (replay) {
             if (run_ahead && ahead_valid) JSP_HIP(hipStreamWaitEvent(stream, ev_tables, 0));   // written beside the replay before this one
-            else launch_table_parse(desc_set(cur_set), stream);
+            else launch_table_parse(cur_set, stream);
         }
-        const uint32_t* tables = desc_set(cur_set);
+        const bool compact = replay && compact_ok;                 // this decode's temporal launches read the compact tables of cur_set
+        const uint32_t* tables = replay ? wide_tables(cur_set) : static_cast<const uint32_t*>(d_desc.p);
+        const uint16_t* tab16 = compact ? static_cast<const uint16_t*>(sets[cur_set].tab16.p) : nullptr;
+        const uint32_t* bases = compact ? static_cast<const uint32_t*>(sets[cur_set].bases.p) : nullptr;
         if (run_ahead && decoded) {
             // the next replay's tables, into the other set, beside the launches below: the other set's last readers (the replay before this one) and the
             // last table-writing launch (it shares the published tile words and the fault word) are all in front of `ev_fork` on the stream
-            const size_t table_bytes = sizeof(uint32_t) * (size_t)std::max(geo.nblocks, 1) * (size_t)nframes;
-            if (!d_desc2.p) {
-                d_desc2.reserve(table_bytes);
-                JSP_HIP(hipMemcpyAsync(d_desc2.p, d_desc.p, table_bytes, hipMemcpyDeviceToDevice, stream));   // (tables the replay never rewrites — host-parsed frames — are in both)
-                std::vector<Msv1TileRec> recs2((size_t)ntiles_emit);
-                std::memcpy(recs2.data(), h_recs_emit.p, sizeof(Msv1TileRec) * recs2.size());
-                for (auto& r : recs2) r.dst = reinterpret_cast<int32_t*>(static_cast<uint32_t*>(d_desc2.p) + (reinterpret_cast<uint32_t*>(r.dst) - static_cast<uint32_t*>(d_desc.p)));
-                d_recs_emit2.reserve(sizeof(Msv1TileRec) * recs2.size());
-                JSP_HIP(hipMemcpy(d_recs_emit2.p, recs2.data(), sizeof(Msv1TileRec) * recs2.size(), hipMemcpyHostToDevice));
-                if (!ev_fork) JSP_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                if (!ev_tables) JSP_HIP(hipEventCreateWithFlags(&ev_tables, hipEventDisableTiming));
-            }
+            make_set(cur_set ^ 1, stream);
+            if (!ev_fork) JSP_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            if (!ev_tables) JSP_HIP(hipEventCreateWithFlags(&ev_tables, hipEventDisableTiming));
             JSP_HIP(hipEventRecord(ev_fork, stream));
             JSP_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-            launch_table_parse(desc_set(cur_set ^ 1), side);
+            launch_table_parse(cur_set ^ 1, side);
             JSP_HIP(hipEventRecord(ev_tables, side));
         }
         if (need_signif) JSP_HIP(hipMemsetAsync(d_signif.p, 0, sizeof(uint32_t) * nframes, stream));
@@ -135,7 +177,7 @@ struct Msv1Staged : jsp_staged {
                                   static_cast<unsigned long long*>(d_agg.p), next_epoch(epoch), tile0, (int)(last.first_tile + last.ntiles - tile0),
                                   static_cast<uint32_t*>(d_sync.p), stream, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, (uint32_t)ntiles);
             } else if (g.temporal) {
-                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p), tables, frames + g.first, g.count, d_palette, stream);
+                msv1_launch_blocks_temporal(geo, static_cast<const uint8_t*>(d_stream.p), tables, frames + g.first, g.count, d_palette, stream, tab16, bases);
             } else {
                 msv1_launch_blocks(geo, static_cast<const uint8_t*>(d_stream.p), tables, frames + g.first, g.count, d_palette, vec_ok, stream);
             }
@@ -407,6 +449,7 @@ struct Msv1Codec : jsp_codec {
     // Several frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until enough frames are submitted behind it
     // — half of what may be in flight ("async_depth"), at most 1 + MSV1_MAX_RIDERS — and they go out together (Msv1AsyncStaged::decode_with);
     // or with whatever is held, as soon as anybody waits for one of them or anything else needs the stream.
+    bool opt_compact_tables = [] { const char* e = std::getenv("JSP_MSV1_COMPACT_TABLES"); return !(e && e[0] == '0'); }();
     bool opt_parse_ahead = [] { const char* e = std::getenv("JSP_MSV1_PARSE_AHEAD"); return !(e && e[0] == '0'); }();
     bool opt_async_pairs = [] { const char* e = std::getenv("JSP_MSV1_ASYNC_PAIRS"); return !(e && e[0] == '0'); }();
     std::vector<jsp_async_job*> held;
@@ -510,6 +553,11 @@ struct Msv1Codec : jsp_codec {
             if (std::strcmp(value, "on") != 0 && std::strcmp(value, "off") != 0) return JSP_ERROR_OCCURED;
             launch_held();
             opt_async_pairs = std::strcmp(value, "on") == 0;
+            return 0;
+        }
+        if (std::strcmp(key, "msv1_compact_tables") == 0) { // replays of an inter-frame batch write and read 2-byte block tables (on) or the 4-byte ones staging builds (off)
+            if (std::strcmp(value, "on") != 0 && std::strcmp(value, "off") != 0) return JSP_ERROR_OCCURED;
+            opt_compact_tables = std::strcmp(value, "on") == 0;
             return 0;
         }
         if (std::strcmp(key, "msv1_parse_ahead") == 0) {    // replays of an inter-frame batch: the next replay's table-writing parse beside this replay's launches (on), or in front of them (off)
@@ -748,7 +796,7 @@ struct Msv1Codec : jsp_codec {
         const int nf = (int)frames.size();
         const size_t nblk = (size_t)std::max(geo.nblocks, 1);
         st->quiesce_side();                            // (a reused batch: nothing of its last replay still runs beside the stream)
-        st->d_desc2.release();
+        st->drop_sets();
         st->side = nullptr;
         if (opt_parse_ahead) {
             if (!side_stream) JSP_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -1069,6 +1117,14 @@ struct Msv1Codec : jsp_codec {
             st->needs_desc = false;
             st->any_fused = false;
             st->kernels.clear();
+            // replays write and read the compact block table (2 bytes per block + a base per 256 blocks, msv1.h) when every launch that reads tables is a
+            // temporal launch of the loader-wave kernel: the per-frame block kernel and the frame-at-a-time temporal kernel read 4-byte tables
+            static const bool temporal_old = std::getenv("JSP_MSV1_TEMPORAL_OLD") != nullptr;
+            bool compact = st->gpu_parse && opt_compact_tables && !temporal_old;
+            for (const auto& g : st->groups) compact = compact && (g.fused || g.temporal);
+            st->compact_ok = compact;
+            const uint64_t table_bytes_per_frame = compact ? sizeof(uint16_t) * (uint64_t)geo.nblocks + sizeof(uint32_t) * (uint64_t)msv1_tab16_groups(geo.nblocks)
+                                                           : sizeof(uint32_t) * (uint64_t)geo.nblocks;
             uint64_t moved = 0;
             for (const auto& g : st->groups) {
                 uint64_t written = 0, prev_reads = 0, sbytes = 0;
@@ -1086,14 +1142,14 @@ struct Msv1Codec : jsp_codec {
                     st->note_kernel("msv1_fused_kernel");
                 } else {
                     st->needs_desc |= gpu_table;
-                    moved += sizeof(uint32_t) * (uint64_t)geo.nblocks * g.count +
+                    moved += table_bytes_per_frame * g.count +
                              64 * (g.temporal ? (uses_prev ? (uint64_t)geo.nblocks : 0) : prev_reads);
                     st->note_kernel(g.temporal ? "msv1_blocks_temporal_kernel" : "msv1_blocks_kernel");
                 }
                 if (g.edge_compare) st->note_kernel("msv1_edge_compare_kernel");
             }
             if (st->needs_desc) {   // (a replay: msv1_fused_kernel in its descriptor form reads the stream once and writes the tables)
-                moved += st->info.stream_bytes + sizeof(uint32_t) * (uint64_t)geo.nblocks * nf;
+                moved += st->info.stream_bytes + table_bytes_per_frame * nf;
                 if (!st->any_fused) st->kernels = "msv1_fused_kernel" + (st->kernels.empty() ? std::string() : " + " + st->kernels);
             }
             st->info.moved_bytes = moved;

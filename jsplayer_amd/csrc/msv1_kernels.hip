@@ -439,11 +439,14 @@ struct TChunk {
 typedef __attribute__((address_space(1))) const void t_gvoid;
 typedef __attribute__((address_space(3))) void t_lvoid;
 
-template <int BITS>
+// COMPACT: the frames' tables are the 2-byte form (msv1.h: an entry per block in `tab16`, a base per group of 256 blocks — this workgroup's tile IS one group —
+// in `bases`): the loader fetches half the bytes per frame into the back half of the frame's LDS row and expands them in place into the 4-byte offsets the
+// workers read; nothing else differs.
+template <int BITS, bool COMPACT>
 __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
     const uint8_t* __restrict__ stream, const uint32_t* __restrict__ desc,
     const Msv1FrameArgs* __restrict__ frames, int nframes, const int32_t* __restrict__ palette, int nblocks,
-    int nbx, int X) {
+    int nbx, int X, const uint16_t* __restrict__ tab16, const uint32_t* __restrict__ bases, int pitch16, int ngroups) {
     extern __shared__ __align__(16) uint8_t t_lds[];
     TChunk* chunks = reinterpret_cast<TChunk*>(t_lds);                          // [2]
     uint32_t* s_pal = reinterpret_cast<uint32_t*>(t_lds + 2 * sizeof(TChunk));  // [256]
@@ -478,11 +481,18 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
                 }
             // 1. table entries of up to T_NF frames (frames that write nothing are left out), one 1 KiB row each
             int nf = 0, scan = f;
+            uint32_t v_base = 0;                                                    // (COMPACT) lane i: the group base of the chunk's frame i
 #pragma unroll 1
             for (; scan < nframes && nf < T_NF; ++scan) {
                 const Msv1FrameArgs fa = frames[scan];
                 if (fa.pad & MSV1_FRAME_NOOP) continue;
-                if (lane * 4 < live_blocks)
+                if (COMPACT) {
+                    const uint32_t fr = fa.desc_base / (uint32_t)nblocks;           // the frame's number in the batch (desc_base = frame x nblocks)
+                    if (lane * 8 < live_blocks)                                     // 512 bytes: eight entries per lane, 32 lanes, into the row's back half
+                        __builtin_amdgcn_global_load_lds((t_gvoid*)(tab16 + (size_t)fr * (size_t)pitch16 + blk0 + lane * 8), (t_lvoid*)&ck.desc[nf][WG / 2], 16, 0, 0);
+                    const uint32_t b = bases[(size_t)fr * (size_t)ngroups + blockIdx.x];
+                    v_base = lane == nf ? b : v_base;
+                } else if (lane * 4 < live_blocks)
                     __builtin_amdgcn_global_load_lds((t_gvoid*)(desc + fa.desc_base + blk0 + lane * 4), (t_lvoid*)&ck.desc[nf][0], 16, 0, 0);
                 if (lane == 0) ck.fidx[nf] = scan;
                 ++nf;
@@ -499,8 +509,24 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
                 const Msv1FrameArgs fa = frames[fi];
                 uint32_t lo = 0xFFFFFFFFu, hi = 0u;
                 if (lane * 4 < live_blocks) {
-                    const uint4 d4 = *reinterpret_cast<const uint4*>(&ck.desc[i][lane * 4]);
-                    const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                    uint32_t dd[4];
+                    if (COMPACT) {
+                        // four entries of the row's back half -> four 4-byte offsets at the row's front.  (Every lane's read is issued before any lane's write:
+                        // one wave, one instruction stream, and LDS takes a wave's operations in order.)
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)v_base, i);
+                        const uint2 e2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(&ck.desc[i][WG / 2]) + lane * 4);
+                        const uint32_t e[4] = {e2.x & 0xFFFFu, e2.x >> 16, e2.y & 0xFFFFu, e2.y >> 16};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            uint32_t c = (base & ~0x7FFFu) | e[k];                  // the group's codes lie within 4 608 bytes of its base: the nearest value with these low 15 bits
+                            c = c + 0x4000u < base ? c + 0x8000u : (c > base + 0x4000u ? c - 0x8000u : c);
+                            dd[k] = (e[k] & 0x8000u) ? (e[k] == MSV1_TAB16_SKIP ? MSV1_DESC_SKIP : MSV1_DESC_UNTOUCHED) : c;
+                        }
+                        *reinterpret_cast<uint4*>(&ck.desc[i][lane * 4]) = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+                    } else {
+                        const uint4 d4 = *reinterpret_cast<const uint4*>(&ck.desc[i][lane * 4]);
+                        dd[0] = d4.x; dd[1] = d4.y; dd[2] = d4.z; dd[3] = d4.w;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (lane * 4 + k < live_blocks && dd[k] < MSV1_DESC_UNTOUCHED) { lo = min(lo, dd[k]); hi = max(hi, dd[k] + 18u); }
@@ -679,7 +705,7 @@ void msv1_launch_blocks(const Msv1Geometry& geo, const uint8_t* d_stream, const 
 
 void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_stream, const uint32_t* d_desc,
                                  const Msv1FrameArgs* d_frames, int nframes, const int32_t* d_palette,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const uint16_t* d_tab16, const uint32_t* d_bases) {
     if (geo.nblocks <= 0 || nframes <= 0) return;
     static const bool old_form = std::getenv("JSP_MSV1_TEMPORAL_OLD") != nullptr;   // lab: the frame-at-a-time kernel
     if (old_form) {
@@ -695,16 +721,46 @@ void msv1_launch_blocks_temporal(const Msv1Geometry& geo, const uint8_t* d_strea
     const size_t lds = 2 * sizeof(TChunk) + 256 * 4 + (((size_t)nframes + 31) / 32 + 1 + TW) * 4;
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msv1_blocks_temporal_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     dim3 grid((geo.nblocks + WG - 1) / WG), block(TWG);
-    if (geo.bits == 16)
-        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<16>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
-                           d_palette, geo.nblocks, geo.nbx, geo.X);
-    else
-        hipLaunchKernelGGL((msv1_blocks_temporal_kernel<8>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes,
-                           d_palette, geo.nblocks, geo.nbx, geo.X);
+    const int pitch16 = msv1_tab16_pitch(geo.nblocks), ngroups = msv1_tab16_groups(geo.nblocks);
+#define JSP_TEMPORAL(BITS, C) hipLaunchKernelGGL((msv1_blocks_temporal_kernel<BITS, C>), grid, block, lds, stream, d_stream, d_desc, d_frames, nframes, \
+                                                 d_palette, geo.nblocks, geo.nbx, geo.X, d_tab16, d_bases, pitch16, ngroups)
+    if (d_tab16) { if (geo.bits == 16) JSP_TEMPORAL(16, true); else JSP_TEMPORAL(8, true); }
+    else { if (geo.bits == 16) JSP_TEMPORAL(16, false); else JSP_TEMPORAL(8, false); }
+#undef JSP_TEMPORAL
+}
+
+// The compact form of 4-byte tables (msv1.h): one workgroup per (group of 256 blocks, listed frame).
+__global__ __launch_bounds__(WG) void msv1_tables_compact_kernel(const uint32_t* __restrict__ desc, uint16_t* __restrict__ tab16, uint32_t* __restrict__ bases,
+                                                                 const uint32_t* __restrict__ list, int nblocks, int pitch16, int ngroups) {
+    __shared__ uint32_t s_min[WG / 64];
+    const uint32_t fr = list[blockIdx.y];
+    const int blk = (int)blockIdx.x * WG + (int)threadIdx.x;
+    const uint32_t o = blk < nblocks ? desc[(size_t)fr * (size_t)nblocks + blk] : MSV1_DESC_UNTOUCHED;
+    uint32_t m = o < MSV1_DESC_UNTOUCHED ? o : 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t all = s_min[0];
+        for (int w = 1; w < WG / 64; ++w) all = min(all, s_min[w]);
+        if (all != 0xFFFFFFFFu) bases[(size_t)fr * (size_t)ngroups + blockIdx.x] = all;
+    }
+    if (blk < nblocks)
+        tab16[(size_t)fr * (size_t)pitch16 + blk] = (uint16_t)(o == MSV1_DESC_SKIP ? MSV1_TAB16_SKIP : (o == MSV1_DESC_UNTOUCHED ? MSV1_TAB16_UNTOUCHED : (o & 0x7FFFu)));
+}
+
+void msv1_launch_tables_compact(const Msv1Geometry& geo, const uint32_t* d_desc, uint16_t* d_tab16, uint32_t* d_bases, const uint32_t* d_list, int count,
+                                hipStream_t stream) {
+    if (geo.nblocks <= 0 || count <= 0) return;
+    hipLaunchKernelGGL(msv1_tables_compact_kernel, dim3(msv1_tab16_groups(geo.nblocks), count), dim3(WG), 0, stream, d_desc, d_tab16, d_bases, d_list,
+                       geo.nblocks, msv1_tab16_pitch(geo.nblocks), msv1_tab16_groups(geo.nblocks));
 }
 
 void msv1_launch_edge_compare(const Msv1Geometry& geo, const Msv1FrameArgs* d_frames, int nframes,

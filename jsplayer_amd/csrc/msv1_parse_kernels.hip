@@ -397,7 +397,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // LS = slots (2 bytes) per lane: 32 (16 KiB tiles) for the batch forms, 16 (8 KiB tiles) for the one-frame-per-launch forms,
 // whose few dozen workgroups have the GPU to themselves: half the serial work per tile, twice the tiles.
 template <int BITS, int MODE, int LS>
-__global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream_p,
+__global__ __launch_bounds__(PWG, (MODE == 4 || MODE == 5) ? JSP_FUSED_WAVES_TABLES : JSP_FUSED_WAVES) void msv1_fused_kernel(const uint8_t* __restrict__ stream_p,
                                                             const Msv1TileRec* __restrict__ recs,
                                                             const int32_t* __restrict__ palette,
                                                             unsigned long long* __restrict__ agg_p, uint32_t epoch_p,
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
     // left the one value this tile needs — where the chain stands at the tile's first slot — so the look-back is ONE word,
     // asked for before anything else and there when it is needed (PREFIX).  The one-frame launches have all of a frame's
     // tiles in flight together: those publish their tables and every tile chains the tables of all tiles before it.
-    constexpr bool PREFIX = MODE == 0 || MODE == 4;
+    constexpr bool PREFIX = MODE == 0 || MODE == 4 || MODE == 5;
     constexpr int BYTES_W = TSLOTS * 2 / 4 + 8, TAB_W = PWG * 9 + 16, ENTER_W = PREFIX ? 4 : LOOKBACK_BATCH * 9 + 4;
     static_assert(TAB_W * 2 >= FSTAGE, "staging window must fit in the tables' space");
     __shared__ __align__(16) uint32_t arena[BYTES_W + TAB_W + ENTER_W + JSP_FUSED_LDS_PAD];
@@ -858,7 +858,36 @@ __global__ __launch_bounds__(PWG, MODE == 4 ? JSP_FUSED_WAVES_TABLES : JSP_FUSED
         }
         __syncthreads();
         JSP_CLOCK(4);   // replay into the staging window
-        if (MODE == 4) {
+        if (MODE == 5) {
+            // ---- 5''. the compact descriptor form (msv1.h): two bytes per block and a base per group of 256 blocks.  The window starts on a multiple of
+            //      256 blocks, so its groups are whole and its entries pair up into aligned words; an entry another tile owns (only in front of the
+            //      tile's first block) is left alone, and so is a group's base when this tile has no code in the group — the tile that has writes it,
+            //      and when both have, either value will do ----
+            static_assert(JSP_FUSED_ALIGN, "compact tables need staging windows that start on multiples of 256 blocks");
+            uint16_t* __restrict__ tab16 = reinterpret_cast<uint16_t*>(dstf) + w0;
+            uint32_t* __restrict__ bases = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(r.prev)) + (w0 >> 8);
+            auto entry = [&](uint32_t o) { return o == F_SKIP ? MSV1_TAB16_SKIP : ((tile_byte0 + o) & 0x7FFFu); };
+            for (uint32_t i = 2u * tid; i < wn; i += 2u * PWG) {
+                const uint32_t a = stage[i], b = i + 1u < wn ? (uint32_t)stage[i + 1u] : F_NONE;
+                if (a != F_NONE && b != F_NONE) *reinterpret_cast<uint32_t*>(tab16 + i) = entry(a) | (entry(b) << 16);
+                else {
+                    if (a != F_NONE) tab16[i] = (uint16_t)entry(a);
+                    if (b != F_NONE) tab16[i + 1u] = (uint16_t)entry(b);
+                }
+            }
+            for (uint32_t g = wave; g * 256u < wn; g += PWG / 64) {
+                uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t idx = g * 256u + k * 64u + lane;
+                    const uint32_t o = idx < wn ? (uint32_t)stage[idx] : F_NONE;
+                    m = o < F_NONE ? min(m, o) : m;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+                if (lane == 0 && m != 0xFFFFFFFFu) bases[g] = tile_byte0 + m;
+            }
+        } else if (MODE == 4) {
             // ---- 5'. the descriptor form: the window goes out as the frame's block table (byte offset of each block's code
             //      in the stream buffer, or "copy from the previous frame"), which msv1_blocks_temporal_kernel /
             //      msv1_blocks_kernel read — what msv1_parse_tiles + _chain + _emit build in three launches ----
@@ -1012,7 +1041,7 @@ void msv1_launch_fused(const Msv1Geometry& geo, const uint8_t* d_stream, const M
 #define JSP_FUSED_LS(BITS, MODE) do { if (small_tiles) JSP_FUSED(BITS, MODE, 16); else JSP_FUSED(BITS, MODE, JSP_BATCH_LS); } while (0)
 #define JSP_FUSED_MODES(BITS)                                                                                                \
     switch (mode) { case 1: JSP_FUSED_LS(BITS, 1); break; case 2: JSP_FUSED_LS(BITS, 2); break; case 3: JSP_FUSED_LS(BITS, 3); break; \
-                    case 4: JSP_FUSED_LS(BITS, 4); break; default: JSP_FUSED(BITS, 0, JSP_BATCH_LS); }
+                    case 4: JSP_FUSED_LS(BITS, 4); break; case 5: JSP_FUSED_LS(BITS, 5); break; default: JSP_FUSED(BITS, 0, JSP_BATCH_LS); }
     if (geo.bits == 16) { JSP_FUSED_MODES(16) } else { JSP_FUSED_MODES(8) }
 #undef JSP_FUSED_MODES
 #undef JSP_FUSED_LS

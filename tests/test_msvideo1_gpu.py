@@ -289,13 +289,14 @@ def test_replay_rebuilds_its_block_tables_with_buffers_repeating_inside_the_grou
     st.close()
 
 
+@pytest.mark.parametrize("compact", ["on", "off"])
 @pytest.mark.parametrize("ahead", ["on", "off"])
-def test_replays_back_to_back_with_the_next_parse_running_beside_them(ahead):
+def test_replays_back_to_back_with_the_next_parse_running_beside_them(ahead, compact):
     """Option msv1_parse_ahead: a replay of an inter-frame batch queues the NEXT replay's table-writing parse on the codec's second stream,
     into the other of two table sets, beside its own temporal launch.  Replays queued back to back with no wait between them, tables poisoned
     before every parse, a look-back fault injected on a later replay (the parse running ahead shares the fault word: the batch is then redone
     through the three-kernel parse and must still come out right), and the batch restaged afterwards: frames equal the oracle's every time,
-    on and off alike."""
+    on and off alike, with the replays' tables in their compact form (msv1_compact_tables) and in the 4-byte one."""
     if PARSE_MODE != "gpu":
         pytest.skip("on-GPU parse only")
     w, h, n = 320, 240, 70
@@ -303,6 +304,7 @@ def test_replays_back_to_back_with_the_next_parse_running_beside_them(ahead):
     gpu = make_gpu(16, w, h, pal)
     gpu.Preinit(36)
     gpu.set_option("msv1_parse_ahead", ahead)
+    gpu.set_option("msv1_compact_tables", compact)             # the replays' tables: 2 bytes per block + a base per 256 blocks, or the 4-byte ones
     gpu.set_option("msv1_scrub_tables", "1")
     nbuf = 4
     dsts = [dev_buf(w * h, 3) for _ in range(nbuf)]

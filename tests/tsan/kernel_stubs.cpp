@@ -62,7 +62,8 @@ void msv1_launch_fused(const Msv1Geometry&, const uint8_t*, const Msv1TileRec*, 
 }
 
 void msv1_launch_blocks(const Msv1Geometry&, const uint8_t*, const uint32_t*, const Msv1FrameArgs*, int, const int32_t*, bool, hipStream_t s) { stub_stream_work(s); }
-void msv1_launch_blocks_temporal(const Msv1Geometry&, const uint8_t*, const uint32_t*, const Msv1FrameArgs*, int, const int32_t*, hipStream_t s) { stub_stream_work(s); }
+void msv1_launch_blocks_temporal(const Msv1Geometry&, const uint8_t*, const uint32_t*, const Msv1FrameArgs*, int, const int32_t*, hipStream_t s, const uint16_t*, const uint32_t*) { stub_stream_work(s); }
+void msv1_launch_tables_compact(const Msv1Geometry&, const uint32_t*, uint16_t*, uint32_t*, const uint32_t*, int, hipStream_t s) { stub_stream_work(s); }
 void msv1_launch_edge_compare(const Msv1Geometry&, const Msv1FrameArgs*, int, hipStream_t s) { stub_stream_work(s); }
 void launch_frames_differ(const int32_t*, const int32_t*, size_t, size_t, uint32_t* d_flag, hipStream_t s) { if (d_flag) *d_flag = 0; stub_stream_work(s); }
 double pool_store_rate(uint32_t* const*, int, int, int, uint32_t) { return 6900.0; }
