@@ -481,7 +481,7 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
                 }
             // 1. table entries of up to T_NF frames (frames that write nothing are left out), one 1 KiB row each
             int nf = 0, scan = f;
-            uint32_t v_base = 0;                                                    // (COMPACT) lane i: the group base of the chunk's frame i
+            uint32_t v_base = 0, v_fr = 0;                                          // (COMPACT) lane i: the group base / the number in the batch of the chunk's frame i
 #pragma unroll 1
             for (; scan < nframes && nf < T_NF; ++scan) {
                 const Msv1FrameArgs fa = frames[scan];
@@ -490,13 +490,13 @@ __global__ __launch_bounds__(TWG) void msv1_blocks_temporal_kernel(
                     const uint32_t fr = fa.desc_base / (uint32_t)nblocks;           // the frame's number in the batch (desc_base = frame x nblocks)
                     if (lane * 8 < live_blocks)                                     // 512 bytes: eight entries per lane, 32 lanes, into the row's back half
                         __builtin_amdgcn_global_load_lds((t_gvoid*)(tab16 + (size_t)fr * (size_t)pitch16 + blk0 + lane * 8), (t_lvoid*)&ck.desc[nf][WG / 2], 16, 0, 0);
-                    const uint32_t b = bases[(size_t)fr * (size_t)ngroups + blockIdx.x];
-                    v_base = lane == nf ? b : v_base;
+                    v_fr = lane == nf ? fr : v_fr;                                   // (its base is fetched below, all frames' at once: a scalar load per frame in this loop would put a memory round trip between the requests)
                 } else if (lane * 4 < live_blocks)
                     __builtin_amdgcn_global_load_lds((t_gvoid*)(desc + fa.desc_base + blk0 + lane * 4), (t_lvoid*)&ck.desc[nf][0], 16, 0, 0);
                 if (lane == 0) ck.fidx[nf] = scan;
                 ++nf;
             }
+            if (COMPACT && lane < nf) v_base = *(cgu32*)(bases + (size_t)v_fr * (size_t)ngroups + blockIdx.x);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             // 2. per frame: which stream bytes its coded blocks point into, as long as the chunk's code area has room.  (The
             //    extents are parked in the lanes of three registers: an LDS read issued after an LDS-DMA is made to wait for it,
