@@ -137,10 +137,11 @@ int jsp_set_stream(jsp_codec* c, void* hip_stream);
  *       same batch).  Such a replay is a table-writing parse launch and the reconstruction launches that read the tables; "on" queues the NEXT
  *       replay's parse on a second stream of the codec, into a second set of tables, beside this replay's reconstruction (jsp_sync waits for both
  *       streams).  Costs a second table set (4 bytes per block and frame).  Results do not depend on it.
- *   "msv1_compact_tables" = "on" (default) | "off" : MSVideo1 only, the same replays.  "on": the table-writing parse leaves 2 bytes per block and a
+ *   "msv1_compact_tables" = "off" (default) | "on" : MSVideo1 only, the same replays.  "on": the table-writing parse leaves 2 bytes per block and a
  *       4-byte base per 256 blocks (the block's code offset modulo 32 768; a group's codes lie within 4 608 bytes of each other) instead of 4 bytes per
  *       block, and the temporal launch expands them as it stages them — half the table bytes written and read.  Used when every launch of the batch that
- *       reads tables is a temporal launch.  Results do not depend on it.
+ *       reads tables is a temporal launch.  Off by default: it saves a twentieth of the step's memory traffic and half the table memory, and no time.
+ *       Results do not depend on it.
  *   ("sp_group_chunk" and "msv1_parse_pieces", launch plans of round 4 that measured slower and were removed in round 5, are still accepted and do
  *   nothing — results never depended on them; their environment twins JSP_SP_GROUP_CHUNK / JSP_MSV1_PARSE_PIECES are no longer read.)
  *   "sp_band_rows" = "auto" (default) | "0" | "<n>" : ScreenPressor only.  Key frames are rebuilt by one

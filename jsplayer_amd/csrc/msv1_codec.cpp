@@ -449,7 +449,9 @@ struct Msv1Codec : jsp_codec {
     // Several frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until enough frames are submitted behind it
     // — half of what may be in flight ("async_depth"), at most 1 + MSV1_MAX_RIDERS — and they go out together (Msv1AsyncStaged::decode_with);
     // or with whatever is held, as soon as anybody waits for one of them or anything else needs the stream.
-    bool opt_compact_tables = [] { const char* e = std::getenv("JSP_MSV1_COMPACT_TABLES"); return !(e && e[0] == '0'); }();
+    // (default OFF: measured, round 6 — the compact tables take 265 MB off a 5.15 GB step's traffic and nothing off its time: the temporal launch takes 868 us with
+    // either table, the table-writing launch 168 us instead of 154; profiles/r06_msv1_inter70_compact_tables_*.  Kept as an option: half the table memory.)
+    bool opt_compact_tables = [] { const char* e = std::getenv("JSP_MSV1_COMPACT_TABLES"); return e && e[0] == '1'; }();
     bool opt_parse_ahead = [] { const char* e = std::getenv("JSP_MSV1_PARSE_AHEAD"); return !(e && e[0] == '0'); }();
     bool opt_async_pairs = [] { const char* e = std::getenv("JSP_MSV1_ASYNC_PAIRS"); return !(e && e[0] == '0'); }();
     std::vector<jsp_async_job*> held;
