@@ -464,26 +464,45 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     int best_form = -1;
                     double best_rate = 0;
                     Candidate held;
-                    for (int k = 0; k < 3 && !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {
+                    std::vector<Candidate> rejects;            // (second phase only) mapped candidates kept allocated so that the next one is made of OTHER memory
+                    uint64_t rejects_bytes = 0;
+                    // Phase one: the three arrangements, the best so far held while the next is measured.  Phase two, only on a board none of them gets within a tenth of
+                    // the plain fill from (a board in its slow state: everything takes 5.4 - 6.3 TB/s there, but not every stretch of memory the same — 6.34 for one
+                    // pool and 5.56 for the next in profiles/r06_h_*, 5.4 - 6.1 in r06_o_*): more candidates of the first arrangement, each made while the ones before
+                    // it are still held — different physical memory every time —, up to JSP_POOL_PROBE_MAX (16) in all and the hold limit; a millisecond to make and
+                    // a probe launch each (~10 ms), where a hipMalloc candidate cost half a second.
+                    for (int k = 0; !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {
+                        const bool second_phase = k >= 3;
+                        if (second_phase && !(yardstick > 0 && best_rate < 0.9 * yardstick)) break;
+                        const Form& form = forms[second_phase ? 0 : k];
                         Candidate c;
-                        if (best_form >= 0 && (uint64_t)held.mapped.bytes + one > hold_limit) break;   // (the best so far stays held while the next is measured: twice the pool, briefly)
-                        if (!c.mapped.make(device_id, bytes, nbuf, c.frames, forms[k].per, forms[k].dealt)) break;
+                        if (best_form >= 0 && (uint64_t)held.mapped.bytes + rejects_bytes + one > hold_limit) break;   // (the best so far stays held while the next is measured: twice the pool, briefly)
+                        if (!c.mapped.make(device_id, bytes, nbuf, c.frames, form.per, form.dealt)) break;
                         try {
                             if (yardstick <= 0) yardstick = jsp::pool_fill_rate(static_cast<uint32_t*>(c.mapped.va), (size_t)std::min<uint64_t>((uint64_t)c.mapped.bytes, 2ull << 30));
                             JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
                             c.rate = jsp::pool_store_rate(d_table, nbuf, width, height, 0u);
                         } catch (...) {
                             release(c);
+                            release(held);
+                            for (auto& r : rejects) release(r);
                             throw;
                         }
                         p->tried.push_back(c.rate);
-                        if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (one address range over %zu physical allocations: %s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, c.mapped.handles.size(), forms[k].what, c.rate, yardstick);
-                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)c.mapped.bytes + (uint64_t)held.mapped.bytes);
+                        if (std::getenv("JSP_POOL_PROBE_LOG")) std::fprintf(stderr, "[jsp_pool] candidate %d (one address range over %zu physical allocations: %s%s): %.0f GB/s (plain fill %.0f)\n", (int)p->tried.size() - 1, c.mapped.handles.size(), form.what, second_phase ? ", other memory" : "", c.rate, yardstick);
+                        p->held_peak = std::max<uint64_t>(p->held_peak, (uint64_t)c.mapped.bytes + (uint64_t)held.mapped.bytes + rejects_bytes);
                         const bool good = yardstick > 0 && c.rate >= 0.97 * yardstick;
-                        if (c.rate > best_rate) { best_rate = c.rate; best_form = k; release(held); held = std::move(c); c.mapped = jsp::MappedRange{}; }
-                        else release(c);
-                        if (good) break;
+                        Candidate loser;
+                        if (c.rate > best_rate) { best_rate = c.rate; best_form = k; loser = std::move(held); held = std::move(c); c.mapped = jsp::MappedRange{}; }
+                        else { loser = std::move(c); c.mapped = jsp::MappedRange{}; }
+                        if (good) { release(loser); break; }
+                        if (k >= 2 && !loser.mapped.empty()) {  // from here on what is rejected stays allocated until the search ends
+                            rejects_bytes += loser.mapped.bytes;
+                            rejects.push_back(std::move(loser));
+                            loser.mapped = jsp::MappedRange{};
+                        } else release(loser);
                     }
+                    for (auto& r : rejects) release(r);
                     if (best_form < 0) slab_yardstick();        // (no mapped form could be made: the older forms are held against a slab's fill)
                     if (best_form >= 0) {
                         cands.push_back(std::move(held));
