@@ -452,7 +452,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                 // best of the three is kept all the same: the hipMalloc forms cost half a second and a pool's worth of memory EACH to try (16 candidates, 2.2 s
                 // and 55 GB held per pool in that run) and were not better there.  They are still tried when this form cannot be made at all, or on request
                 // (JSP_POOL_PROBE_THOROUGH=1).  JSP_POOL_PROBE_MAPPED=0: skip the mapped forms (lab).
-                bool settled = false;
+                bool settled = false, last_resort = false;
                 {
                     const char* m = std::getenv("JSP_POOL_PROBE_MAPPED");
                     const char* th = std::getenv("JSP_POOL_PROBE_THOROUGH");
@@ -471,7 +471,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     // pool and 5.56 for the next in profiles/r06_h_*, 5.4 - 6.1 in r06_o_*): more candidates of the first arrangement, each made while the ones before
                     // it are still held — different physical memory every time —, up to JSP_POOL_PROBE_MAX (16) in all and the hold limit; a millisecond to make and
                     // a probe launch each (~10 ms), where a hipMalloc candidate cost half a second.
-                    for (int k = 0; !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {
+                    for (int k = 0; k < 9 && !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {   // (three arrangements, then at most six more of the first)
                         const bool second_phase = k >= 3;
                         if (second_phase && !(yardstick > 0 && best_rate < 0.9 * yardstick)) break;
                         const Form& form = forms[second_phase ? 0 : k];
@@ -508,12 +508,16 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         cands.push_back(std::move(held));
                         held.mapped = jsp::MappedRange{};
                         best = 0;
-                        settled = !thorough || (yardstick > 0 && best_rate >= 0.97 * yardstick);
+                        // good enough: within 3 % of the plain fill on request (JSP_POOL_PROBE_THOROUGH), within a tenth of it otherwise.  A board that gives less than
+                        // that to nine mapped candidates is in its slow state; ONE run of hipMalloc chunks (four candidates out of one run of allocations, the
+                        // first form of round 5: half a second) is still tried there, as a last resort, and then the best of all is kept.
+                        settled = yardstick > 0 && best_rate >= (thorough ? 0.97 : 0.9) * yardstick;
+                        last_resort = !thorough && !settled;
                     }
                 }
                 int hint = pool_form_hint(device_id)->load();
                 if (const char* f = std::getenv("JSP_POOL_PROBE_FORM")) { const int v = std::atoi(f); if (v >= 0 && v < 3) hint = v; }   // (start with that older form: 0 two frames per allocation, 1 one allocation, 2 one per frame)
-                if (!settled && hint >= 0 && hint < 3) {      // the form this board liked last time, next
+                if (!settled && !last_resort && hint >= 0 && hint < 3) {      // the form this board liked last time, next
                     Candidate c;
                     if (make_old(hint, c)) {
                         cands.push_back(std::move(c));
@@ -600,12 +604,12 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     chunked = (int)cands.size() - 1;
                     // (an older form — its frames lie densely — must beat the chunked candidate by 3 % to stand before it: the probe's shape does not mind density,
                     // the key-frame kernel's does, profiles/r05_front_lab_frame_order.txt)
-                    if (best < 0 || cands[chunked].rate * 1.03 >= cands[best].rate) best = chunked;
+                    if (best < 0 || cands[chunked].rate * (cands[best].mapped.empty() ? 1.03 : 1.0) > cands[best].rate) best = chunked;   // (against a mapped candidate: the better probe wins, no allowance)
                 } else if (!run.empty()) {                     // no chunked candidate was measured (JSP_POOL_PROBE_MAX used up by the hinted form): the run goes back whole
                     for (void* d : run) (void)hipFree(d);
                     run.clear();
                 }
-                const bool good_enough = settled || (chunked >= 0 && best == chunked && (yardstick <= 0 || cands[chunked].rate >= 0.95 * yardstick));
+                const bool good_enough = settled || last_resort || (chunked >= 0 && best == chunked && (yardstick <= 0 || cands[chunked].rate >= 0.95 * yardstick));
                 for (int a = 0; (int)p->tried.size() < kCandidates && !good_enough; ++a) {
                     if (best >= 0 && (uint64_t)(cands.size() + 1) * one > hold_limit) break;   // holding another candidate would pass the limit
                     Candidate c;
