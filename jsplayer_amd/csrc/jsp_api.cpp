@@ -640,7 +640,8 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
             p->mapped = std::move(cands[best].mapped);
             cands[best].mapped = jsp::MappedRange{};
             p->bufs = cands[best].frames;
-            for (int32_t* f : p->bufs) JSP_HIP(hipMemset(f, 0, bytes));
+            if (!p->mapped.empty()) JSP_HIP(hipMemset(p->mapped.va, 0, p->mapped.bytes));   // (one call for the whole range: a memset per frame is a fifth of a millisecond each)
+            else for (int32_t* f : p->bufs) JSP_HIP(hipMemset(f, 0, bytes));
             p->probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - probe_t0).count();
             return p.release();
         }
