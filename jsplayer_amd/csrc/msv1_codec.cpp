@@ -158,7 +158,15 @@ struct Msv1Staged : jsp_staged {
         if (run_ahead && decoded) {
             // the next replay's tables, into the other set, beside the launches below: the other set's last readers (the replay before this one) and the
             // last table-writing launch (it shares the published tile words and the fault word) are all in front of `ev_fork` on the stream
-            make_set(cur_set ^ 1, stream);
+            try {
+                make_set(cur_set ^ 1, stream);
+            } catch (const std::exception&) {          // no room for a second table set: this batch's replays parse in line from now on
+                (void)hipGetLastError();
+                { TableSet& t = sets[cur_set ^ 1]; t.wide.release(); t.tab16.release(); t.bases.release(); t.recs.release(); t.made = false; }
+                side = nullptr;
+            }
+        }
+        if (run_ahead && decoded && side) {
             if (!ev_fork) JSP_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
             if (!ev_tables) JSP_HIP(hipEventCreateWithFlags(&ev_tables, hipEventDisableTiming));
             JSP_HIP(hipEventRecord(ev_fork, stream));
@@ -190,7 +198,7 @@ struct Msv1Staged : jsp_staged {
         if (any_fused || needs_desc)
             JSP_HIP(hipMemcpyAsync(h_fault.p, d_sync.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         ++clock_launches;
-        if (run_ahead && decoded) { cur_set ^= 1; ahead_valid = true; }   // the next replay reads what was just started beside this one
+        if (run_ahead && decoded && side) { cur_set ^= 1; ahead_valid = true; }   // the next replay reads what was just started beside this one
         decoded = true;
     }
     int clock_launches = 0;                                    // (read by the lab build's phase clocks only: msv1_fused_hooks.h)
@@ -446,13 +454,14 @@ struct Msv1Codec : jsp_codec {
         held.clear();            // (frames held for their successors are among those about to be re-run: they are never launched)
         if (d_poison.p) JSP_HIP(hipMemsetAsync(d_poison.p, 0, sizeof(uint32_t), stream));
     }
+    // Replays of staged inter-frame batches (Msv1Staged::decode): "msv1_parse_ahead" (default on) and "msv1_compact_tables" (default OFF: measured, round 6 — the
+    // compact tables take 265 MB off a 5.15 GB step's traffic and nothing off its time: the temporal launch takes 868 us with either table, the table-writing
+    // launch 168 us instead of 154; profiles/r06_msv1_inter70_compact_tables_*.  Kept as an option: half the table memory.)
+    bool opt_compact_tables = [] { const char* e = std::getenv("JSP_MSV1_COMPACT_TABLES"); return e && e[0] == '1'; }();
+    bool opt_parse_ahead = [] { const char* e = std::getenv("JSP_MSV1_PARSE_AHEAD"); return !(e && e[0] == '0'); }();
     // Several frames per launch (option "msv1_async_pairs", default on): a one-launch frame is HELD until enough frames are submitted behind it
     // — half of what may be in flight ("async_depth"), at most 1 + MSV1_MAX_RIDERS — and they go out together (Msv1AsyncStaged::decode_with);
     // or with whatever is held, as soon as anybody waits for one of them or anything else needs the stream.
-    // (default OFF: measured, round 6 — the compact tables take 265 MB off a 5.15 GB step's traffic and nothing off its time: the temporal launch takes 868 us with
-    // either table, the table-writing launch 168 us instead of 154; profiles/r06_msv1_inter70_compact_tables_*.  Kept as an option: half the table memory.)
-    bool opt_compact_tables = [] { const char* e = std::getenv("JSP_MSV1_COMPACT_TABLES"); return e && e[0] == '1'; }();
-    bool opt_parse_ahead = [] { const char* e = std::getenv("JSP_MSV1_PARSE_AHEAD"); return !(e && e[0] == '0'); }();
     bool opt_async_pairs = [] { const char* e = std::getenv("JSP_MSV1_ASYNC_PAIRS"); return !(e && e[0] == '0'); }();
     std::vector<jsp_async_job*> held;
     long long paired_frames = 0;      // jsp_counter("paired_frames"): frames that shared a launch with others
