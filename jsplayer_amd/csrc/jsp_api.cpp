@@ -477,7 +477,9 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         const Form& form = forms[second_phase ? 0 : k];
                         Candidate c;
                         if (best_form >= 0 && (uint64_t)held.mapped.bytes + rejects_bytes + one > hold_limit) break;   // (the best so far stays held while the next is measured: twice the pool, briefly)
-                        if (!c.mapped.make(device_id, bytes, nbuf, c.frames, form.per, form.dealt)) break;
+                        // (frames far smaller than the 2 MB a physical allocation is rounded up to share one: "an allocation per frame" is an allocation per 2 MB of frames)
+                        const int per = form.per == 1 ? (int)std::max<size_t>(1, ((size_t)2 << 20) / std::max<size_t>(bytes, 1)) : form.per;
+                        if (!c.mapped.make(device_id, bytes, nbuf, c.frames, per, form.dealt)) break;
                         try {
                             if (yardstick <= 0) yardstick = jsp::pool_fill_rate(static_cast<uint32_t*>(c.mapped.va), (size_t)std::min<uint64_t>((uint64_t)c.mapped.bytes, 2ull << 30));
                             JSP_HIP(hipMemcpy(d_table, c.frames.data(), sizeof(uint32_t*) * (size_t)nbuf, hipMemcpyHostToDevice));
