@@ -46,7 +46,7 @@ def main():
             elif r < 0.30:
                 b = b + b"\x07"
             frames[i] = bytes(b)
-        mode = str(rng.choice(["host", "gpu", "gpu", "async"]))   # async: jsp_decompress_*_async / jsp_wait with the on-GPU parse
+        mode = str(rng.choice(["host", "gpu", "gpu", "async", "staged"]))   # async: jsp_decompress_*_async / jsp_wait with the on-GPU parse; staged: the whole clip as ONE batch, replayed
         host_buffers, misalign = rng.random() < 0.15, rng.random() < 0.15
         lines = int(rng.integers(0, 60))
         depth = int(rng.choice([1, 2, 4, 8]))
@@ -64,6 +64,10 @@ def main():
                 ranges = int(rng.integers(1, 5)) if rng.random() < 0.33 else 0
                 A.drive(gpu, OracleMSVideo1(bits, w, h, pal), w, h, frames, keys, depth=depth, pinned=bool(ranges) or bool(rng.random() < 0.5), lines=lines,
                         prefetch=ranges, drop_ranges_at=(n // 2 if ranges and rng.random() < 0.5 else None))
+            elif mode == "staged":
+                opts = dict(msv1_parse_ahead=str(rng.choice(["on", "off"])), msv1_compact_tables=str(rng.choice(["on", "off"])), msv1_scrub_tables="1")
+                tag += " " + " ".join(f"{k}={v}" for k, v in opts.items())
+                drive_staged(T, bits, w, h, frames, keys, pal, lines, int(rng.integers(2, 6)), int(rng.integers(1, 4)), opts)
             else:
                 drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
         except AssertionError as e:
@@ -83,6 +87,58 @@ def drive(T, bits, w, h, frames, keys, pal, lines, mode, host_buffers, misalign)
     """test_msvideo1_gpu.drive_pair with the parse mode its make_gpu() applies."""
     T.PARSE_MODE = mode
     T.drive_pair(bits, w, h, frames, keys, pal, lines=lines, host=host_buffers, misalign=misalign and not host_buffers)
+
+
+def drive_staged(T, bits, w, h, frames, keys, pal, lines, nbuf, replays, opts):
+    """The clip as ONE staged batch into `nbuf` rotating buffers, decoded and replayed `replays` times back to back (round 6: the next replay's
+    parse beside this one, compact block tables, tables poisoned before every parse) — mutated, truncated and random frames included, so that
+    frames the host parser has to settle sit between the GPU-parsed ones.  Statuses, adoption, significance and every buffer against the oracle."""
+    from jsplayer_amd import MSVideo1_16bit, MSVideo1_8bit
+    from oracle_binding import OracleAbort, OracleMSVideo1
+    n = len(frames)
+    orc = OracleMSVideo1(bits, w, h, pal)
+    orc.Preinit(lines)
+    obufs = [np.full(w * h, 5, dtype=np.int32) for _ in range(nbuf)]
+    want, where = [], []                        # per frame: None (the reference raises) or (adopted, significant or None for a key frame); the buffer it goes to
+    for i in range(n):
+        k = next(j for j in range(nbuf) if obufs[j] is not orc.PreviousFrame())   # the Manager's rule: any buffer but the previous frame's
+        where.append(k)
+        if keys[i]:
+            assert orc.DecompressI(frames[i], obufs[k]) == 0
+            want.append((True, None))
+        else:
+            try:
+                data, sig = orc.DecompressP(frames[i], obufs[k])
+                want.append((data is obufs[k], sig))
+            except OracleAbort:
+                want.append(None)
+    gpu = MSVideo1_16bit(w, h) if bits == 16 else MSVideo1_8bit(w, h, pal)
+    gpu.Preinit(lines)
+    gpu.set_option("msv1_parse", "gpu")
+    for k, v in opts.items():
+        gpu.set_option(k, v)
+    dsts = [T.dev_buf(w * h, 5) for _ in range(nbuf)]
+    st = gpu.stage_batch(frames, [dsts[where[i]] for i in range(n)], is_key=keys)
+    for run in range(2):
+        for d in dsts:
+            d.fill_(5)
+        for _ in range(replays if run else 1):
+            st.decode()
+        gpu.sync()
+        status, adopted, signif = st.results()
+        for i in range(n):
+            if want[i] is None:
+                assert status[i] != 0, f"run {run} frame {i}: the reference raises here"
+                continue
+            assert status[i] == 0, f"run {run} frame {i}: status {status[i]}"
+            if not keys[i]:
+                assert bool(adopted[i]) == want[i][0], f"run {run} frame {i}: adoption"
+                assert bool(signif[i]) == want[i][1], f"run {run} frame {i}: significant_changes"
+        if all(x is not None for x in want):    # (a frame at which the reference raises leaves the later ones undefined there)
+            for k in range(nbuf):
+                assert np.array_equal(obufs[k], T.to_np(dsts[k])), f"run {run}: buffer {k} differs"
+    st.close()
+    gpu.StopAndClean()
 
 
 if __name__ == "__main__":
