@@ -466,14 +466,16 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     Candidate held;
                     std::vector<Candidate> rejects;            // (second phase only) mapped candidates kept allocated so that the next one is made of OTHER memory
                     uint64_t rejects_bytes = 0;
-                    // Phase one: the three arrangements, the best so far held while the next is measured.  Phase two, only on a board none of them gets within a tenth of
-                    // the plain fill from (a board in its slow state: everything takes 5.4 - 6.3 TB/s there, but not every stretch of memory the same — 6.34 for one
-                    // pool and 5.56 for the next in profiles/r06_h_*, 5.4 - 6.1 in r06_o_*): more candidates of the first arrangement, each made while the ones before
-                    // it are still held — different physical memory every time —, up to JSP_POOL_PROBE_MAX (16) in all and the hold limit; a millisecond to make and
-                    // a probe launch each (~10 ms), where a hipMalloc candidate cost half a second.
+                    // Phase one: the three arrangements, the best so far held while the next is measured.  Phase two, while none has come within 3 % of the plain fill:
+                    // more candidates of the first arrangement, each made while the ones before it are still held — different physical memory every time.  What a pool
+                    // gets from its memory is a property of WHERE that memory lies that lasts as long as the allocation does (tools/front_lab.hip LAB_TIME,
+                    // profiles/r06_time_lab_memory.txt: four pools kept and re-probed through six rounds of churn and idling 6.97 / 6.68 / 5.95 / 6.68 TB/s every time,
+                    // fresh pools beside them 6.4 - 6.6 / 5.4 / 5.5 by their place in the order of allocation) — unless the whole board is in its slow state
+                    // (r06_time_lab_slow_state.txt: everything 5.4 - 5.8, kept or fresh).  So the best of up to nine is worth ~10 ms apiece (a millisecond to make, a
+                    // probe launch) and a transient hold of up to nine pools within the hold limit; a hipMalloc candidate cost half a second.
                     for (int k = 0; k < 9 && !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {   // (three arrangements, then at most six more of the first)
                         const bool second_phase = k >= 3;
-                        if (second_phase && !(yardstick > 0 && best_rate < 0.9 * yardstick)) break;
+                        if (second_phase && !(yardstick > 0 && best_rate < 0.97 * yardstick)) break;   // (unreachable: a candidate that good ended the loop; kept for the reader)
                         const Form& form = forms[second_phase ? 0 : k];
                         Candidate c;
                         if (best_form >= 0 && (uint64_t)held.mapped.bytes + rejects_bytes + one > hold_limit) break;   // (the best so far stays held while the next is measured: twice the pool, briefly)

@@ -348,6 +348,77 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     };
+    if (getenv("LAB_TIME")) {   // round 6, last question: is "fast" a property of the MEMORY a pool got, or of the MOMENT it is measured?  Pools made of per-frame 8 MB handles, probed (the 512-front
+        // shape), then churn (allocations made and freed, host work with the GPU idle), then the SAME pools probed again next to fresh ones, several rounds.
+        const int NF = F / 2;                                   // frames per pool (256: 2.1 GB)
+        const int T = 8192, tpf = (NBLK + T - 1) / T;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        struct Pool { void* va; size_t bytes; std::vector<hipMemGenericAllocationHandle_t> h; std::vector<uint32_t*> fr; };
+        const size_t HB = (size_t)8 << 20;
+        auto make = [&](Pool& p) {
+            p.bytes = (size_t)NF * HB;
+            CK(hipMemAddressReserve(&p.va, p.bytes, HB, nullptr, 0));
+            p.h.resize(NF);
+            for (int i = 0; i < NF; ++i) { CK(hipMemCreate(&p.h[i], HB, &prop, 0)); CK(hipMemMap((char*)p.va + (size_t)i * HB, HB, 0, p.h[i], 0)); }
+            hipMemAccessDesc acc{};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            CK(hipMemSetAccess(p.va, p.bytes, &acc, 1));
+            p.fr.resize(NF);
+            for (int i = 0; i < NF; ++i) p.fr[i] = (uint32_t*)((char*)p.va + (size_t)i * HB);
+        };
+        auto drop = [&](Pool& p) { (void)hipMemUnmap(p.va, p.bytes); for (auto h : p.h) (void)hipMemRelease(h); (void)hipMemAddressFree(p.va, p.bytes); };
+        auto probe = [&](const Pool& p) {
+            CK(hipMemcpy(d_table, p.fr.data(), sizeof(uint32_t*) * NF, hipMemcpyHostToDevice));
+            auto launch = [&] { hipLaunchKernelGGL(front_kernel, dim3(tpf * NF), dim3(256), 0, 0, d_table, NF, T, tpf, 1); };
+            launch();
+            CK(hipDeviceSynchronize());
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                float ms = 0;
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 3; ++i) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms / 3 < best ? ms / 3 : best;
+            }
+            return (double)NF * FRAME_BYTES / best / 1e6;
+        };
+        std::vector<Pool> kept(4);
+        printf("four pools of %d frames made one after the other and kept:", NF);
+        for (auto& p : kept) { make(p); printf(" %5.0f", probe(p)); }
+        printf(" GB/s\n");
+        for (int round = 0; round < 6; ++round) {
+            // churn: what a bench leg does between pools — big allocations made and freed, pinned host memory, then the host busy and the GPU idle
+            {
+                std::vector<void*> junk;
+                for (int i = 0; i < 24; ++i) { void* d = nullptr; if (hipMalloc(&d, (size_t)(64 + 37 * i) << 20) == hipSuccess) junk.push_back(d); }
+                void* hp = nullptr;
+                (void)hipHostMalloc(&hp, (size_t)512 << 20, hipHostMallocDefault);
+                for (size_t i = 0; i < junk.size(); i += 2) (void)hipFree(junk[i]);
+                timespec ts{(round % 3 == 2) ? 4 : 1, 0};        // (every third round: four seconds of idle)
+                nanosleep(&ts, nullptr);
+                for (size_t i = 1; i < junk.size(); i += 2) (void)hipFree(junk[i]);
+                if (hp) (void)hipHostFree(hp);
+            }
+            printf("round %d (after churn%s): the kept pools again:", round, round % 3 == 2 ? " + 4 s idle" : "");
+            for (auto& p : kept) printf(" %5.0f", probe(p));
+            Pool fresh[3];
+            printf(" | three fresh pools (held together):");
+            for (auto& p : fresh) { make(p); printf(" %5.0f", probe(p)); }
+            printf(" | the kept pools once more:");
+            for (auto& p : kept) printf(" %5.0f", probe(p));
+            printf(" GB/s\n");
+            fflush(stdout);
+            for (auto& p : fresh) drop(p);
+        }
+        for (auto& p : kept) drop(p);
+        return 0;
+    }
     if (getenv("LAB_VMM")) {   // round 6: the pool built from hipMemCreate handles mapped into one VA range — holds exactly the pool; does an arrangement of the handles match the dealt hipMalloc pool?
         // three store shapes per arrangement: the 512 write fronts (what jsp_pool_create probes with), band-walking waves (the ScreenPressor key-frame kernel's), frame-walking workgroups (the group kernels')
         auto rates = [&](const char* what, const std::vector<uint32_t*>& fr, double setup_ms, double held_x) {
