@@ -464,7 +464,7 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     int best_form = -1;
                     double best_rate = 0;
                     Candidate held;
-                    std::vector<Candidate> rejects;            // (second phase only) mapped candidates kept allocated so that the next one is made of OTHER memory
+                    std::vector<Candidate> rejects;            // mapped candidates kept allocated so that the next one is made of OTHER memory
                     uint64_t rejects_bytes = 0;
                     // Phase one: the three arrangements, the best so far held while the next is measured.  Phase two, while none has come within 3 % of the plain fill:
                     // more candidates of the first arrangement, each made while the ones before it are still held — different physical memory every time.  What a pool
@@ -500,11 +500,11 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         if (c.rate > best_rate) { best_rate = c.rate; best_form = k; loser = std::move(held); held = std::move(c); c.mapped = jsp::MappedRange{}; }
                         else { loser = std::move(c); c.mapped = jsp::MappedRange{}; }
                         if (good) { release(loser); break; }
-                        if (k >= 2 && !loser.mapped.empty()) {  // from here on what is rejected stays allocated until the search ends
+                        if (!loser.mapped.empty()) {           // what is rejected stays allocated until the search ends: the next candidate is then made of other memory
                             rejects_bytes += loser.mapped.bytes;
                             rejects.push_back(std::move(loser));
                             loser.mapped = jsp::MappedRange{};
-                        } else release(loser);
+                        }
                     }
                     for (auto& r : rejects) release(r);
                     if (best_form < 0) slab_yardstick();        // (no mapped form could be made: the older forms are held against a slab's fill)
