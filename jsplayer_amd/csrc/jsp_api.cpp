@@ -473,7 +473,12 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                     // fresh pools beside them 6.4 - 6.6 / 5.4 / 5.5 by their place in the order of allocation) — unless the whole board is in its slow state
                     // (r06_time_lab_slow_state.txt: everything 5.4 - 5.8, kept or fresh).  So the best of up to nine is worth ~10 ms apiece (a millisecond to make, a
                     // probe launch) and a transient hold of up to nine pools within the hold limit; a hipMalloc candidate cost half a second.
-                    for (int k = 0; k < 9 && !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates; ++k) {   // (three arrangements, then at most six more of the first)
+                    // ... and within a time budget (JSP_POOL_PROBE_MS, default 250): a physical allocation is usually made in microseconds, but right after gigabytes have been
+                    // given back the driver can take half a second over the next ones (a pool's search once took 1.7 s that way: profiles/r06_w_pool_probe_log.txt)
+                    double budget_ms = 250.0;
+                    if (const char* b = std::getenv("JSP_POOL_PROBE_MS")) budget_ms = std::max(0.0, std::atof(b));
+                    auto spent_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - probe_t0).count(); };
+                    for (int k = 0; k < 9 && !(m && std::atoi(m) == 0) && (int)p->tried.size() < kCandidates && (k < 3 || spent_ms() < budget_ms); ++k) {   // (three arrangements, then at most six more of the first)
                         const bool second_phase = k >= 3;
                         if (second_phase && !(yardstick > 0 && best_rate < 0.97 * yardstick)) break;   // (unreachable: a candidate that good ended the loop; kept for the reader)
                         const Form& form = forms[second_phase ? 0 : k];
@@ -516,7 +521,8 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         // that to nine mapped candidates is in its slow state; ONE run of hipMalloc chunks (four candidates out of one run of allocations, the
                         // first form of round 5: half a second) is still tried there, as a last resort, and then the best of all is kept.
                         settled = yardstick > 0 && best_rate >= (thorough ? 0.97 : 0.9) * yardstick;
-                        last_resort = !thorough && !settled;
+                        last_resort = !thorough && !settled && spent_ms() < budget_ms;
+                        if (!thorough && !settled && !last_resort) settled = true;   // (out of time: the best so far it is)
                     }
                 }
                 int hint = pool_form_hint(device_id)->load();
