@@ -517,12 +517,12 @@ jsp_pool* jsp_pool_create(int device_id, int width, int height, int nbuf) {
                         cands.push_back(std::move(held));
                         held.mapped = jsp::MappedRange{};
                         best = 0;
-                        // good enough: within 3 % of the plain fill on request (JSP_POOL_PROBE_THOROUGH), within a tenth of it otherwise.  A board that gives less than
-                        // that to nine mapped candidates is in its slow state; ONE run of hipMalloc chunks (four candidates out of one run of allocations, the
-                        // first form of round 5: half a second) is still tried there, as a last resort, and then the best of all is kept.
-                        settled = yardstick > 0 && best_rate >= (thorough ? 0.97 : 0.9) * yardstick;
-                        last_resort = !thorough && !settled && spent_ms() < budget_ms;
-                        if (!thorough && !settled && !last_resort) settled = true;   // (out of time: the best so far it is)
+                        // The search ends here with the best of the mapped candidates.  (On request, JSP_POOL_PROBE_THOROUGH=1, and unless that best is within 3 % of the
+                        // plain fill, the hipMalloc forms of rounds 3 - 5 are tried after it.  An earlier version of this round tried one run of hipMalloc chunks as a last
+                        // resort whenever nine mapped candidates stayed a tenth under the fill: on boards in their slow state — the only ones where that happens — it cost
+                        // 0.4 - 1 s per pool and never found anything, profiles/r06_y_bench_default_final_slow_state_board.json.)
+                        settled = !thorough || (yardstick > 0 && best_rate >= 0.97 * yardstick);
+                        last_resort = false;
                     }
                 }
                 int hint = pool_form_hint(device_id)->load();
